@@ -1,0 +1,168 @@
+"""ORACLE (test infrastructure): numpy/ctypes front-end of oracle/libff_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package fermiflow_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FfoNet(C.Structure):
+    _fields_ = [("He", C.c_int), ("ew1", C.c_void_p), ("eb1", C.c_void_p), ("ew2", C.c_void_p),
+                ("Hm", C.c_int), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "libff_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Net:
+    """eta = (w1, b1, w2) each (H,), mu likewise or None."""
+
+    def __init__(self, eta, mu=None):
+        self.e = [_d(np.reshape(a, -1)) for a in eta]
+        self.m = [_d(np.reshape(a, -1)) for a in mu] if mu is not None else None
+        self.c = FfoNet(len(self.e[0]), _p(self.e[0]), _p(self.e[1]), _p(self.e[2]),
+                        len(self.m[0]) if self.m else 0,
+                        _p(self.m[0]) if self.m else None, _p(self.m[1]) if self.m else None,
+                        _p(self.m[2]) if self.m else None)
+
+    @property
+    def nparams(self):
+        return 3 * self.c.He + 3 * self.c.Hm
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _tables(nup, ndn, tab_up, tab_dn):
+    tu = _i(np.arange(nup) if tab_up is None else tab_up).reshape(-1, max(nup, 1)) if nup else None
+    td = _i(np.arange(ndn) if tab_dn is None else tab_dn).reshape(-1, max(ndn, 1)) if ndn else None
+    return tu, td
+
+
+def num_threads():
+    return lib().ffo_num_threads()
+
+
+def orbitals(k, pts):
+    k = _i(k); pts = _d(pts).reshape(-1, 2)
+    out = np.empty((len(k), len(pts)))
+    st = lib().ffo_orbitals(_p(k), len(k), _p(pts), len(pts), _p(out))
+    assert st == 0
+    return out
+
+
+def logprob(x, nup, ndn, tab_up=None, tab_dn=None, wstate=None, derivs=True):
+    x = _d(x); B = x.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    logp = np.empty(B); grad = np.empty_like(x) if derivs else None; lap = np.empty(B) if derivs else None
+    st = lib().ffo_logprob(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), _p(x), _p(logp), _p(grad), _p(lap))
+    assert st == 0
+    return (logp, grad, lap) if derivs else logp
+
+
+def mcmc_noise(g0, g, u, nup, ndn, tau=0.1, tab_up=None, tab_dn=None, wstate=None):
+    g0, g, u = _d(g0), _d(g), _d(u)
+    B = g0.shape[0]; steps = g.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    x = np.empty_like(g0); logp = np.empty(B); acc = np.empty((steps, B), dtype=np.uint8)
+    st = lib().ffo_mcmc_noise(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), steps, C.c_double(tau),
+                              _p(g0), _p(g), _p(u), _p(x), _p(logp), _p(acc))
+    assert st == 0
+    return x, logp, acc
+
+
+def backflow(x, net):
+    x = _d(x); B, n, d = x.shape
+    v = np.empty_like(x); div = np.empty(B)
+    st = lib().ffo_backflow(C.c_int64(B), n, d, net.ref(), _p(x), _p(v), _p(div))
+    assert st == 0
+    return v, div
+
+
+def potential(x, Z, use_ho=True):
+    x = _d(x); B, n, d = x.shape
+    V = np.empty(B)
+    lib().ffo_potential(C.c_int64(B), n, d, C.c_double(Z), int(use_ho), _p(x), _p(V))
+    return V
+
+
+def cnf_generate(z, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    z = _d(z); B, n, d = z.shape
+    x = np.empty_like(z); nfev = C.c_int(0)
+    st = lib().ffo_cnf_generate(C.c_int64(B), n, d, net.ref(), C.c_double(t0), C.c_double(t1), C.c_double(rtol),
+                                C.c_double(atol), _p(z), _p(x), C.byref(nfev))
+    assert st == 0, st
+    return x, nfev.value
+
+
+def cnf_delta_logp(x, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    x = _d(x); B, n, d = x.shape
+    z = np.empty_like(x); dl = np.empty(B); nfev = C.c_int(0)
+    st = lib().ffo_cnf_delta_logp(C.c_int64(B), n, d, net.ref(), C.c_double(t0), C.c_double(t1), C.c_double(rtol),
+                                  C.c_double(atol), _p(x), _p(z), _p(dl), C.byref(nfev))
+    assert st == 0, st
+    return z, dl, nfev.value
+
+
+def cnf_adjoint(z_t0, dlogp_t0, a_z, a_d, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    z_t0, dlogp_t0, a_z, a_d = _d(z_t0), _d(dlogp_t0), _d(a_z), _d(a_d)
+    B, n, d = z_t0.shape
+    gx = np.empty_like(z_t0); gp = np.empty(net.nparams); nfev = C.c_int(0)
+    st = lib().ffo_cnf_adjoint(C.c_int64(B), n, d, net.ref(), C.c_double(t0), C.c_double(t1), C.c_double(rtol),
+                               C.c_double(atol), _p(z_t0), _p(dlogp_t0), _p(a_z), _p(a_d), _p(gx), _p(gp), C.byref(nfev))
+    assert st == 0, st
+    return gx, gp, nfev.value
+
+
+def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None):
+    x = _d(x); B = x.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    logp = np.empty(B); grad = np.empty_like(x); lap = np.empty(B); V = np.empty(B); el = np.empty(B)
+    st = lib().ffo_eloc(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), net.ref(), C.c_double(t0), C.c_double(t1),
+                        C.c_double(rtol), C.c_double(atol), C.c_double(Z), int(use_ho), _p(x),
+                        _p(logp), _p(grad), _p(lap), _p(V), _p(el))
+    assert st == 0, st
+    return dict(logp=logp, grad=grad, lap=lap, V=V, eloc=el)
+
+
+def gsvmc_sweep(B, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=100, tau=0.1, seed=0):
+    E = C.c_double(); Es = C.c_double(); gE = C.c_double()
+    gp = np.empty(net.nparams); tm = np.empty(5)
+    st = lib().ffo_gsvmc_sweep(C.c_int64(B), nup, ndn, net.ref(), C.c_double(t0), C.c_double(t1), C.c_double(rtol),
+                               C.c_double(atol), C.c_double(Z), int(use_ho), steps, C.c_double(tau), C.c_uint64(seed),
+                               C.byref(E), C.byref(Es), C.byref(gE), _p(gp), _p(tm))
+    assert st == 0, st
+    return dict(E=E.value, E_std=Es.value, gradE=gE.value, grad_params=gp,
+                seconds=dict(zip(("mcmc", "generate", "logp_full", "eloc", "backward"), tm.tolist())))
