@@ -1,0 +1,112 @@
+"""ctypes binding of libfermiflow_hip.so (the C ABI declared in include/fermiflow.h).
+
+The library is the product: if it is missing, or a tensor is not a contiguous fp64 CUDA tensor, the
+calls raise -- there is no CPU or PyTorch fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfermiflow_hip.so")
+_LIB = None
+
+SYMBOLS = [
+    "ff_version", "ff_last_error", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
+    "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential",
+    "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint",
+    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments",
+]
+
+
+class FFNet(C.Structure):
+    _fields_ = [("He", C.c_int32), ("ew1", C.c_void_p), ("eb1", C.c_void_p), ("ew2", C.c_void_p),
+                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p)]
+
+
+class FFOde(C.Structure):
+    _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_steps", C.c_int32)]
+
+
+def lib():
+    """Load the HIP library (once). Raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP kernels first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C fermiflow_amd/csrc). fermiflow_amd has no CPU fallback.")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.ff_last_error.restype = C.c_char_p
+        _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
+        _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
+    return _LIB
+
+
+def check(status, what):
+    if status == 0:
+        return
+    msg = lib().ff_last_error().decode()
+    if status == 1:
+        raise ValueError(f"{what}: {msg}")
+    if status == 2:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: HIP failure: {msg}")
+
+
+def dev(t, dtype=torch.float64, name="tensor"):
+    """Validate a tensor for the C ABI and return it (contiguous)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device (got {t.device}); fermiflow_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i64(v):
+    return C.c_int64(int(v))
+
+
+def f64(v):
+    return C.c_double(float(v))
+
+
+class Net:
+    """Device pointers of the backflow's two scalar MLPs (keeps the tensors alive)."""
+
+    def __init__(self, eta, mu=None):
+        self.t = []
+
+        def three(m):
+            ws = (dev(m.fc1.weight.detach().reshape(-1)), dev(m.fc1.bias.detach()), dev(m.fc2.weight.detach().reshape(-1)))
+            self.t.extend(ws)
+            return ws
+        e = three(eta)
+        m = three(mu) if mu is not None else (None, None, None)
+        self.He = e[0].numel()
+        self.Hm = m[0].numel() if mu is not None else 0
+        self.c = FFNet(self.He, ptr(e[0]), ptr(e[1]), ptr(e[2]), self.Hm, ptr(m[0]), ptr(m[1]), ptr(m[2]))
+        self.device = e[0].device
+
+    @property
+    def nparams(self):
+        return 3 * self.He + 3 * self.Hm
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def ode(t0, t1, rtol, atol, max_steps=0):
+    return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps))

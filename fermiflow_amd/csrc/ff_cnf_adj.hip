@@ -1,0 +1,444 @@
+// ff_cnf_adj.hip -- fused adjoint of CNF.delta_logp: SolveIVP.backward with F_augFull
+// (src/NeuralODE/nnModule.py:76-133), i.e. the theta-gradient pass of `gradE.backward()`
+// (src/FermionHO2D.py:71) and the x-gradient of log p.
+//
+// Augmented system integrated from t0 to t1 per walker (a_D is constant in time):
+//     dz/dt      = v(z)
+//     da_z/dt    = -(dv/dz)^T a_z + a_D grad_z div v          (dv/dz is symmetric: v is a gradient field)
+//     dtheta*/dt = -d/dtheta [ a_z . v(z) - a_D div v(z) ]     (a pure quadrature, summed over walkers)
+//
+// Mapping: lane (g,i) owns coordinate i of walker g AND the hidden units k = i, i+M, i+2M, ... of eta and mu.
+// In the "unit phase" a lane evaluates its own sigmoids at every radius of its walker; per radius the
+// partial derivative heads of its units go to LDS (reduced over the group's M lanes afterwards) while the
+// parameter-gradient integrands stay in the lane's registers, so the 3*(He+Hm)-wide reduction over
+// radii, stages, steps and walkers needs no cross-lane traffic until the kernel's last instruction.
+// Rejected steps simply drop the lane-private tentative sums.
+#include "ff_common.h"
+#include "ff_ode.h"
+
+struct ff_adj_args {
+  int64_t B;
+  ff_net net;
+  double ta, tb, rtol, atol;
+  int max_steps;
+  const double* z_in;   // (B, M)  z(t0)
+  const double* az_in;  // (B, M)  incoming gradient wrt z(t0)
+  const double* ad_in;  // (B)     incoming gradient wrt Delta
+  double* gx_out;       // (B, M)  gradient wrt x = z(t1); may be NULL
+  double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials
+  int32_t* stats;
+};
+
+template <int N, int D>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_ode_adj_kernel(ff_adj_args A) {
+  using Gm = ff_geom<N, D>;
+  constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
+  constexpr int MAXU = (FF_HMAX + M - 1) / M;  // hidden units owned per lane and net
+  constexpr int NV = 2;
+
+  __shared__ ff_wtab s_w[2][FF_HMAX];
+  __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G];
+  __shared__ double s_rad[G][R], s_rinv[G][R], s_ca[G][R], s_cb[G][R];
+  __shared__ double s_ph[G][M][R][3], s_hd[G][R][3];
+  __shared__ int s_pa[R], s_pb[R], s_any;
+
+  const int lane = threadIdx.x;
+  const int g = lane / M, i = lane % M;
+  const bool ingrp = g < G;
+  const int gg = ingrp ? g : 0;
+  const int ai = i / D, ci = i % D;
+
+  ff_load_weights(s_w, A.net, lane);
+  if (lane == 0) {
+    int p = 0;
+    for (int a = 0; a < N; a++)
+      for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
+    for (int a = 0; a < N; a++) { if (P + a < R) { s_pa[P + a] = a; s_pb[P + a] = -1; } }
+  }
+  __syncthreads();
+  const int He = A.net.He, Hm = A.net.Hm;
+  const bool has_mu = Hm > 0;
+  const int nrad = has_mu ? (P + N) : P;
+  const double rtol = A.rtol, atol = A.atol;
+  constexpr double NT = 2 * M;
+  const int64_t ngroups = (A.B + G - 1) / G;
+  long long ev_sum = 0;
+  int acc_max = 0, rej_sum = 0, fail_any = 0;
+
+  // parameter-gradient accumulators of this lane's units: [net][unit][w1,b1,w2]
+  double fin[2][MAXU][3];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int j = 0; j < MAXU; j++) fin[t][j][0] = fin[t][j][1] = fin[t][j][2] = 0.0;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t b = grp * G + g;
+    const bool valid = ingrp && b < A.B;
+    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV], yn[NV];
+    y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
+    y[1] = valid ? A.az_in[b * M + i] : 0.0;
+    if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
+    double tent[2][MAXU][3], fsal[2][MAXU][3];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int j = 0; j < MAXU; j++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { tent[t][j][c] = 0.0; fsal[t][j][c] = 0.0; }
+    ff_stepper S;
+    S.begin(A.ta, A.tb, valid);
+    int s = -2, nev = 0;
+    double h0v = 0.0, d1v = 0.0;
+
+    auto group_sum = [&](double part) -> double {
+      if (ingrp) s_err[g][i] = part;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; j++) t += s_err[gg][j];
+      __syncthreads();
+      return t;
+    };
+
+#pragma unroll 1
+    for (;;) {
+      double in[NV];
+      const double h = S.h;
+      switch (s) {
+        case -2:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = y[v];
+          break;
+        case -1:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h0v * S.dir, k0[v], y[v]);
+          break;
+        case 1:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h * FF_A10, k0[v], y[v]);
+          break;
+        case 2:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
+          break;
+        case 3:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
+          break;
+        case 4:
+#pragma unroll
+          for (int v = 0; v < NV; v++)
+            in[v] = fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
+          break;
+        case 5:
+#pragma unroll
+          for (int v = 0; v < NV; v++)
+            in[v] = fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
+          break;
+        default:
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            yn[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
+            in[v] = yn[v];
+          }
+          break;
+      }
+      // ------------------------------------------------------------------ publish z_i, a_i
+      __syncthreads();
+      if (ingrp) { s_z[g][i] = in[0]; s_kb[g][i] = in[1]; }
+      __syncthreads();
+      // ------------------------------------------------------------------ radius set-up (lane <-> radius)
+      for (int q = lane; q < G * nrad; q += FF_WAVE) {
+        const int qg = q / nrad, p = q - qg * nrad;
+        const int a = s_pa[p], bb = s_pb[p];
+        double r2 = 0.0, al = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          const double rho = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
+          const double dl = s_kb[qg][a * D + c] - (bb >= 0 ? s_kb[qg][bb * D + c] : 0.0);
+          r2 = fma(rho, rho, r2);
+          al = fma(dl, rho, al);
+        }
+        const double r = sqrt(r2), ad = s_ad[qg];
+        s_rad[qg][p] = r;
+        s_rinv[qg][p] = ff_rcp(r);
+        // integrand of the parameter adjoint is  ca * df(r)/dtheta + cb * df'(r)/dtheta
+        s_ca[qg][p] = bb >= 0 ? -(al - 2.0 * D * ad) : -(al - D * ad);
+        s_cb[qg][p] = bb >= 0 ? 2.0 * ad * r : ad * r;
+      }
+      __syncthreads();
+      nev++;
+      // ------------------------------------------------------------------ unit phase
+      double cur[2][MAXU][3];
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int j = 0; j < MAXU; j++) cur[t][j][0] = cur[t][j][1] = cur[t][j][2] = 0.0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int H = t ? Hm : He;
+        const int p_lo = t ? P : 0, p_hi = t ? nrad : P;
+        for (int p = p_lo; p < p_hi; p++) {
+          const double r = s_rad[gg][p], ca = s_ca[gg][p], cb = s_cb[gg][p];
+          double h0 = 0.0, h1 = 0.0, h2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < MAXU; j++) {
+            const int k = i + j * M;
+            if (k < H) {
+              const ff_wtab w = s_w[t][k];
+              const double sg = ff_sigmoid(fma(w.w1, r, w.b1));
+              const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
+              h0 = fma(w.w2, sg, h0);
+              h1 = fma(w.w2w1, s1, h1);
+              h2 = fma(w.w2w1_2, s2, h2);
+              const double w1rs2 = w.w1 * r * s2;
+              cur[t][j][0] += w.w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
+              cur[t][j][1] += fma(ca * w.w2, s1, cb * w.w2w1 * s2);
+              cur[t][j][2] += fma(ca, sg, cb * w.w1 * s1);
+            }
+          }
+          if (ingrp) { s_ph[g][i][p][0] = h0; s_ph[g][i][p][1] = h1; s_ph[g][i][p][2] = h2; }
+        }
+      }
+      __syncthreads();
+      // reduce the partial heads over the group's lanes
+      for (int e = i; e < nrad * 3; e += M) {
+        const int p = e / 3, m = e - 3 * p;
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < M; l++) t += s_ph[gg][l][p][m];
+        if (ingrp) s_hd[g][p][m] = t;
+      }
+      __syncthreads();
+      // ------------------------------------------------------------------ component phase
+      double out[NV];
+      {
+        const double* sz = s_z[gg];
+        const double* sl = s_kb[gg];
+        double vi = 0.0, dvk = 0.0, gdi = 0.0;
+        for (int bq = 0; bq < N; bq++) {
+          if (bq == ai) continue;
+          const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
+          const int p = ff_pair_index(N, lo, hi);
+          const double rc = sz[ai * D + ci] - sz[bq * D + ci];
+          const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2];
+          double rdk = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c] - sz[bq * D + c], sl[ai * D + c] - sl[bq * D + c], rdk);
+          const double ri = s_rinv[gg][p], r1 = rdk * ri;
+          vi = fma(f0, rc, vi);
+          dvk += fma(f1 * r1, rc, f0 * (sl[ai * D + ci] - sl[bq * D + ci]));
+          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
+          gdi = fma(2.0 * sp * ri, rc, gdi);
+        }
+        if (has_mu) {
+          const int p = P + ai;
+          const double rc = sz[ai * D + ci];
+          const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2];
+          double rdk = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c], sl[ai * D + c], rdk);
+          const double ri = s_rinv[gg][p], r1 = rdk * ri;
+          vi = fma(f0, rc, vi);
+          dvk += fma(f1 * r1, rc, f0 * sl[ai * D + ci]);
+          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
+          gdi = fma(sp * ri, rc, gdi);
+        }
+        out[0] = vi;
+        out[1] = fma(s_ad[gg], gdi, -dvk);
+      }
+      // ------------------------------------------------------------------ consume
+      if (s == -2) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k0[v] = out[v];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int j = 0; j < MAXU; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) fsal[t][j][c] = cur[t][j][c];
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double isc = 1.0 / (atol + fabs(y[v]) * rtol);
+          p0 = fma(y[v] * isc, y[v] * isc, p0);
+          p1 = fma(k0[v] * isc, k0[v] * isc, p1);
+        }
+        const double d0 = sqrt(group_sum(p0) / NT);
+        d1v = sqrt(group_sum(p1) / NT);
+        h0v = S.h0(d0, d1v);
+        s = -1;
+      } else if (s == -1) {
+        double p2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double t = (out[v] - k0[v]) / (atol + fabs(y[v]) * rtol);
+          p2 = fma(t, t, p2);
+        }
+        const double d2 = sqrt(group_sum(p2) / NT) / h0v;
+        S.init_habs(h0v, d1v, d2);
+        S.plan();
+        s = 1;
+      } else if (s >= 1 && s <= 5) {
+        const double bw = s == 1 ? 0.0 : (s == 2 ? FF_B2 : (s == 3 ? FF_B3 : (s == 4 ? FF_B4 : FF_B5)));
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int j = 0; j < MAXU; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) tent[t][j][c] = fma(bw, cur[t][j][c], tent[t][j][c]);
+        if (s == 1) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) k1[v] = out[v];
+        } else if (s == 2) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) k2[v] = out[v];
+        } else if (s == 3) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) k3[v] = out[v];
+        } else if (s == 4) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) k4[v] = out[v];
+        } else {
+#pragma unroll
+          for (int v = 0; v < NV; v++) k5[v] = out[v];
+        }
+        s++;
+      } else {
+        double pe = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
+          const double t = e / (atol + fmax(fabs(y[v]), fabs(yn[v])) * rtol);
+          pe = fma(t, t, pe);
+        }
+        const double err = sqrt(group_sum(pe) / NT);
+        const bool acc = S.decide(err, A.max_steps);
+        if (acc) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) { y[v] = yn[v]; k0[v] = out[v]; }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int j = 0; j < MAXU; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              if (acc) {
+                fin[t][j][c] = fma(h, fma(FF_B0, fsal[t][j][c], tent[t][j][c]), fin[t][j][c]);
+                fsal[t][j][c] = cur[t][j][c];
+              }
+              tent[t][j][c] = 0.0;
+            }
+        S.plan();
+        if (lane == 0) s_any = 0;
+        __syncthreads();
+        if (!S.done) s_any = 1;
+        __syncthreads();
+        const int any = s_any;
+        if (!any) break;
+        s = 1;
+      }
+    }
+    if (valid) {
+      if (A.gx_out) A.gx_out[b * M + i] = y[1];
+      if (i == 0) {
+        ev_sum += nev;
+        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
+        rej_sum += S.nrej;
+        fail_any |= S.fail;
+      }
+    }
+    __syncthreads();
+  }
+  // per-(workgroup, group-slot) rows; summed deterministically by ff_rows_reduce_kernel
+  if (ingrp) {
+    double* row = A.rows + ((int64_t)blockIdx.x * G + g) * (3 * He + 3 * Hm);
+#pragma unroll
+    for (int j = 0; j < MAXU; j++) {
+      const int k = i + j * M;
+      if (k < He) { row[k] = fin[0][j][0]; row[He + k] = fin[0][j][1]; row[2 * He + k] = fin[0][j][2]; }
+      if (k < Hm) { row[3 * He + k] = fin[1][j][0]; row[3 * He + Hm + k] = fin[1][j][1]; row[3 * He + 2 * Hm + k] = fin[1][j][2]; }
+    }
+  }
+  if (A.stats && (ev_sum || fail_any)) {
+    atomicAdd(&A.stats[0], (int)ev_sum);
+    atomicMax(&A.stats[1], acc_max);
+    atomicAdd(&A.stats[2], rej_sum);
+    if (fail_any) atomicMax(&A.stats[3], 1);
+  }
+}
+
+__global__ void __launch_bounds__(64)
+ff_rows_reduce_kernel(int nrows, int P, const double* __restrict__ rows, double* __restrict__ out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  double s = 0.0;
+  for (int r = 0; r < nrows; r++) s += rows[(int64_t)r * P + k];
+  out[k] = s;
+}
+
+// =================================================================================================
+extern void ff_set_error(const char* msg);
+#define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
+#define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
+
+#ifndef FF_PERSIST_BLOCKS
+#define FF_PERSIST_BLOCKS 2048
+#endif
+
+static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? FF_WAVE / M : 0; }
+static unsigned adj_grid(int64_t B, int G) {
+  int64_t ngroups = (B + G - 1) / G;
+  return (unsigned)(ngroups < FF_PERSIST_BLOCKS ? ngroups : FF_PERSIST_BLOCKS);
+}
+
+template <int N, int D>
+static void launch_adj(void* stream, const ff_adj_args& a) {
+  FF_LAUNCH((ff_ode_adj_kernel<N, D>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+}
+
+extern "C" {
+
+size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
+  int G = adj_G(n, d);
+  if (G == 0 || B <= 0) return 0;
+  return sizeof(double) * (size_t)adj_grid(B, G) * G * (size_t)(3 * He + 3 * Hm);
+}
+
+int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
+                   const double* a_z, const double* a_d, double* grad_x, double* grad_params, void* workspace,
+                   int32_t* stats) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode && grad_params, FF_EINVAL, "ff_cnf_adjoint: bad argument");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_cnf_adjoint: bad net");
+  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf_adjoint: hidden width > 64");
+  FF_CHECK(ode->rtol > 0 && ode->atol > 0, FF_EINVAL, "ff_cnf_adjoint: tolerances must be positive");
+  const int P = 3 * net->He + 3 * net->Hm;
+  if (B == 0) {
+    if (hipMemsetAsync(grad_params, 0, sizeof(double) * P, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+    return FF_OK;
+  }
+  FF_CHECK(z_t0 && a_z && a_d && workspace, FF_EINVAL, "ff_cnf_adjoint: null pointer");
+  ff_adj_args a = {};
+  a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
+  a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  int G = 0;
+#define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
+  FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2)
+#undef FF_ND
+  if (G == 0) {
+    ff_set_error("fused CNF kernels are instantiated for (n,d) in {(2,2),(3,2),(4,2),(6,2),(12,2)}");
+    return FF_EUNSUPPORTED;
+  }
+  FF_LAUNCH_CHECK();
+  const int nrows = (int)adj_grid(B, G) * G;
+  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)((P + 63) / 64), 64, stream, nrows, P, (const double*)workspace, grad_params);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,613 @@
+// ff_cnf_fwd.hip -- fused forward CNF integrations:
+//   MODE 0  CNF.generate      (src/flow.py:42-44)     state z                      heads eta
+//   MODE 1  CNF.delta_logp    (src/flow.py:51-55)     state (z, Delta)             heads eta, eta'
+//   MODE 2  local-energy pass (src/VMC.py:46-49, replaces the 2+2*n*d nested adjoint solves of
+//           src/utils.py:40-65)  state (z, J = dz/dx, kbar = lap_x z, Delta, grad_x Delta, lap_x Delta)
+//                                                                                heads eta .. eta'''
+// All of one walker's stages, error control and accept/reject happen on chip; HBM sees the walker's
+// coordinates once on the way in and the results once on the way out.
+//
+// Per RHS evaluation (all lanes of the wave):
+//   1. every lane publishes its stage value z_i (and kbar_i) to LDS;
+//   2. "radius phase": the wave's G*R radii (pairs r_ab, one-body r_a) are dealt one per lane; a lane
+//      evaluates the H sigmoids of eta (or mu) at its radius and leaves the NH derivative heads in LDS;
+//   3. "jet phase" (MODE 2): lane (g,i) pushes its direction u_i = dz/dx_i through every pair term as a
+//      2nd-order Taylor jet (first-order part -> dJ/dt column, quadratic part -> source of kbar and lap Delta);
+//   4. "component phase": lane (g,i) assembles v_i, (Dv[kbar])_i, (grad div)_i from the heads of the pairs
+//      its particle takes part in.
+#include "ff_common.h"
+#include "ff_ode.h"
+#include "ff_slater.h"
+
+struct ff_fwd_args {
+  int64_t B;
+  ff_net net;
+  double ta, tb, rtol, atol;
+  int max_steps;
+  const double* y_in;   // (B, M)
+  double* y_out;        // (B, M)   z(tb)
+  double* dl_out;       // (B)      Delta(tb)                  MODE >= 1
+  double* Jt;           // (B, M, M) Jt[b][i][k] = dz_k/dx_i   MODE 2
+  double* kbar;         // (B, M)
+  double* dD;           // (B, M)   d Delta / d x_i
+  double* Lpart;        // (B, M)   per-direction parts of lap_x Delta
+  int32_t* stats;
+};
+
+template <int N, int D, int MODE>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_ode_fwd_kernel(ff_fwd_args A) {
+  using Gm = ff_geom<N, D>;
+  constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
+  constexpr int NH = MODE == 0 ? 1 : (MODE == 1 ? 2 : 4);
+  constexpr int NV = MODE == 0 ? 1 : (MODE == 1 ? 2 : M + 5);
+  // state slots of a lane: [0] z_i; MODE1: [1] Delta; MODE2: [1..M] u_k = dz_k/dx_i, [M+1] kbar_i,
+  // [M+2] dDelta/dx_i, [M+3] Delta, [M+4] L_i
+  constexpr int IDL = MODE == 1 ? 1 : M + 3;  // slot of the replicated Delta
+
+  __shared__ ff_wtab s_w[2][FF_HMAX];
+  __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M];
+  __shared__ double s_rad[G][R], s_rinv[G][R], s_hd[G][R][NH];
+  __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
+  __shared__ int s_pa[R], s_pb[R], s_any;
+
+  const int lane = threadIdx.x;
+  const int g = lane / M, i = lane % M;
+  const bool ingrp = g < G;
+  const int gg = ingrp ? g : 0;  // safe LDS row for the idle tail lanes
+  const int ai = i / D, ci = i % D;
+
+  ff_load_weights(s_w, A.net, lane);
+  if (lane == 0) {
+    int p = 0;
+    for (int a = 0; a < N; a++)
+      for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
+    for (int a = 0; a < N; a++) { if (P + a < R) { s_pa[P + a] = a; s_pb[P + a] = -1; } }
+  }
+  __syncthreads();
+  const int He = A.net.He, Hm = A.net.Hm;
+  const bool has_mu = Hm > 0;
+  const int nrad = has_mu ? (P + N) : P;
+  const double rtol = A.rtol, atol = A.atol;
+  constexpr double NT = MODE == 0 ? M : (MODE == 1 ? M + 1 : M * (M + 4) + 1);
+  const int64_t ngroups = (A.B + G - 1) / G;
+  long long ev_sum = 0;
+  int acc_max = 0, rej_sum = 0, fail_any = 0;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t b = grp * G + g;
+    const bool valid = ingrp && b < A.B;
+    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV], yn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) y[v] = 0.0;
+    y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int k = 0; k < M; k++) y[1 + k] = (k == i) ? 1.0 : 0.0;
+    }
+    ff_stepper S;
+    S.begin(A.ta, A.tb, valid);
+    int s = -2, nev = 0;
+    double h0v = 0.0, d1v = 0.0;
+
+    // group-wide sum of a per-lane partial (all lanes of a walker get the identical result)
+    auto group_sum = [&](double part) -> double {
+      if (ingrp) s_err[g][i] = part;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; j++) t += s_err[gg][j];
+      __syncthreads();
+      return t;
+    };
+    auto wgt = [&](int v) -> double { return (MODE >= 1 && v == IDL && i != 0) ? 0.0 : 1.0; };  // Delta is replicated: count it once
+
+#pragma unroll 1
+    for (;;) {
+      // ------------------------------------------------------------------ stage input
+      double in[NV];
+      const double h = S.h;
+      switch (s) {
+        case -2:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = y[v];
+          break;
+        case -1:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h0v * S.dir, k0[v], y[v]);
+          break;
+        case 1:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h * FF_A10, k0[v], y[v]);
+          break;
+        case 2:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
+          break;
+        case 3:
+#pragma unroll
+          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
+          break;
+        case 4:
+#pragma unroll
+          for (int v = 0; v < NV; v++)
+            in[v] = fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
+          break;
+        case 5:
+#pragma unroll
+          for (int v = 0; v < NV; v++)
+            in[v] = fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
+          break;
+        default:
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            yn[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
+            in[v] = yn[v];
+          }
+          break;
+      }
+      // ------------------------------------------------------------------ publish
+      __syncthreads();
+      if (ingrp) {
+        s_z[g][i] = in[0];
+        if constexpr (MODE == 2) s_kb[g][i] = in[M + 1];
+      }
+      __syncthreads();
+      // ------------------------------------------------------------------ radius phase
+      for (int q = lane; q < G * nrad; q += FF_WAVE) {
+        const int qg = q / nrad, p = q - qg * nrad;
+        const int a = s_pa[p], bb = s_pb[p];
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          double t = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
+          r2 = fma(t, t, r2);
+        }
+        const double r = sqrt(r2);
+        double hd[NH];
+        ff_heads<NH>(s_w[bb >= 0 ? 0 : 1], bb >= 0 ? He : Hm, r, hd);
+        s_rad[qg][p] = r;
+        s_rinv[qg][p] = ff_rcp(r);
+#pragma unroll
+        for (int m = 0; m < NH; m++) s_hd[qg][p][m] = hd[m];
+      }
+      __syncthreads();
+      nev++;
+      // ------------------------------------------------------------------ right-hand side
+      double out[NV];
+      const double* sz = s_z[gg];
+      double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
+      if constexpr (MODE == 2) {
+        // jet phase: this lane's direction u = in[1..M]
+        double du[M], qv[M];
+#pragma unroll
+        for (int k = 0; k < M; k++) { du[k] = 0.0; qv[k] = 0.0; }
+        const double* u = &in[1];
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < N; a++) {
+#pragma unroll
+          for (int bq = a + 1; bq < N; bq++) {
+            double rho[D], dl[D], rd = 0.0, dd = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; c++) {
+              rho[c] = sz[a * D + c] - sz[bq * D + c];
+              dl[c] = u[a * D + c] - u[bq * D + c];
+              rd = fma(rho[c], dl[c], rd);
+              dd = fma(dl[c], dl[c], dd);
+            }
+            const double r = s_rad[gg][p], ri = s_rinv[gg][p];
+            const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2], f3 = s_hd[gg][p][3];
+            const double r1 = rd * ri, r1s = r1 * r1;
+            const double r2q = (dd - r1s) * ri;
+            const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+#pragma unroll
+            for (int c = 0; c < D; c++) {
+              const double g1 = fma(F1, rho[c], f0 * dl[c]);
+              const double g2 = fma(F2, rho[c], 2.0 * F1 * dl[c]);
+              du[a * D + c] += g1; du[bq * D + c] -= g1;
+              qv[a * D + c] += g2; qv[bq * D + c] -= g2;
+            }
+            const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
+            ddiv = fma(2.0 * sp, r1, ddiv);
+            qdiv += 2.0 * fma(spp, r1s, sp * r2q);
+            divv += 2.0 * fma(f1, r, D * f0);
+            p++;
+          }
+        }
+        if (has_mu) {
+#pragma unroll
+          for (int a = 0; a < N; a++) {
+            double rho[D], dl[D], rd = 0.0, dd = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; c++) {
+              rho[c] = sz[a * D + c];
+              dl[c] = u[a * D + c];
+              rd = fma(rho[c], dl[c], rd);
+              dd = fma(dl[c], dl[c], dd);
+            }
+            const int pp = P + a;
+            const double r = s_rad[gg][pp], ri = s_rinv[gg][pp];
+            const double f0 = s_hd[gg][pp][0], f1 = s_hd[gg][pp][1], f2 = s_hd[gg][pp][2], f3 = s_hd[gg][pp][3];
+            const double r1 = rd * ri, r1s = r1 * r1;
+            const double r2q = (dd - r1s) * ri;
+            const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+#pragma unroll
+            for (int c = 0; c < D; c++) {
+              du[a * D + c] += fma(F1, rho[c], f0 * dl[c]);
+              qv[a * D + c] += fma(F2, rho[c], 2.0 * F1 * dl[c]);
+            }
+            const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
+            ddiv = fma(sp, r1, ddiv);
+            qdiv += fma(spp, r1s, sp * r2q);
+            divv += fma(f1, r, D * f0);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < M; k++) out[1 + k] = du[k];
+        // transpose-reduce the quadratic sources: lane c needs sum_j qv_j[c]
+        if (ingrp) {
+#pragma unroll
+          for (int k = 0; k < M; k++) s_q[g][i][k] = qv[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < M; j++) sumq += s_q[gg][j][i];
+      } else if constexpr (MODE == 1) {
+        for (int p = 0; p < nrad; p++) {
+          const double c = p < P ? 2.0 : 1.0;
+          divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rad[gg][p], D * s_hd[gg][p][0]), divv);
+        }
+      }
+      // component phase: coordinate (ai, ci)
+      double vi = 0.0, dvk = 0.0, gdi = 0.0;
+      for (int bq = 0; bq < N; bq++) {
+        if (bq == ai) continue;
+        const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
+        const int p = ff_pair_index(N, lo, hi);
+        const double rc = sz[ai * D + ci] - sz[bq * D + ci];
+        const double f0 = s_hd[gg][p][0];
+        vi = fma(f0, rc, vi);
+        if constexpr (MODE == 2) {
+          double rdk = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; c++)
+            rdk = fma(sz[ai * D + c] - sz[bq * D + c], s_kb[gg][ai * D + c] - s_kb[gg][bq * D + c], rdk);
+          const double ri = s_rinv[gg][p], f1 = s_hd[gg][p][NH > 1 ? 1 : 0], f2 = s_hd[gg][p][NH > 2 ? 2 : 0];
+          const double r1 = rdk * ri;
+          dvk += fma(f1 * r1, rc, f0 * (s_kb[gg][ai * D + ci] - s_kb[gg][bq * D + ci]));
+          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
+          gdi = fma(2.0 * sp * ri, rc, gdi);
+        }
+      }
+      if (has_mu) {
+        const int p = P + ai;
+        const double rc = sz[ai * D + ci];
+        const double f0 = s_hd[gg][p][0];
+        vi = fma(f0, rc, vi);
+        if constexpr (MODE == 2) {
+          double rdk = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c], s_kb[gg][ai * D + c], rdk);
+          const double ri = s_rinv[gg][p], f1 = s_hd[gg][p][NH > 1 ? 1 : 0], f2 = s_hd[gg][p][NH > 2 ? 2 : 0];
+          const double r1 = rdk * ri;
+          dvk += fma(f1 * r1, rc, f0 * s_kb[gg][ai * D + ci]);
+          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
+          gdi = fma(sp * ri, rc, gdi);
+        }
+      }
+      out[0] = vi;
+      if constexpr (MODE == 1) out[1] = -divv;
+      if constexpr (MODE == 2) {
+        out[M + 1] = sumq + dvk;
+        out[M + 2] = -ddiv;
+        out[M + 3] = -divv;
+        out[M + 4] = -fma(gdi, in[M + 1], qdiv);
+      }
+      // ------------------------------------------------------------------ consume
+      if (s == -2) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k0[v] = out[v];
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double isc = wgt(v) / (atol + fabs(y[v]) * rtol);
+          p0 = fma(y[v] * isc, y[v] * isc, p0);
+          p1 = fma(k0[v] * isc, k0[v] * isc, p1);
+        }
+        const double d0 = sqrt(group_sum(p0) / NT);
+        d1v = sqrt(group_sum(p1) / NT);
+        h0v = S.h0(d0, d1v);
+        s = -1;
+      } else if (s == -1) {
+        double p2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double t = (out[v] - k0[v]) * wgt(v) / (atol + fabs(y[v]) * rtol);
+          p2 = fma(t, t, p2);
+        }
+        const double d2 = sqrt(group_sum(p2) / NT) / h0v;
+        S.init_habs(h0v, d1v, d2);
+        S.plan();
+        s = 1;
+      } else if (s == 1) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k1[v] = out[v];
+        s = 2;
+      } else if (s == 2) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k2[v] = out[v];
+        s = 3;
+      } else if (s == 3) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k3[v] = out[v];
+        s = 4;
+      } else if (s == 4) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k4[v] = out[v];
+        s = 5;
+      } else if (s == 5) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) k5[v] = out[v];
+        s = 6;
+      } else {
+        double pe = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
+          const double t = e * wgt(v) / (atol + fmax(fabs(y[v]), fabs(yn[v])) * rtol);
+          pe = fma(t, t, pe);
+        }
+        const double err = sqrt(group_sum(pe) / NT);
+        if (S.decide(err, A.max_steps)) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) { y[v] = yn[v]; k0[v] = out[v]; }
+        }
+        S.plan();
+        if (lane == 0) s_any = 0;
+        __syncthreads();
+        if (!S.done) s_any = 1;
+        __syncthreads();
+        const int any = s_any;
+        if (!any) break;
+        s = 1;
+      }
+    }
+    // ---------------------------------------------------------------------- results
+    if (valid) {
+      A.y_out[b * M + i] = y[0];
+      if constexpr (MODE >= 1) { if (i == 0) A.dl_out[b] = y[IDL]; }
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < M; k++) A.Jt[(b * M + i) * M + k] = y[1 + k];
+        A.kbar[b * M + i] = y[M + 1];
+        A.dD[b * M + i] = y[M + 2];
+        A.Lpart[b * M + i] = y[M + 4];
+      }
+      if (i == 0) {
+        ev_sum += nev;
+        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
+        rej_sum += S.nrej;
+        fail_any |= S.fail;
+      }
+    }
+    __syncthreads();
+  }
+  if (A.stats && (ev_sum || fail_any)) {
+    atomicAdd(&A.stats[0], (int)ev_sum);
+    atomicMax(&A.stats[1], acc_max);
+    atomicAdd(&A.stats[2], rej_sum);
+    if (fail_any) atomicMax(&A.stats[3], 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Local-energy finish (one lane per walker): Slater gradient/Hessian at z(t0) contracted with the
+// sensitivities from the MODE-2 pass.  With g0 = grad_z logp0, H0 = Hess_z logp0:
+//   grad_i = g0 . u_i - dDelta_i
+//   lap    = sum_i u_i^T H0 u_i + g0 . kbar - sum_i L_i
+//   E_loc  = -lap/4 - |grad|^2/8 + V(x)            (src/VMC.py:49-55)
+__global__ void __launch_bounds__(128)
+ff_eloc_finish_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                      const int* __restrict__ wstate, double Zc, int use_ho, const double* __restrict__ x,
+                      const double* __restrict__ z0, const double* __restrict__ Jt, const double* __restrict__ kbar,
+                      const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
+                      double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
+                      double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
+  double zl[2 * FF_MAX_NS], T[2][2 * FF_MAX_NS * FF_MAX_NS], S[2][3 * FF_MAX_NS], g0[4 * FF_MAX_NS];
+  double lp0 = 0.0;
+  for (int sp = 0; sp < 2; sp++) {
+    const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+    if (!ns) continue;
+    for (int k = 0; k < 2 * ns; k++) zl[k] = z0[b * M + 2 * off + k];
+    lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T[sp], S[sp]);
+    for (int a = 0; a < ns; a++) {
+      g0[2 * (off + a)] = 2.0 * T[sp][a * ns + a];
+      g0[2 * (off + a) + 1] = 2.0 * T[sp][ns * ns + a * ns + a];
+    }
+  }
+  lp0 *= 2.0;
+  double lapv = 0.0, g2 = 0.0;
+  for (int i = 0; i < M; i++) {
+    const double* u = Jt + (b * M + i) * M;
+    double gi = 0.0;
+    for (int k = 0; k < M; k++) gi = fma(g0[k], u[k], gi);
+    gi -= dD[b * M + i];
+    if (grad) grad[b * M + i] = gi;
+    g2 = fma(gi, gi, g2);
+    double hq = 0.0;
+    for (int sp = 0; sp < 2; sp++) {
+      const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+      if (!ns) continue;
+      const double* Tx = T[sp];
+      const double* Ty = T[sp] + ns * ns;
+      double q = 0.0;
+      for (int a = 0; a < ns; a++) {
+        const double ux = u[2 * (off + a)], uy = u[2 * (off + a) + 1];
+        q += ux * ux * S[sp][3 * a] + 2.0 * ux * uy * S[sp][3 * a + 1] + uy * uy * S[sp][3 * a + 2];
+        for (int c = 0; c < ns; c++) {
+          const double vx = u[2 * (off + c)], vy = u[2 * (off + c) + 1];
+          const double Wac = ux * Tx[a * ns + c] + uy * Ty[a * ns + c];
+          const double Wca = vx * Tx[c * ns + a] + vy * Ty[c * ns + a];
+          q -= Wac * Wca;
+        }
+      }
+      hq += 2.0 * q;
+    }
+    lapv += hq - Lpart[b * M + i];
+  }
+  for (int k = 0; k < M; k++) lapv = fma(g0[k], kbar[b * M + k], lapv);
+  double pair = 0.0, ho = 0.0;
+  for (int a = 0; a < n; a++) {
+    const double xa = x[b * M + 2 * a], ya = x[b * M + 2 * a + 1];
+    ho += xa * xa + ya * ya;
+    for (int c = a + 1; c < n; c++) {
+      const double dx = xa - x[b * M + 2 * c], dy = ya - x[b * M + 2 * c + 1];
+      pair += Zc / sqrt(dx * dx + dy * dy);
+    }
+  }
+  const double Vv = pair + (use_ho ? 0.5 * ho : 0.0);
+  if (logp) logp[b] = lp0 - delta[b];
+  if (lap) lap[b] = lapv;
+  if (V) V[b] = Vv;
+  if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv;
+  if (glogp0) for (int k = 0; k < M; k++) glogp0[b * M + k] = g0[k];
+}
+
+// =================================================================================================
+extern void ff_set_error(const char* msg);
+#define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
+#define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
+
+#ifndef FF_PERSIST_BLOCKS
+#define FF_PERSIST_BLOCKS 2048  // 256 CUs x 8 single-wave workgroups
+#endif
+
+template <int N, int D, int MODE>
+static void launch_fwd(void* stream, const ff_fwd_args& a) {
+  constexpr int G = ff_geom<N, D>::G;
+  int64_t ngroups = (a.B + G - 1) / G;
+  unsigned grid = (unsigned)(ngroups < FF_PERSIST_BLOCKS ? ngroups : FF_PERSIST_BLOCKS);
+  FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE>), grid, FF_WAVE, stream, a);
+}
+
+template <int MODE>
+static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a) {
+#define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+  FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2)
+#undef FF_ND
+  ff_set_error("fused CNF kernels are instantiated for (n,d) in {(2,2),(3,2),(4,2),(6,2),(12,2)}");
+  return FF_EUNSUPPORTED;
+}
+
+static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode* ode) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode, FF_EINVAL, "ff_cnf: bad argument");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_cnf: bad net");
+  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf: hidden width > 64");
+  FF_CHECK(ode->rtol > 0 && ode->atol > 0, FF_EINVAL, "ff_cnf: tolerances must be positive");
+  return FF_OK;
+}
+
+extern "C" {
+
+int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z,
+                    double* x_out, int32_t* stats) {
+  int st = check_common(B, n, d, net, ode);
+  if (st) return st;
+  FF_CHECK(z && x_out, FF_EINVAL, "ff_cnf_generate: null pointer");
+  if (B == 0) return FF_OK;
+  ff_fwd_args a = {};
+  a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
+  a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.y_in = z; a.y_out = x_out; a.stats = stats;
+  return dispatch_fwd<0>(stream, n, d, a);
+}
+
+int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
+                      double* z_out, double* dlogp_out, int32_t* stats) {
+  int st = check_common(B, n, d, net, ode);
+  if (st) return st;
+  FF_CHECK(x && z_out && dlogp_out, FF_EINVAL, "ff_cnf_delta_logp: null pointer");
+  if (B == 0) return FF_OK;
+  ff_fwd_args a = {};
+  a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
+  a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
+  return dispatch_fwd<1>(stream, n, d, a);
+}
+
+size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
+  size_t M = (size_t)n * d;
+  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1);
+}
+
+struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl; };
+static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
+  double* w = (double*)workspace;
+  ff_eloc_ws o;
+  o.z0 = w;   w += (size_t)B * M;
+  o.Jt = w;   w += (size_t)B * M * M;
+  o.kbar = w; w += (size_t)B * M;
+  o.dD = w;   w += (size_t)B * M;
+  o.Lp = w;   w += (size_t)B * M;
+  o.dl = w;
+  return o;
+}
+
+/* pass 1 of ff_eloc: the fused sensitivity integration (results stay in `workspace`) */
+int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
+                          void* workspace, int32_t* stats) {
+  int st = check_common(B, n, d, net, ode);
+  if (st) return st;
+  FF_CHECK(x && workspace, FF_EINVAL, "ff_eloc_sensitivities: null pointer");
+  if (B == 0) return FF_OK;
+  ff_eloc_ws w = eloc_carve(workspace, B, (size_t)n * d);
+  ff_fwd_args a = {};
+  a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
+  a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
+  return dispatch_fwd<2>(stream, n, d, a);
+}
+
+/* pass 2 of ff_eloc: Slater gradient/Hessian contraction, potentials, E_loc */
+int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                   const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                   double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                   double* glogp0_out) {
+  const int n = nup + ndn;
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && n > 0 && x && workspace, FF_EINVAL, "ff_eloc_finish: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc_finish: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_eloc_finish: determinant larger than FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  const size_t M = (size_t)n * 2;
+  ff_eloc_ws w = eloc_carve((void*)workspace, B, M);
+  FF_LAUNCH(ff_eloc_finish_kernel, (unsigned)((B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho,
+            x, (const double*)w.z0, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
+            (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+  FF_LAUNCH_CHECK();
+#ifdef FF_HOSTSIM
+  if (z_out) memcpy(z_out, w.z0, sizeof(double) * (size_t)B * M);
+  if (dlogp_out) memcpy(dlogp_out, w.dl, sizeof(double) * (size_t)B);
+#else
+  if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+#endif
+  return FF_OK;
+}
+
+int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+            const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho, const double* x,
+            double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+            double* glogp0_out, void* workspace, int32_t* stats) {
+  FF_CHECK(nup >= 0 && ndn >= 0 && nup + ndn > 0, FF_EINVAL, "ff_eloc: bad particle numbers");
+  int st = ff_eloc_sensitivities(stream, B, nup + ndn, 2, net, ode, x, workspace, stats);
+  if (st) return st;
+  return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
+                        z_out, dlogp_out, glogp0_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// ff_ode.h -- shared pieces of the fused CNF integrators (ff_cnf_fwd.hip, ff_cnf_adj.hip).
+//
+// Mapping (N particles, D dims, M = N*D coordinates): a 64-lane wave holds G = 64/M walkers; lane (g,i)
+// owns coordinate i of walker g (and, for the local-energy kernel, the sensitivity column d z / d x_i).
+// One workgroup = one wave, so __syncthreads() is a single-wave barrier and walkers with different adaptive
+// step counts never wait for another wave.  Workgroups are persistent and stride over walker groups.
+//
+// Solver: Dormand-Prince 5(4) with per-walker step control (Hairer initial step; RMS error norm over the
+// walker's own state, tolerance atol + rtol*max(|y|,|y_new|); factor 0.9*err^-1/5 clamped to [0.2,10], no
+// growth right after a rejection; last step clipped to the end point).  These are the rules of the
+// reference's scipy-RK45 backend (src/NeuralODE/nnModule.py:49-61) applied per walker instead of to the
+// whole flattened batch -- SURVEY.md finding 3: E_loc is insensitive to the step sequence (1e-10 relative).
+#pragma once
+#include "ff_common.h"
+
+template <int N, int D>
+struct ff_geom {
+  static constexpr int M = N * D;          // coordinates per walker
+  static constexpr int G = FF_WAVE / M;    // walkers per wave
+  static constexpr int P = N * (N - 1) / 2;  // electron pairs
+  static constexpr int R = P + N;          // radii per walker: pairs then one-body
+  static constexpr int RA = R > 0 ? R : 1;
+};
+
+// per-hidden-unit weight record staged in LDS (48 B, 16-B aligned -> three ds_read_b128)
+struct __attribute__((aligned(16))) ff_wtab { double w1, b1, w2, w2w1, w2w1_2, w2w1_3; };
+
+FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HMAX], const ff_net& net, int lane) {
+  for (int h = lane; h < FF_HMAX; h += FF_WAVE) {
+    ff_wtab e = {0, 0, 0, 0, 0, 0}, m = {0, 0, 0, 0, 0, 0};
+    if (h < net.He) {
+      e.w1 = net.ew1[h]; e.b1 = net.eb1[h]; e.w2 = net.ew2[h];
+      e.w2w1 = e.w2 * e.w1; e.w2w1_2 = e.w2w1 * e.w1; e.w2w1_3 = e.w2w1_2 * e.w1;
+    }
+    if (h < net.Hm) {
+      m.w1 = net.mw1[h]; m.b1 = net.mb1[h]; m.w2 = net.mw2[h];
+      m.w2w1 = m.w2 * m.w1; m.w2w1_2 = m.w2w1 * m.w1; m.w2w1_3 = m.w2w1_2 * m.w1;
+    }
+    s_w[0][h] = e; s_w[1][h] = m;
+  }
+}
+
+// f(r) = sum_h w2 sigma(w1 r + b1) and its first NH-1 derivatives (MLP.forward / .grad, src/MLP.py:30-45,
+// extended analytically: sigma' = s(1-s), sigma'' = s'(1-2s), sigma''' = s'(1-6s')).
+template <int NH>
+FF_D void ff_heads(const ff_wtab* __restrict__ tab, int H, double r, double* hd) {
+  double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+  for (int h = 0; h < H; h++) {
+    const ff_wtab w = tab[h];
+    double s = ff_sigmoid(fma(w.w1, r, w.b1));
+    h0 = fma(w.w2, s, h0);
+    if (NH >= 2) {
+      double s1 = s * (1.0 - s);
+      h1 = fma(w.w2w1, s1, h1);
+      if (NH >= 3) h2 = fma(w.w2w1_2, s1 * fma(-2.0, s, 1.0), h2);
+      if (NH >= 4) h3 = fma(w.w2w1_3, s1 * fma(-6.0, s1, 1.0), h3);
+    }
+  }
+  hd[0] = h0;
+  if (NH >= 2) hd[1] = h1;
+  if (NH >= 3) hd[2] = h2;
+  if (NH >= 4) hd[3] = h3;
+}
+
+// Dormand-Prince tableau
+#define FF_A10 (1.0 / 5)
+#define FF_A20 (3.0 / 40)
+#define FF_A21 (9.0 / 40)
+#define FF_A30 (44.0 / 45)
+#define FF_A31 (-56.0 / 15)
+#define FF_A32 (32.0 / 9)
+#define FF_A40 (19372.0 / 6561)
+#define FF_A41 (-25360.0 / 2187)
+#define FF_A42 (64448.0 / 6561)
+#define FF_A43 (-212.0 / 729)
+#define FF_A50 (9017.0 / 3168)
+#define FF_A51 (-355.0 / 33)
+#define FF_A52 (46732.0 / 5247)
+#define FF_A53 (49.0 / 176)
+#define FF_A54 (-5103.0 / 18656)
+#define FF_B0 (35.0 / 384)
+#define FF_B2 (500.0 / 1113)
+#define FF_B3 (125.0 / 192)
+#define FF_B4 (-2187.0 / 6784)
+#define FF_B5 (11.0 / 84)
+#define FF_E0 (-71.0 / 57600)
+#define FF_E2 (71.0 / 16695)
+#define FF_E3 (-71.0 / 1920)
+#define FF_E4 (17253.0 / 339200)
+#define FF_E5 (-22.0 / 525)
+#define FF_E6 (1.0 / 40)
+
+// per-walker step-size bookkeeping (identical on all lanes of a walker's group)
+struct ff_stepper {
+  double t, tb, dir, interval, habs, h, tnew;
+  int nacc, nrej, natt, rejected, fail;
+  bool done;
+  FF_D void begin(double ta_, double tb_, bool active) {
+    t = ta_; tb = tb_; dir = tb_ > ta_ ? 1.0 : -1.0; interval = fabs(tb_ - ta_);
+    habs = 0.0; h = 0.0; tnew = ta_; nacc = nrej = natt = rejected = fail = 0;
+    done = !active || interval == 0.0;
+  }
+  // Hairer initial step, part 1 (scipy select_initial_step)
+  FF_D double h0(double d0, double d1) const {
+    double v = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    return fmin(v, interval);
+  }
+  FF_D void init_habs(double h0v, double d1, double d2) {
+    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0v * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+    habs = fmin(fmin(100.0 * h0v, h1), interval);
+  }
+  FF_D void plan() {  // choose h for the next attempt
+    if (done) { h = 0.0; tnew = t; return; }
+    tnew = t + habs * dir;
+    if (dir * (tnew - tb) > 0.0) tnew = tb;
+    h = tnew - t;
+    habs = fabs(h);
+  }
+  // returns true if the attempt is accepted
+  FF_D bool decide(double err, int max_steps) {
+    if (done) return false;
+    natt++;
+    bool acc = err < 1.0;
+    if (acc) {
+      double f = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+      if (rejected) f = fmin(1.0, f);
+      habs *= f; t = tnew; rejected = 0; nacc++;
+      if (dir * (t - tb) >= 0.0) done = true;
+    } else {
+      if (!(err == err)) { fail = 1; done = true; }
+      else { habs *= fmax(0.2, 0.9 * pow(err, -0.2)); rejected = 1; nrej++; }
+    }
+    if (!done && natt >= max_steps) { fail = 1; done = true; }
+    return acc;
+  }
+};

@@ -1,0 +1,43 @@
+// ff_rng.h -- counter-based Philox4x32-10 + Box-Muller for the throughput-mode MCMC.
+// (The reference draws from torch's global generator, src/base_dist.py:62,65,68; bit-parity with it is
+// only possible by feeding its noise explicitly -- ff_mcmc_sample_noise.  This generator gives every
+// (walker, step, particle) its own counter, so results do not depend on how walkers are sharded.)
+#pragma once
+#include "ff_common.h"
+
+struct ff_u4 { uint32_t x, y, z, w; };
+
+FF_D ff_u4 ff_philox(uint64_t key, uint64_t c01, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  uint32_t c0 = (uint32_t)c01, c1 = (uint32_t)(c01 >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  ff_u4 o = {c0, c1, c2, c3};
+  return o;
+}
+
+FF_D uint64_t ff_bits53(uint32_t hi, uint32_t lo) { return (((uint64_t)hi << 32) | lo) >> 11; }
+
+// two independent N(0,1) from one Philox block
+FF_D void ff_normal_pair(uint64_t key, uint64_t walker, uint32_t step, uint32_t slot, double& z0, double& z1) {
+  ff_u4 r = ff_philox(key, walker, step, slot);
+  double u1 = (double)(ff_bits53(r.x, r.y) + 1) * 1.1102230246251565e-16;  // (0,1]
+  double u2 = (double)ff_bits53(r.z, r.w) * 1.1102230246251565e-16;        // [0,1)
+  double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}
+
+// uniform in [0,1) (torch.rand_like semantics)
+FF_D double ff_uniform(uint64_t key, uint64_t walker, uint32_t step, uint32_t slot) {
+  ff_u4 r = ff_philox(key, walker, step, slot);
+  return (double)ff_bits53(r.x, r.y) * 1.1102230246251565e-16;
+}

@@ -1,0 +1,213 @@
+// ff_slater.h -- HO2D orbitals and Slater-determinant device routines.
+//
+// Reference semantics: HO2D orbitals  src/orbitals.py:65-82; LogAbsSlaterDet  src/slater.py:13-62;
+// FreeFermion.log_prob  src/base_dist.py:49-56.  Derivatives are closed-form (Hermite polynomials are
+// differentiated analytically; d log|det D| = tr(D^-1 dD)) instead of the reference's autograd passes.
+#pragma once
+#include "ff_common.h"
+
+// h_n(x) = FF_HERM_NORM[n] * sum_k FF_HERM_A[n][k] x^k, the polynomials of src/orbitals.py:66-73
+__constant__ double FF_HERM_A[8][8] = {
+    {1, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 0, 0, 0, 0, 0, 0},
+    {-1, 0, 2, 0, 0, 0, 0, 0},
+    {0, -3, 0, 2, 0, 0, 0, 0},
+    {1.5, 0, -6, 0, 2, 0, 0, 0},
+    {0, 7.5, 0, -10, 0, 2, 0, 0},
+    {-1.25, 0, 7.5, 0, -5, 0, 2.0 / 3.0, 0},
+    {0, -17.5, 0, 35, 0, -14, 0, 4.0 / 3.0}};
+__constant__ double FF_HERM_NORM[8] = {
+    1.0, 1.4142135623730951 /* sqrt(2) */, 0.70710678118654746 /* 1/sqrt(2) */, 0.57735026918962584 /* 1/sqrt(3) */,
+    0.40824829046386307 /* 1/sqrt(6) */, 0.25819888974716110 /* 1/sqrt(15) */, 0.44721359549995793 /* 1/sqrt(5) */,
+    0.11952286093343936 /* 1/sqrt(70) */};
+#define FF_PI_SQRT_INV 0.56418958354775628
+
+// orbital index k -> (nx, ny): list order "for n in range(8) for nx in range(n+1): (nx, n-nx)"
+FF_D void ff_orb_decode(int k, int& nx, int& ny) {
+  int shell = 0;
+  while ((shell + 1) * (shell + 2) / 2 <= k) shell++;
+  nx = k - shell * (shell + 1) / 2;
+  ny = shell - nx;
+}
+
+// h_n(x) and (optionally) its first two derivatives, Horner on the coefficient table
+template <bool DERIV>
+FF_D void ff_herm(int n, double x, double& h, double& h1, double& h2) {
+  double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    double ck = FF_HERM_A[n][k];
+    a = fma(a, x, ck);
+    if (DERIV) {
+      if (k >= 1) b = fma(b, x, ck * k);
+      if (k >= 2) c = fma(c, x, ck * (k * (k - 1)));
+    }
+  }
+  double nm = FF_HERM_NORM[n];
+  h = nm * a;
+  if (DERIV) { h1 = nm * b; h2 = nm * c; }
+}
+
+// phi_k at (x,y) and optionally gradient (2) and Hessian (xx, xy, yy)
+template <bool DERIV>
+FF_D void ff_orbital(int k, double x, double y, double gauss /* pi^-1/2 exp(-r^2/2) */, double& v, double* g, double* hs) {
+  int nx, ny;
+  ff_orb_decode(k, nx, ny);
+  double hx, hx1, hx2, hy, hy1, hy2;
+  ff_herm<DERIV>(nx, x, hx, hx1, hx2);
+  ff_herm<DERIV>(ny, y, hy, hy1, hy2);
+  v = gauss * hx * hy;
+  if (DERIV) {
+    double px1 = hx1 - x * hx, py1 = hy1 - y * hy;
+    double px2 = hx2 - 2.0 * x * hx1 + (x * x - 1.0) * hx, py2 = hy2 - 2.0 * y * hy1 + (y * y - 1.0) * hy;
+    g[0] = gauss * px1 * hy; g[1] = gauss * hx * py1;
+    hs[0] = gauss * px2 * hy; hs[1] = gauss * px1 * py1; hs[2] = gauss * hx * py2;
+  }
+}
+
+FF_D double ff_gauss2d(double x, double y) { return FF_PI_SQRT_INV * exp(-0.5 * (x * x + y * y)); }
+
+// --------------------------------------------------------------------------------------------------
+// Register-resident log|det| for compile-time NS (MCMC hot loop).  The normalised Hermite functions of
+// one coordinate are produced together by the three-term recurrence
+//   h_0 = 1, h_1 = sqrt(2) x, h_{m+1} = sqrt(2/(m+1)) x h_m - sqrt(m/(m+1)) h_{m-1}
+// (same polynomials as src/orbitals.py:66-73, no table loads) and picked per orbital with a select chain, so
+// everything stays in VGPRs.  LU with partial pivoting; all indices static, row exchange by predicated swaps.
+FF_D void ff_herm_all(double x, double* h /* [8] */) {
+  const double a[7] = {1.4142135623730951, 1.0, 0.81649658092772603, 0.70710678118654752, 0.63245553203367588,
+                       0.57735026918962576, 0.53452248382484879};  // sqrt(2/(m+1)), m = 0..6
+  const double b[7] = {0.0, 0.70710678118654752, 0.81649658092772603, 0.86602540378443865, 0.89442719099991588,
+                       0.91287092917527686, 0.92582009977255146};  // sqrt(m/(m+1))
+  h[0] = 1.0;
+  h[1] = a[0] * x;
+#pragma unroll
+  for (int m = 1; m < 7; m++) h[m + 1] = fma(a[m] * x, h[m], -b[m] * h[m - 1]);
+}
+FF_D double ff_pick8(const double* h, int n) {
+  double v = h[0];
+#pragma unroll
+  for (int m = 1; m < 8; m++) v = (n == m) ? h[m] : v;
+  return v;
+}
+
+template <int NS>
+FF_D double ff_slater_logabsdet_reg(const int* __restrict__ orb, const double* x) {
+  double D[NS][NS];
+  int nx[NS], ny[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) ff_orb_decode(orb[j], nx[j], ny[j]);
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
+    double hx[8], hy[8];
+    ff_herm_all(x[2 * i], hx);
+    ff_herm_all(x[2 * i + 1], hy);
+#pragma unroll
+    for (int j = 0; j < NS; j++) D[i][j] = gs * ff_pick8(hx, nx[j]) * ff_pick8(hy, ny[j]);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < NS; c++) {
+    int p = c;
+    double best = fabs(D[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < NS; r++) {
+      double a = fabs(D[r][c]);
+      if (a > best) { best = a; p = r; }
+    }
+#pragma unroll
+    for (int r = c + 1; r < NS; r++) {
+      bool sw = (p == r);
+#pragma unroll
+      for (int j = c; j < NS; j++) {
+        double a = D[c][j], b = D[r][j];
+        D[c][j] = sw ? b : a;
+        D[r][j] = sw ? a : b;
+      }
+    }
+    double piv = D[c][c];
+    acc += log(fabs(piv));
+    double ip = 1.0 / piv;
+#pragma unroll
+    for (int r = c + 1; r < NS; r++) {
+      double f = D[r][c] * ip;
+#pragma unroll
+      for (int j = c + 1; j < NS; j++) D[r][j] = fma(-f, D[c][j], D[r][j]);
+    }
+  }
+  return acc;
+}
+
+// --------------------------------------------------------------------------------------------------
+// General routine (runtime ns <= FF_MAX_NS, arrays in private memory).  Builds D, inverts it by
+// Gauss-Jordan with partial pivoting and returns log|det D|.  If T/S are given also forms
+//   T[c][a][b] = sum_j d_c phi_j(r_a) Dinv[j][b]         (c = 0,1)
+//   S[a][0..2] = sum_j (d_xx, d_xy, d_yy) phi_j(r_a) Dinv[j][a]
+// from which  grad_a,c log|det| = T[c][a][a],  Hessian[(a,c),(b,e)] = delta_ab S_a^{ce} - T[c][a][b] T[e][b][a].
+FF_D double ff_slater_general(int ns, const int* __restrict__ orb, const double* x,
+                              double* T /* [2*ns*ns] or null */, double* S /* [3*ns] or null */) {
+  double A[FF_MAX_NS * FF_MAX_NS], Inv[FF_MAX_NS * FF_MAX_NS];
+  for (int i = 0; i < ns; i++) {
+    double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
+    for (int j = 0; j < ns; j++) {
+      double v;
+      ff_orbital<false>(orb[j], x[2 * i], x[2 * i + 1], gs, v, nullptr, nullptr);
+      A[i * ns + j] = v;
+      Inv[i * ns + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  double acc = 0.0;
+  for (int c = 0; c < ns; c++) {
+    int p = c;
+    double best = fabs(A[c * ns + c]);
+    for (int r = c + 1; r < ns; r++) {
+      double a = fabs(A[r * ns + c]);
+      if (a > best) { best = a; p = r; }
+    }
+    if (p != c)
+      for (int j = 0; j < ns; j++) {
+        double t = A[c * ns + j]; A[c * ns + j] = A[p * ns + j]; A[p * ns + j] = t;
+        t = Inv[c * ns + j]; Inv[c * ns + j] = Inv[p * ns + j]; Inv[p * ns + j] = t;
+      }
+    double piv = A[c * ns + c];
+    acc += log(fabs(piv));
+    if (!T) {  // value only: plain elimination below the pivot
+      double ip = 1.0 / piv;
+      for (int r = c + 1; r < ns; r++) {
+        double f = A[r * ns + c] * ip;
+        for (int j = c + 1; j < ns; j++) A[r * ns + j] = fma(-f, A[c * ns + j], A[r * ns + j]);
+      }
+      continue;
+    }
+    double ip = 1.0 / piv;
+    for (int j = 0; j < ns; j++) { A[c * ns + j] *= ip; Inv[c * ns + j] *= ip; }
+    for (int r = 0; r < ns; r++) {
+      if (r == c) continue;
+      double f = A[r * ns + c];
+      for (int j = 0; j < ns; j++) {
+        A[r * ns + j] = fma(-f, A[c * ns + j], A[r * ns + j]);
+        Inv[r * ns + j] = fma(-f, Inv[c * ns + j], Inv[r * ns + j]);
+      }
+    }
+  }
+  if (T) {
+    for (int a = 0; a < ns; a++) {
+      double gs = ff_gauss2d(x[2 * a], x[2 * a + 1]);
+      for (int b = 0; b < ns; b++) { T[a * ns + b] = 0.0; T[ns * ns + a * ns + b] = 0.0; }
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int j = 0; j < ns; j++) {
+        double v, g[2], hs[3];
+        ff_orbital<true>(orb[j], x[2 * a], x[2 * a + 1], gs, v, g, hs);
+        for (int b = 0; b < ns; b++) {
+          double di = Inv[j * ns + b];
+          T[a * ns + b] = fma(g[0], di, T[a * ns + b]);
+          T[ns * ns + a * ns + b] = fma(g[1], di, T[ns * ns + a * ns + b]);
+        }
+        double da = Inv[j * ns + a];
+        s0 = fma(hs[0], da, s0); s1 = fma(hs[1], da, s1); s2 = fma(hs[2], da, s2);
+      }
+      if (S) { S[3 * a] = s0; S[3 * a + 1] = s1; S[3 * a + 2] = s2; }
+    }
+  }
+  return acc;
+}

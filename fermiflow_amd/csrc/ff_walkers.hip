@@ -1,0 +1,393 @@
+// ff_walkers.hip -- one-lane-per-walker kernels: Metropolis sweep, Slater log-determinants and their
+// derivatives, potentials, stand-alone backflow/MLP evaluation, energy moments.
+//
+// Data layout in HBM: walker coordinates (B, n, d) row-major fp64 exactly as the reference's tensors, so a
+// wave of 64 consecutive walkers reads one contiguous 64*n*d*8-byte span (fully used cache lines).
+// The Metropolis sweep keeps a walker's coordinates and log-probability in VGPRs for all `steps` proposals:
+// per walker-step the only HBM traffic is the proposal noise (parity mode) or nothing at all (Philox mode).
+#include "ff_common.h"
+#include "ff_slater.h"
+#include "ff_rng.h"
+
+#define FF_MAX_N 24  // particles per walker for the generic paths
+
+#ifdef FF_HOSTSIM
+FF_D double ff_mul_rn(double a, double b) { volatile double r = a * b; return r; }
+FF_D double ff_add_rn(double a, double b) { volatile double r = a + b; return r; }
+#else
+FF_D double ff_mul_rn(double a, double b) { return __dmul_rn(a, b); }
+FF_D double ff_add_rn(double a, double b) { return __dadd_rn(a, b); }
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// FreeFermion.sample (src/base_dist.py:58-71).  NU/ND > 0: compile-time spin sizes, everything in VGPRs.
+// NU = ND = -1: runtime sizes (private arrays).
+template <int NU, int ND>
+FF_D double ff_logprob_value(int nup, int ndn, const int* ou, const int* od, const double* x) {
+  double s = 0.0;
+  if constexpr (NU >= 0) {
+    if constexpr (NU > 0) s += ff_slater_logabsdet_reg<NU>(ou, x);
+    if constexpr (ND > 0) s += ff_slater_logabsdet_reg<ND>(od, x + 2 * NU);
+  } else {
+    if (nup) s += ff_slater_general(nup, ou, x, nullptr, nullptr);
+    if (ndn) s += ff_slater_general(ndn, od, x + 2 * nup, nullptr, nullptr);
+  }
+  return 2.0 * s;
+}
+
+template <int NU, int ND, bool NOISE>
+__global__ void __launch_bounds__(128)
+ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+               const int* __restrict__ wstate, int steps, double tau,
+               const double* __restrict__ g0, const double* __restrict__ g, const double* __restrict__ u,
+               uint64_t seed, int64_t woff,
+               double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept,
+               int* __restrict__ acc_count) {
+  constexpr bool FIXED = (NU >= 0);
+  const int nup = FIXED ? NU : nup_rt, ndn = FIXED ? ND : ndn_rt;
+  const int n = nup + ndn, M = 2 * n;
+  constexpr int MAXM = FIXED ? 2 * (NU + ND) : 2 * FF_MAX_N;
+  constexpr int MAXU = FIXED ? (NU > 0 ? NU : 1) : FF_MAX_NS, MAXD = FIXED ? (ND > 0 ? ND : 1) : FF_MAX_NS;
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int st = wstate ? wstate[b] : 0;
+  int ou[MAXU], od[MAXD];
+#pragma unroll
+  for (int j = 0; j < MAXU; j++) ou[j] = (j < nup) ? tab_up[st * nup + j] : 0;
+#pragma unroll
+  for (int j = 0; j < MAXD; j++) od[j] = (j < ndn) ? tab_dn[st * ndn + j] : 0;
+
+  double x[MAXM], nx[MAXM];
+  const uint64_t wid = (uint64_t)(woff + b);
+  if (NOISE) {
+#pragma unroll
+    for (int i = 0; i < MAXM; i++) if (i < M) x[i] = g0[b * M + i];
+  } else {
+#pragma unroll
+    for (int j = 0; j < MAXM / 2; j++) if (j < n) ff_normal_pair(seed, wid, 0u, (uint32_t)j, x[2 * j], x[2 * j + 1]);
+  }
+  double logp = ff_logprob_value<NU, ND>(nup, ndn, ou, od, x);
+  int nacc = 0;
+  for (int s = 0; s < steps; s++) {
+    if (NOISE) {
+      const double* gs = g + ((int64_t)s * B + b) * M;
+#pragma unroll
+      for (int i = 0; i < MAXM; i++) if (i < M) nx[i] = ff_add_rn(x[i], ff_mul_rn(tau, gs[i]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < MAXM / 2; j++)
+        if (j < n) {
+          double z0, z1;
+          ff_normal_pair(seed, wid, (uint32_t)(s + 1), (uint32_t)j, z0, z1);
+          nx[2 * j] = ff_add_rn(x[2 * j], ff_mul_rn(tau, z0));
+          nx[2 * j + 1] = ff_add_rn(x[2 * j + 1], ff_mul_rn(tau, z1));
+        }
+    }
+    double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx);
+    double p = exp(nl - logp);
+    double uu = NOISE ? u[(int64_t)s * B + b] : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
+    bool acc = uu < p;  // NaN p -> reject, +inf p -> accept (IEEE), as torch
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < MAXM; i++) if (i < M) x[i] = nx[i];
+      logp = nl;
+      nacc++;
+    }
+    if (accept) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXM; i++) if (i < M) x_out[b * M + i] = x[i];
+  if (logp_out) logp_out[b] = logp;
+  if (acc_count) acc_count[b] = nacc;
+}
+
+// materialise the Philox noise stream of ff_mcmc_kernel<.., false>
+__global__ void __launch_bounds__(128)
+ff_rng_fill_kernel(int64_t B, int n, int steps, uint64_t seed, int64_t woff, double* __restrict__ g0,
+                   double* __restrict__ g, double* __restrict__ u) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int M = 2 * n;
+  const uint64_t wid = (uint64_t)(woff + b);
+  for (int j = 0; j < n; j++) ff_normal_pair(seed, wid, 0u, (uint32_t)j, g0[b * M + 2 * j], g0[b * M + 2 * j + 1]);
+  for (int s = 0; s < steps; s++) {
+    double* gs = g + ((int64_t)s * B + b) * M;
+    for (int j = 0; j < n; j++) ff_normal_pair(seed, wid, (uint32_t)(s + 1), (uint32_t)j, gs[2 * j], gs[2 * j + 1]);
+    u[(int64_t)s * B + b] = ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LogAbsSlaterDet forward / backward (src/slater.py:13-62), one lane per walker
+__global__ void __launch_bounds__(128)
+ff_slater_fwd_kernel(int64_t B, int n, const int* __restrict__ tab, const int* __restrict__ wstate,
+                     const double* __restrict__ x, double* __restrict__ lad) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xl[2 * FF_MAX_NS];
+  for (int i = 0; i < 2 * n; i++) xl[i] = x[b * 2 * n + i];
+  lad[b] = ff_slater_general(n, tab + (wstate ? wstate[b] : 0) * n, xl, nullptr, nullptr);
+}
+
+__global__ void __launch_bounds__(128)
+ff_slater_bwd_kernel(int64_t B, int n, const int* __restrict__ tab, const int* __restrict__ wstate,
+                     const double* __restrict__ x, const double* __restrict__ gout, double* __restrict__ gx) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS];
+  for (int i = 0; i < 2 * n; i++) xl[i] = x[b * 2 * n + i];
+  ff_slater_general(n, tab + (wstate ? wstate[b] : 0) * n, xl, T, nullptr);
+  double go = gout[b];
+  for (int a = 0; a < n; a++) {
+    gx[b * 2 * n + 2 * a] = go * T[a * n + a];
+    gx[b * 2 * n + 2 * a + 1] = go * T[n * n + a * n + a];
+  }
+}
+
+// FreeFermion.log_prob with gradient and Laplacian (what y_grad_laplacian extracts, src/utils.py:40-65)
+__global__ void __launch_bounds__(128)
+ff_logprob_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                  const int* __restrict__ wstate, const double* __restrict__ x, double* __restrict__ logp,
+                  double* __restrict__ grad, double* __restrict__ lap) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = nup + ndn, st = wstate ? wstate[b] : 0;
+  const bool deriv = grad || lap;
+  double xl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS], S[3 * FF_MAX_NS];
+  double lp = 0.0, lpl = 0.0;
+  for (int sp = 0; sp < 2; sp++) {
+    const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+    if (!ns) continue;
+    const int* orb = (sp ? tab_dn : tab_up) + st * ns;
+    for (int i = 0; i < 2 * ns; i++) xl[i] = x[b * 2 * n + 2 * off + i];
+    lp += ff_slater_general(ns, orb, xl, deriv ? T : nullptr, deriv ? S : nullptr);
+    if (deriv)
+      for (int a = 0; a < ns; a++) {
+        double gxa = T[a * ns + a], gya = T[ns * ns + a * ns + a];
+        if (grad) { grad[b * 2 * n + 2 * (off + a)] = 2.0 * gxa; grad[b * 2 * n + 2 * (off + a) + 1] = 2.0 * gya; }
+        lpl += S[3 * a] + S[3 * a + 2] - gxa * gxa - gya * gya;
+      }
+  }
+  logp[b] = 2.0 * lp;
+  if (lap) lap[b] = 2.0 * lpl;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// HO.V + CoulombPairPotential.V (src/potentials.py:13,23-47)
+__global__ void __launch_bounds__(128)
+ff_potential_kernel(int64_t B, int n, int d, double Z, int use_ho, const double* __restrict__ x, double* __restrict__ V) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xl[3 * FF_MAX_N];
+  const int M = n * d;
+  for (int i = 0; i < M; i++) xl[i] = x[b * M + i];
+  double pair = 0.0, ho = 0.0;
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++) {
+      double r2 = 0.0;
+      for (int c = 0; c < d; c++) { double t = xl[i * d + c] - xl[j * d + c]; r2 = fma(t, t, r2); }
+      pair += Z / sqrt(r2);
+    }
+  for (int i = 0; i < M; i++) ho = fma(xl[i], xl[i], ho);
+  V[b] = pair + (use_ho ? 0.5 * ho : 0.0);
+}
+
+// MLP.forward / MLP.grad (src/MLP.py:30-45) on a flat list of scalars
+FF_D void ff_mlp_point(int H, const double* __restrict__ w1, const double* __restrict__ b1, const double* __restrict__ w2,
+                       double r, double& val, double& dval) {
+  double s = 0.0, g = 0.0;
+  for (int h = 0; h < H; h++) {
+    double a = ff_sigmoid(fma(w1[h], r, b1[h]));
+    s = fma(w2[h], a, s);
+    g = fma(w2[h] * w1[h], a * (1.0 - a), g);
+  }
+  val = s; dval = g;
+}
+
+__global__ void __launch_bounds__(128)
+ff_mlp_kernel(int64_t N, int H, const double* __restrict__ w1, const double* __restrict__ b1, const double* __restrict__ w2,
+              const double* __restrict__ r, double* __restrict__ val, double* __restrict__ dval) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double v, g;
+  ff_mlp_point(H, w1, b1, w2, r[i], v, g);
+  val[i] = v;
+  if (dval) dval[i] = g;
+}
+
+// Backflow.forward / .divergence (src/equivariant_funs.py:83-102), any n <= FF_MAX_N, d <= 3, any H.
+// (The j == i term of the reference's "+eye" formulation cancels analytically and is skipped.)
+__global__ void __launch_bounds__(128)
+ff_backflow_kernel(int64_t B, int n, int d, ff_net net, const double* __restrict__ x, double* __restrict__ v,
+                   double* __restrict__ div) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int M = n * d;
+  double xl[3 * FF_MAX_N], vl[3 * FF_MAX_N];
+  for (int i = 0; i < M; i++) { xl[i] = x[b * M + i]; vl[i] = 0.0; }
+  double dv = 0.0;
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++) {
+      double rho[3], r2 = 0.0;
+      for (int c = 0; c < d; c++) { rho[c] = xl[i * d + c] - xl[j * d + c]; r2 = fma(rho[c], rho[c], r2); }
+      double r = sqrt(r2), eta, deta;
+      ff_mlp_point(net.He, net.ew1, net.eb1, net.ew2, r, eta, deta);
+      for (int c = 0; c < d; c++) { vl[i * d + c] = fma(eta, rho[c], vl[i * d + c]); vl[j * d + c] = fma(-eta, rho[c], vl[j * d + c]); }
+      dv += 2.0 * fma(deta, r, d * eta);
+    }
+  if (net.Hm > 0)
+    for (int i = 0; i < n; i++) {
+      double r2 = 0.0;
+      for (int c = 0; c < d; c++) r2 = fma(xl[i * d + c], xl[i * d + c], r2);
+      double r = sqrt(r2), mu, dmu;
+      ff_mlp_point(net.Hm, net.mw1, net.mb1, net.mw2, r, mu, dmu);
+      for (int c = 0; c < d; c++) vl[i * d + c] = fma(mu, xl[i * d + c], vl[i * d + c]);
+      dv += fma(dmu, r, d * mu);
+    }
+  if (v) for (int i = 0; i < M; i++) v[b * M + i] = vl[i];
+  if (div) div[b] = dv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[0] = sum (e - shift), out[1] = sum (e - shift)^2; one workgroup, fixed summation tree (deterministic)
+__global__ void __launch_bounds__(256)
+ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift, double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  double a = 0.0, q = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += 256) { double t = e[i] - shift; a += t; q = fma(t, t, q); }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { s1[threadIdx.x] += s1[threadIdx.x + w]; s2[threadIdx.x] += s2[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern void ff_set_error(const char* msg);
+#define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
+#define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
+static inline unsigned ff_grid(int64_t B, int block) { return (unsigned)((B + block - 1) / block); }
+
+template <int NU, int ND>
+static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
+                        int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
+                        double* x_out, double* logp_out, uint8_t* accept, int* acc_count) {
+  if (noise)
+    FF_LAUNCH((ff_mcmc_kernel<NU, ND, true>), ff_grid(B, 128), 128, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff,
+              x_out, logp_out, accept, acc_count);
+  else
+    FF_LAUNCH((ff_mcmc_kernel<NU, ND, false>), ff_grid(B, 128), 128, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff,
+              x_out, logp_out, accept, acc_count);
+}
+
+static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
+                         int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
+                         double* x_out, double* logp_out, uint8_t* accept, int* acc_count) {
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && nup + ndn > 0 && steps >= 0, FF_EINVAL, "ff_mcmc: bad sizes");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_mcmc: determinant larger than FF_MAX_NS");
+  FF_CHECK(x_out && (nup == 0 || tu) && (ndn == 0 || td), FF_EINVAL, "ff_mcmc: null pointer");
+  FF_CHECK(!noise || (g0 && (steps == 0 || (g && u))), FF_EINVAL, "ff_mcmc: null noise pointer");
+  if (B == 0) return FF_OK;
+#define FF_MC(NU_, ND_) if (nup == NU_ && ndn == ND_) { launch_mcmc<NU_, ND_>(noise, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count); FF_LAUNCH_CHECK(); return FF_OK; }
+  FF_MC(3, 3) FF_MC(3, 0) FF_MC(6, 0) FF_MC(6, 6) FF_MC(1, 0) FF_MC(2, 0) FF_MC(4, 0)
+#undef FF_MC
+  launch_mcmc<-1, -1>(noise, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+extern "C" {
+
+int ff_mcmc_sample_noise(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                         const int32_t* walker_state, int steps, double tau, const double* g0, const double* g,
+                         const double* u, double* x_out, double* logp_out, uint8_t* accept) {
+  return mcmc_dispatch(true, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, g0, g, u, 0, 0, x_out, logp_out, accept, nullptr);
+}
+
+int ff_mcmc_sample(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                   const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                   double* x_out, double* logp_out, int32_t* accept_count) {
+  return mcmc_dispatch(false, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, nullptr, nullptr, nullptr, seed,
+                       walker_offset, x_out, logp_out, nullptr, accept_count);
+}
+
+int ff_rng_fill(void* stream, int64_t B, int n, int steps, uint64_t seed, int64_t walker_offset, double* g0, double* g, double* u) {
+  FF_CHECK(B >= 0 && n > 0 && steps >= 0 && g0 && (steps == 0 || (g && u)), FF_EINVAL, "ff_rng_fill: bad argument");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_rng_fill_kernel, ff_grid(B, 128), 128, stream, B, n, steps, seed, walker_offset, g0, g, u);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_slater_logabsdet_fwd(void* stream, int64_t B, int n, const int32_t* orb_table, const int32_t* walker_state,
+                            const double* x, double* logabsdet) {
+  FF_CHECK(B >= 0 && n > 0 && orb_table && x && logabsdet, FF_EINVAL, "ff_slater_logabsdet_fwd: bad argument");
+  FF_CHECK(n <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_slater_logabsdet_fwd: n > FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_slater_fwd_kernel, ff_grid(B, 128), 128, stream, B, n, orb_table, walker_state, x, logabsdet);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_slater_logabsdet_bwd(void* stream, int64_t B, int n, const int32_t* orb_table, const int32_t* walker_state,
+                            const double* x, const double* grad_out, double* grad_x) {
+  FF_CHECK(B >= 0 && n > 0 && orb_table && x && grad_out && grad_x, FF_EINVAL, "ff_slater_logabsdet_bwd: bad argument");
+  FF_CHECK(n <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_slater_logabsdet_bwd: n > FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_slater_bwd_kernel, ff_grid(B, 128), 128, stream, B, n, orb_table, walker_state, x, grad_out, grad_x);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_logprob(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+               const int32_t* walker_state, const double* x, double* logp, double* grad, double* lap) {
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && nup + ndn > 0 && x && logp, FF_EINVAL, "ff_logprob: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_logprob: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_logprob: determinant larger than FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_logprob_kernel, ff_grid(B, 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, x, logp, grad, lap);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_mlp_eval(void* stream, int64_t N, int H, const double* w1, const double* b1, const double* w2, const double* r,
+                double* val, double* dval) {
+  FF_CHECK(N >= 0 && H > 0 && w1 && b1 && w2 && r && val, FF_EINVAL, "ff_mlp_eval: bad argument");
+  if (N == 0) return FF_OK;
+  FF_LAUNCH(ff_mlp_kernel, ff_grid(N, 128), 128, stream, N, H, w1, b1, w2, r, val, dval);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_backflow_v_div(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && net && x && (v || div), FF_EINVAL, "ff_backflow_v_div: bad argument");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_backflow_v_div: bad net");
+  FF_CHECK(n <= FF_MAX_N && d <= 3, FF_EUNSUPPORTED, "ff_backflow_v_div: n > 24 or d > 3");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_backflow_kernel, ff_grid(B, 128), 128, stream, B, n, d, *net, x, v, div);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && x && V, FF_EINVAL, "ff_potential: bad argument");
+  FF_CHECK(n <= FF_MAX_N && d <= 3, FF_EUNSUPPORTED, "ff_potential: n > 24 or d > 3");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_potential_kernel, ff_grid(B, 128), 128, stream, B, n, d, Z, use_ho, x, V);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, double* out2) {
+  FF_CHECK(B > 0 && e && out2, FF_EINVAL, "ff_reduce_moments: bad argument");
+  FF_LAUNCH(ff_moments_kernel, 1, 256, stream, B, e, shift, out2);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+"""Data parallelism over walkers: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Walkers are independent in the MCMC, the flow and the local energy; ranks couple only through
+  phase A: [sum E_loc, count]            -> E           (src/VMC.py:57, mean)
+  phase B: [sum (E_loc - E)^2]           -> E_std       (src/VMC.py:57, unbiased std)
+  phase C: [sum_b w_b logp_b] + the 3(He+Hm)-double parameter gradient (src/VMC.py:58, FermionHO2D.py:71)
+all a few hundred bytes to 2.4 KB, i.e. latency-bound: one fused buffer per phase, no bucketing.
+The functions work on any device so the same code runs under gloo on CPU in the tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_reduce_sum_(t):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def shard(batch, rank=None, world_size=None):
+    """Contiguous block of the global walker batch owned by `rank`: (offset, count)."""
+    if rank is None:
+        rank, world_size = world()
+    base, rem = divmod(int(batch), world_size)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def global_mean_std(sum_e, count, centered_sumsq_fn):
+    """Two-phase mean / unbiased std over all ranks.
+    sum_e: 0-dim tensor with the local sum; count: local number of walkers;
+    centered_sumsq_fn(mean) -> 0-dim tensor with the local sum of (e - mean)^2."""
+    buf = torch.stack([sum_e, torch.as_tensor(float(count), dtype=sum_e.dtype, device=sum_e.device)])
+    all_reduce_sum_(buf)
+    n = buf[1].item()
+    mean = (buf[0] / buf[1]).item()
+    ss = centered_sumsq_fn(mean).reshape(1).clone()
+    all_reduce_sum_(ss)
+    std = (ss[0] / (n - 1)).sqrt().item() if n > 1 else float("nan")
+    return mean, std, int(round(n))

@@ -1,0 +1,34 @@
+"""Permutation-equivariant backflow velocity field (src/equivariant_funs.py):
+    v_i = sum_{j != i} eta(|r_i - r_j|) (r_i - r_j) + mu(|r_i|) r_i
+and its hand-derived divergence.  Stand-alone calls run ff_backflow_v_div (any n <= 24, d <= 3, any H);
+inside flow.CNF the field is fused into the ODE kernels.
+"""
+import torch
+
+from . import _lib as L
+from . import native
+
+
+class Backflow(torch.nn.Module):
+    def __init__(self, eta, mu=None):
+        """ The argument eta must be an instance of torch.nn.Module. """
+        super(Backflow, self).__init__()
+        self.eta = eta
+        self.mu = mu
+
+    def net(self):
+        return L.Net(self.eta, self.mu)
+
+    def forward(self, x):
+        v, _ = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=True, need_div=False)
+        return v
+
+    def divergence(self, x):
+        _, div = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=False, need_div=True)
+        return div
+
+    def _e_e(self, x):
+        return native.backflow_v_div(L.Net(self.eta, None), x.detach().contiguous(), True, False)[0]
+
+    def _e_e_divergence(self, x):
+        return native.backflow_v_div(L.Net(self.eta, None), x.detach().contiguous(), False, True)[1]

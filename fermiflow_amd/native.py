@@ -1,0 +1,186 @@
+"""Tensor-level wrappers over the C ABI (include/fermiflow.h).  Every function takes/returns fp64 CUDA
+tensors, enqueues on torch's current stream and never synchronises."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def orbital_table(idx, device):
+    """int32 device table [n_states, n_spin] from a (list of) orbital index list(s)."""
+    t = torch.as_tensor(idx, dtype=torch.int32)
+    if t.dim() == 1:
+        t = t[None]
+    return t.contiguous().to(device)
+
+
+def _state(ws):
+    return None if ws is None else L.dev(ws, torch.int32, "walker_state")
+
+
+def slater_fwd(table, x, walker_state=None):
+    x = L.dev(x, name="x")
+    B, n = x.shape[0], x.shape[1]
+    out = torch.empty(B, dtype=torch.float64, device=x.device)
+    L.check(L.lib().ff_slater_logabsdet_fwd(L.stream(), L.i64(B), n, L.ptr(table), L.ptr(_state(walker_state)), L.ptr(x),
+                                            L.ptr(out)), "ff_slater_logabsdet_fwd")
+    return out
+
+
+def slater_bwd(table, x, grad_out, walker_state=None):
+    x = L.dev(x, name="x"); go = L.dev(grad_out, name="grad_out")
+    B, n = x.shape[0], x.shape[1]
+    gx = torch.empty_like(x)
+    L.check(L.lib().ff_slater_logabsdet_bwd(L.stream(), L.i64(B), n, L.ptr(table), L.ptr(_state(walker_state)), L.ptr(x),
+                                            L.ptr(go), L.ptr(gx)), "ff_slater_logabsdet_bwd")
+    return gx
+
+
+def logprob(tab_up, tab_dn, nup, ndn, x, walker_state=None, derivs=False):
+    x = L.dev(x, name="x")
+    B = x.shape[0]
+    logp = torch.empty(B, dtype=torch.float64, device=x.device)
+    grad = torch.empty_like(x) if derivs else None
+    lap = torch.empty(B, dtype=torch.float64, device=x.device) if derivs else None
+    L.check(L.lib().ff_logprob(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                               L.ptr(x), L.ptr(logp), L.ptr(grad), L.ptr(lap)), "ff_logprob")
+    return (logp, grad, lap) if derivs else logp
+
+
+def mcmc_sample(tab_up, tab_dn, nup, ndn, B, steps, tau, seed, device, walker_offset=0, walker_state=None):
+    n = nup + ndn
+    x = torch.empty(B, n, 2, dtype=torch.float64, device=device)
+    logp = torch.empty(B, dtype=torch.float64, device=device)
+    cnt = torch.empty(B, dtype=torch.int32, device=device)
+    L.check(L.lib().ff_mcmc_sample(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                   int(steps), L.f64(tau), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
+                                   L.ptr(x), L.ptr(logp), L.ptr(cnt)), "ff_mcmc_sample")
+    return x, logp, cnt
+
+
+def mcmc_sample_noise(tab_up, tab_dn, nup, ndn, g0, g, u, tau=0.1, walker_state=None):
+    g0, g, u = L.dev(g0, name="g0"), L.dev(g, name="g"), L.dev(u, name="u")
+    B, steps = g0.shape[0], g.shape[0]
+    x = torch.empty_like(g0)
+    logp = torch.empty(B, dtype=torch.float64, device=g0.device)
+    acc = torch.empty(steps, B, dtype=torch.uint8, device=g0.device)
+    L.check(L.lib().ff_mcmc_sample_noise(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn),
+                                         L.ptr(_state(walker_state)), int(steps), L.f64(tau), L.ptr(g0), L.ptr(g), L.ptr(u),
+                                         L.ptr(x), L.ptr(logp), L.ptr(acc)), "ff_mcmc_sample_noise")
+    return x, logp, acc
+
+
+def rng_fill(B, n, steps, seed, device, walker_offset=0):
+    g0 = torch.empty(B, n, 2, dtype=torch.float64, device=device)
+    g = torch.empty(steps, B, n, 2, dtype=torch.float64, device=device)
+    u = torch.empty(steps, B, dtype=torch.float64, device=device)
+    L.check(L.lib().ff_rng_fill(L.stream(), L.i64(B), n, int(steps), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
+                                L.ptr(g0), L.ptr(g), L.ptr(u)), "ff_rng_fill")
+    return g0, g, u
+
+
+def mlp_eval(w1, b1, w2, r, need_grad=True):
+    r = L.dev(r, name="r")
+    w1, b1, w2 = L.dev(w1.reshape(-1)), L.dev(b1), L.dev(w2.reshape(-1))
+    val = torch.empty_like(r)
+    dval = torch.empty_like(r) if need_grad else None
+    L.check(L.lib().ff_mlp_eval(L.stream(), L.i64(r.numel()), b1.numel(), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(r),
+                                L.ptr(val), L.ptr(dval)), "ff_mlp_eval")
+    return val, dval
+
+
+def backflow_v_div(net, x, need_v=True, need_div=True):
+    x = L.dev(x, name="x")
+    B, n, d = x.shape
+    v = torch.empty_like(x) if need_v else None
+    div = torch.empty(B, dtype=torch.float64, device=x.device) if need_div else None
+    L.check(L.lib().ff_backflow_v_div(L.stream(), L.i64(B), n, d, net.ref(), L.ptr(x), L.ptr(v), L.ptr(div)),
+            "ff_backflow_v_div")
+    return v, div
+
+
+def potential(x, Z, use_ho):
+    x = L.dev(x, name="x")
+    B, n, d = x.shape
+    V = torch.empty(B, dtype=torch.float64, device=x.device)
+    L.check(L.lib().ff_potential(L.stream(), L.i64(B), n, d, L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(V)), "ff_potential")
+    return V
+
+
+def _stats(device, want):
+    return torch.zeros(4, dtype=torch.int32, device=device) if want else None
+
+
+def cnf_generate(net, z, t0, t1, rtol, atol, want_stats=False):
+    z = L.dev(z, name="z")
+    B, n, d = z.shape
+    x = torch.empty_like(z)
+    st = _stats(z.device, want_stats)
+    o = L.ode(t0, t1, rtol, atol)
+    L.check(L.lib().ff_cnf_generate(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(z), L.ptr(x), L.ptr(st)),
+            "ff_cnf_generate")
+    return (x, st) if want_stats else x
+
+
+def cnf_delta_logp(net, x, t0, t1, rtol, atol, want_stats=False):
+    x = L.dev(x, name="x")
+    B, n, d = x.shape
+    z = torch.empty_like(x)
+    dl = torch.empty(B, dtype=torch.float64, device=x.device)
+    st = _stats(x.device, want_stats)
+    o = L.ode(t0, t1, rtol, atol)
+    L.check(L.lib().ff_cnf_delta_logp(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(x), L.ptr(z), L.ptr(dl),
+                                      L.ptr(st)), "ff_cnf_delta_logp")
+    return (z, dl, st) if want_stats else (z, dl)
+
+
+def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, want_stats=False):
+    """Adjoint sweep from t_from (where y_start, a_z, a_d are given) to t_to."""
+    y = L.dev(y_start, name="y_start"); a_z = L.dev(a_z, name="a_z"); a_d = L.dev(a_d, name="a_d")
+    B, n, d = y.shape
+    gx = torch.empty_like(y) if need_gx else None
+    gp = torch.empty(net.nparams, dtype=torch.float64, device=y.device)
+    nbytes = L.lib().ff_cnf_adjoint_workspace_bytes(L.i64(B), n, d, net.He, net.Hm)
+    ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=y.device)
+    st = _stats(y.device, want_stats)
+    o = L.ode(t_from, t_to, rtol, atol)
+    L.check(L.lib().ff_cnf_adjoint(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(a_d),
+                                   L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint")
+    return (gx, gp, st) if want_stats else (gx, gp)
+
+
+def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker_state=None, want_stats=False,
+         pass1_events=None):
+    """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity kernel
+    only (bench.py times the dominant kernel with it)."""
+    x = L.dev(x, name="x")
+    B, n = x.shape[0], nup + ndn
+    f = dict(dtype=torch.float64, device=x.device)
+    out = dict(logp=torch.empty(B, **f), grad=torch.empty_like(x), lap=torch.empty(B, **f), V=torch.empty(B, **f),
+               eloc=torch.empty(B, **f), z=torch.empty_like(x), dlogp=torch.empty(B, **f), glogp0=torch.empty_like(x))
+    nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, 2)
+    ws = torch.empty(max(1, nbytes // 8), **f)
+    st = _stats(x.device, want_stats)
+    o = L.ode(t0, t1, rtol, atol)
+    if pass1_events is not None:
+        pass1_events[0].record()
+    L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, 2, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),
+            "ff_eloc_sensitivities")
+    if pass1_events is not None:
+        pass1_events[1].record()
+    L.check(L.lib().ff_eloc_finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                   L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(ws), L.ptr(out["logp"]), L.ptr(out["grad"]),
+                                   L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), L.ptr(out["z"]),
+                                   L.ptr(out["dlogp"]), L.ptr(out["glogp0"])), "ff_eloc_finish")
+    if want_stats:
+        out["stats"] = st
+    return out
+
+
+def reduce_moments(e, shift=0.0):
+    """tensor [sum(e - shift), sum((e - shift)^2)] on the device."""
+    e = L.dev(e, name="e")
+    out = torch.empty(2, dtype=torch.float64, device=e.device)
+    L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(out)), "ff_reduce_moments")
+    return out

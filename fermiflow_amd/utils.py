@@ -1,0 +1,32 @@
+"""y_grad_laplacian (src/utils.py:40-65) for the functions the hot path applies it to.
+
+The reference obtains grad and Laplacian of log p by 1 + n*d extra autograd passes through nested adjoint
+ODE solves.  Here they come out of one native pass; `f` must therefore be one of the callables that know
+how to do that (GSVMC.logp / BetaVMC.logp bound methods, or a FreeFermion.log_prob closure made by
+`freefermion_logp`)."""
+from . import native
+from .orbitals import orbital_indices
+
+
+class freefermion_logp:
+    """log p_0(x) of a FreeFermion state as a callable understood by y_grad_laplacian."""
+
+    def __init__(self, basedist, orbitals_up, orbitals_down):
+        self.nup, self.ndn = len(orbitals_up), len(orbitals_down)
+        self.tu = native.orbital_table(orbital_indices(orbitals_up), basedist.device) if self.nup else None
+        self.td = native.orbital_table(orbital_indices(orbitals_down), basedist.device) if self.ndn else None
+
+    def __call__(self, x):
+        return native.logprob(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous())
+
+    def _native_grad_laplacian(self, x):
+        return native.logprob(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous(), derivs=True)
+
+
+def y_grad_laplacian(f, x):
+    target = getattr(f, "__self__", f)
+    fn = getattr(target, "_native_grad_laplacian", None)
+    if fn is None:
+        raise NotImplementedError("y_grad_laplacian: no native gradient/Laplacian for this callable "
+                                  "(supported: GSVMC.logp, BetaVMC.logp, utils.freefermion_logp)")
+    return fn(x)

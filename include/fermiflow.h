@@ -1,0 +1,132 @@
+/* fermiflow.h -- C ABI of libfermiflow_hip.so: the MI355X-native VMC inner loop of FermiFlow.
+ *
+ * The reference (buwantaiji/FermiFlow) has no FFI layer: its hot path is Python/PyTorch objects
+ * (SURVEY.md 8b).  Each entry point below replaces the arithmetic behind one of those Python
+ * call sites; the Python classes in fermiflow_amd/ keep the reference signatures and call in here
+ * through ctypes with raw device pointers (INTEGRATION.md shows the binding).  Paths are relative
+ * to the reference root.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp64 (or int32/uint8 where typed so), contiguous,
+ *    row-major; walker coordinates are (B, n, d) exactly as the reference's tensors;
+ *  - `stream` is a hipStream_t (0 = default stream); every call only enqueues work, no hidden sync;
+ *  - the library allocates nothing: callers pass workspaces where a size query exists;
+ *  - return value: 0 ok, 1 invalid argument, 2 no native instantiation for this configuration,
+ *    3 HIP launch failure; ff_last_error() gives a message.  No C++ exception crosses the ABI.
+ *  - orbitals are identified by their index k into HO2D().orbitals (src/orbitals.py:81,
+ *    k <-> (nx, shell-nx)); an orbital table is int32 [n_states][n_spin]; `walker_state` (int32 [B],
+ *    may be NULL = all walkers use row 0) selects the row per walker (BetaVMC, src/VMC.py:89-103).
+ */
+#ifndef FERMIFLOW_H
+#define FERMIFLOW_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The two scalar MLPs eta, mu of the backflow (src/MLP.py:9-16; Backflow(eta, mu), src/equivariant_funs.py:11-15).
+ * w1 = fc1.weight (H,1) flattened, b1 = fc1.bias (H), w2 = fc2.weight (1,H) flattened.  Hm = 0 <=> mu=None. */
+typedef struct ff_net {
+  int32_t He; const double *ew1, *eb1, *ew2;
+  int32_t Hm; const double *mw1, *mb1, *mw2;
+} ff_net;
+
+/* ODE controls of solve_ivp_nnmodule (src/NeuralODE/nnModule.py:161-162: rtol=1e-6, atol=1e-8). */
+typedef struct ff_ode {
+  double t0, t1;      /* CNF t_span (src/flow.py:7-40) */
+  double rtol, atol;
+  int32_t max_steps;  /* safety bound on accepted+rejected steps per walker (0 -> 10000) */
+} ff_ode;
+
+int ff_version(void);
+const char* ff_last_error(void);
+
+/* ---- Slater determinants / base distribution ------------------------------------------------ */
+/* LogAbsSlaterDet.forward (src/slater.py:13-37): logabsdet[b] = log|det phi_j(r_i)|, x (B,n,2). */
+int ff_slater_logabsdet_fwd(void* stream, int64_t B, int n, const int32_t* orb_table, const int32_t* walker_state,
+                            const double* x, double* logabsdet);
+/* LogAbsSlaterDet.backward (src/slater.py:40-62): grad_x[b,i,:] = grad_out[b] * sum_j grad phi_j(r_i) Dinv[j,i]. */
+int ff_slater_logabsdet_bwd(void* stream, int64_t B, int n, const int32_t* orb_table, const int32_t* walker_state,
+                            const double* x, const double* grad_out, double* grad_x);
+/* FreeFermion.log_prob (src/base_dist.py:49-56) = 2*(log|det up| + log|det down|), plus optionally its
+ * gradient (B,n,2) and Laplacian (B) wrt x (what y_grad_laplacian, src/utils.py:40-65, extracts). */
+int ff_logprob(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+               const int32_t* walker_state, const double* x, double* logp, double* grad, double* lap);
+
+/* ---- MCMC (FreeFermion.sample loop, src/base_dist.py:58-71) -------------------------------- */
+/* Parity mode: explicit noise in the reference's draw order: g0 (B,n,2) initial N(0,1) walkers,
+ * g (S,B,n,2) proposal noise, u (S,B) uniforms.  accept (S,B) uint8 may be NULL. */
+int ff_mcmc_sample_noise(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                         const int32_t* walker_state, int steps, double tau,
+                         const double* g0, const double* g, const double* u,
+                         double* x_out, double* logp_out, uint8_t* accept);
+/* Throughput mode: counter-based Philox4x32-10 + Box-Muller on device; walker b of the global batch
+ * uses counter (walker_offset + b), so shards of one batch draw disjoint streams.
+ * accept_count (int32 [B], may be NULL) receives the number of accepted proposals. */
+int ff_mcmc_sample(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                   const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                   double* x_out, double* logp_out, int32_t* accept_count);
+/* The very noise ff_mcmc_sample consumes, materialised (for tests: feed it to ff_mcmc_sample_noise). */
+int ff_rng_fill(void* stream, int64_t B, int n, int steps, uint64_t seed, int64_t walker_offset,
+                double* g0, double* g, double* u);
+
+/* ---- backflow / MLP / potentials ------------------------------------------------------------ */
+/* MLP.forward / MLP.grad (src/MLP.py:30-45) on N scalars r; dval may be NULL. */
+int ff_mlp_eval(void* stream, int64_t N, int H, const double* w1, const double* b1, const double* w2,
+                const double* r, double* val, double* dval);
+/* Backflow.forward / .divergence (src/equivariant_funs.py:83-102); v (B,n,d) / div (B) may be NULL. */
+int ff_backflow_v_div(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div);
+/* HO.V + CoulombPairPotential(Z).V (src/potentials.py:13, 23-47); use_ho = 0 drops the trap term. */
+int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V);
+
+/* ---- CNF: fused adaptive Dormand-Prince 5(4) integrations, one walker group per wave ------------ */
+/* stats (int32 [4], may be NULL; caller zeroes): [0] += RHS evaluations summed over walkers,
+ * [1] = max accepted steps of any walker, [2] += rejected steps, [3] |= failure flags. */
+/* CNF.generate (src/flow.py:42-44): x = z + int_{t0}^{t1} v dt. */
+int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
+                    const double* z, double* x_out, int32_t* stats);
+/* CNF.delta_logp (src/flow.py:51-55): integrate (x,0) under (v,-div v) from t1 to t0 -> (z, delta). */
+int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
+                      const double* x, double* z_out, double* dlogp_out, int32_t* stats);
+/* Backward of delta_logp (SolveIVP.backward + F_augFull, src/NeuralODE/nnModule.py:76-133): given the
+ * forward result z(t0) and the incoming gradients a_z (B,n,d), a_d (B), integrates the adjoint system
+ * from t0 to t1 and returns grad_x (B,n,d; may be NULL) and the parameter gradient grad_params
+ * [3*He + 3*Hm] in Backflow.parameters() order (eta.fc1.weight, eta.fc1.bias, eta.fc2.weight, mu.*).
+ * workspace: ff_cnf_adjoint_workspace_bytes(...) bytes of device memory. */
+size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm);
+int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
+                   const double* z_t0, const double* a_z, const double* a_d,
+                   double* grad_x, double* grad_params, void* workspace, int32_t* stats);
+
+/* ---- local energy (src/VMC.py:46-55 via src/utils.py:40-65) --------------------------------- */
+/* Two launches: (1) a fused per-walker Dormand-Prince pass integrating z, J = dz/dx, the x-Laplacian of z,
+ * delta and its x-gradient / x-Laplacian from t1 to t0; (2) a finish kernel contracting them with the
+ * Slater gradient / Hessian at z(t0):
+ *   logp = logp0(z) - delta,  grad = d logp/dx (B,n,2),  lap = sum_i d2 logp/dx_i^2,
+ *   V = Coulomb + trap,  eloc = -lap/4 - |grad|^2/8 + V.
+ * Any of logp, grad, lap, V, eloc may be NULL.  Optional extra outputs (may be NULL): z_out (B,n,2) = z(t0),
+ * dlogp_out (B) = delta, glogp0_out (B,n,2) = grad_z logp0(z(t0)).
+ * workspace: ff_eloc_workspace_bytes(B, n, 2) bytes of device memory (the sensitivities between the launches). */
+size_t ff_eloc_workspace_bytes(int64_t B, int n, int d);
+int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+            const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho,
+            const double* x, double* logp, double* grad, double* lap, double* V, double* eloc,
+            double* z_out, double* dlogp_out, double* glogp0_out, void* workspace, int32_t* stats);
+
+/* The two launches of ff_eloc individually (same arguments; results of pass 1 stay in `workspace`). */
+int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
+                          const double* x, void* workspace, int32_t* stats);
+int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                   const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                   double* logp, double* grad, double* lap, double* V, double* eloc,
+                   double* z_out, double* dlogp_out, double* glogp0_out);
+
+/* ---- estimator reductions (src/VMC.py:57-58) ------------------------------------------------ */
+/* out2[0] = sum_b (e[b] - shift), out2[1] = sum_b (e[b] - shift)^2; one workgroup, fixed summation tree
+ * (deterministic).  Called with shift = 0 for the mean, then with shift = mean for the unbiased std. */
+int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, double* out2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

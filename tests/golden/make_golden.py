@@ -321,11 +321,24 @@ def g_betavmc(R_unused):
     for tag, boltz, bta in (("boltz", True, 10.0), ("hot", True, 0.5)):
         model = R.VMC.BetaVMC(bta, nup, 0, dE, boltz, ho, bd, cnf,
                               R.potentials.CoulombPairPotential(2.0), sp_potential=R.potentials.HO())
+        # capture the per-walker data of this very forward (x, E_loc, logp) by wrapping the pieces it calls
+        cap = {}
+        orig_sample, orig_ygl = model.sample, R.utils.y_grad_laplacian
+        def sample_cap(shape, nframes=None):
+            z, x = orig_sample(shape, nframes=nframes); cap["z"], cap["x"] = z.detach().clone(), x.detach().clone(); return z, x
+        def ygl_cap(f, x):
+            y, g, l = orig_ygl(f, x); cap["logp"], cap["grad"], cap["lap"] = y.detach().clone(), g.detach().clone(), l.detach().clone(); return y, g, l
+        model.sample = sample_cap; R.utils.y_grad_laplacian = ygl_cap
         torch.manual_seed(seed)
         with contextlib.redirect_stdout(io.StringIO()):
             gphi, gtheta = model(B)
+        model.sample = orig_sample; R.utils.y_grad_laplacian = orig_ygl
         model.zero_grad()
         (gphi + gtheta).backward()
+        for k_, v_ in cap.items():
+            out[f"{tag}_{k_}"] = v_.numpy()
+        kin = -0.25 * cap["lap"] - 0.125 * (cap["grad"] ** 2).sum(dim=(-2, -1))
+        out[f"{tag}_Eloc"] = (kin + model.pair_potential.V(cap["x"]) + model.sp_potential.V(cap["x"])).numpy()
         keys = list(model.state_indices_collection.keys()); cnts = list(model.state_indices_collection.values())
         out[f"{tag}_cfg"] = np.array([nup, B, seed], dtype=np.int64)
         out[f"{tag}_beta"] = np.array(bta); out[f"{tag}_dE"] = np.array(dE)

@@ -1,0 +1,72 @@
+// hip_shim.h -- TEST-ONLY host simulation of the small HIP subset the FermiFlow kernels use.
+//
+// Lets tests/hostsim/ compile fermiflow_amd/csrc/*.hip with g++ (-DFF_HOSTSIM) so the kernel sources can be
+// exercised in the GPU-less build container: every workgroup runs as blockDim.x host threads with a real
+// barrier for __syncthreads(); workgroups run one after another; "device" pointers are host pointers.
+// Never part of the product: fermiflow_amd loads only the hipcc-built library and needs a GPU.
+#pragma once
+#include <pthread.h>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+struct ff_sim_dim3 { unsigned x = 1, y = 1, z = 1; };
+inline thread_local ff_sim_dim3 threadIdx, blockIdx, blockDim, gridDim;
+inline pthread_barrier_t* ff_sim_bar = nullptr;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __constant__ static const
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __syncthreads() pthread_barrier_wait(ff_sim_bar)
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline int hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(int) { return "hostsim"; }
+inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return 0; }
+
+template <class T> inline T ff_sim_atomic_add(T* p, T v) {
+  std::atomic_ref<T> a(*p);
+  T old = a.load();
+  while (!a.compare_exchange_weak(old, old + v)) {}
+  return old;
+}
+inline double atomicAdd(double* p, double v) { return ff_sim_atomic_add(p, v); }
+inline int atomicAdd(int* p, int v) { return ff_sim_atomic_add(p, v); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return ff_sim_atomic_add(p, v); }
+inline int atomicMax(int* p, int v) {
+  std::atomic_ref<int> a(*p);
+  int old = a.load();
+  while (old < v && !a.compare_exchange_weak(old, v)) {}
+  return old;
+}
+inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
+
+template <class K, class... A>
+inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, block);
+  ff_sim_bar = &bar;
+  for (unsigned b = 0; b < grid; b++) {
+    std::vector<std::thread> th;
+    th.reserve(block);
+    for (unsigned t = 0; t < block; t++)
+      th.emplace_back([=]() {
+        threadIdx.x = t; blockIdx.x = b; blockDim.x = block; gridDim.x = grid;
+        kernel(args...);
+      });
+    for (auto& x : th) x.join();
+  }
+  pthread_barrier_destroy(&bar);
+  ff_sim_bar = nullptr;
+}
+#define FF_LAUNCH(kernel, grid, block, stream, ...) ff_sim_launch(kernel, (unsigned)(grid), (unsigned)(block), __VA_ARGS__)

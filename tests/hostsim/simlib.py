@@ -1,0 +1,186 @@
+"""TEST-ONLY: numpy/ctypes access to tests/hostsim/libff_hostsim.so -- the kernel sources of
+fermiflow_amd/csrc compiled for the host (see hip_shim.h).  "Device" pointers are numpy buffers.
+Used by tests/test_hostsim.py to exercise the kernels' logic in the GPU-less build container.
+The product package never imports this."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FFNet(C.Structure):
+    _fields_ = [("He", C.c_int32), ("ew1", C.c_void_p), ("eb1", C.c_void_p), ("ew2", C.c_void_p),
+                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p)]
+
+
+class FFOde(C.Structure):
+    _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_steps", C.c_int32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-j4", "-C", HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        _LIB = C.CDLL(os.path.join(HERE, "libff_hostsim.so"))
+        _LIB.ff_last_error.restype = C.c_char_p
+        _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
+        _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ck(st):
+    if st != 0:
+        raise RuntimeError(f"ff status {st}: {lib().ff_last_error().decode()}")
+
+
+class Net:
+    def __init__(self, eta, mu=None):
+        self.e = [_d(np.reshape(a, -1)) for a in eta]
+        self.m = [_d(np.reshape(a, -1)) for a in mu] if mu is not None else None
+        self.c = FFNet(len(self.e[0]), _p(self.e[0]), _p(self.e[1]), _p(self.e[2]),
+                       len(self.m[0]) if self.m else 0,
+                       _p(self.m[0]) if self.m else None, _p(self.m[1]) if self.m else None,
+                       _p(self.m[2]) if self.m else None)
+
+    @property
+    def nparams(self):
+        return 3 * self.c.He + 3 * self.c.Hm
+
+
+def _tabs(nup, ndn, tab_up, tab_dn):
+    tu = _i(np.arange(nup) if tab_up is None else tab_up) if nup else None
+    td = _i(np.arange(ndn) if tab_dn is None else tab_dn) if ndn else None
+    return tu, td
+
+
+def logprob(x, nup, ndn, tab_up=None, tab_dn=None, wstate=None):
+    x = _d(x); B = x.shape[0]
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    lp = np.empty(B); g = np.empty_like(x); l = np.empty(B)
+    _ck(lib().ff_logprob(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), _p(x), _p(lp), _p(g), _p(l)))
+    return lp, g, l
+
+
+def slater(x, orb, wstate=None, gout=None):
+    x = _d(x); B, n, _ = x.shape
+    t = _i(orb); ws = _i(wstate) if wstate is not None else None
+    lad = np.empty(B)
+    _ck(lib().ff_slater_logabsdet_fwd(None, C.c_int64(B), n, _p(t), _p(ws), _p(x), _p(lad)))
+    gx = None
+    if gout is not None:
+        gx = np.empty_like(x); go = _d(gout)
+        _ck(lib().ff_slater_logabsdet_bwd(None, C.c_int64(B), n, _p(t), _p(ws), _p(x), _p(go), _p(gx)))
+    return lad, gx
+
+
+def mcmc_noise(g0, g, u, nup, ndn, tau=0.1, tab_up=None, tab_dn=None, wstate=None):
+    g0, g, u = _d(g0), _d(g), _d(u)
+    B = g0.shape[0]; steps = g.shape[0]
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    x = np.empty_like(g0); lp = np.empty(B); acc = np.empty((steps, B), dtype=np.uint8)
+    _ck(lib().ff_mcmc_sample_noise(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), steps, C.c_double(tau),
+                                   _p(g0), _p(g), _p(u), _p(x), _p(lp), _p(acc)))
+    return x, lp, acc
+
+
+def mcmc(B, nup, ndn, steps, seed, offset=0, tau=0.1):
+    n = nup + ndn
+    tu, td = _tabs(nup, ndn, None, None)
+    x = np.empty((B, n, 2)); lp = np.empty(B); cnt = np.empty(B, dtype=np.int32)
+    _ck(lib().ff_mcmc_sample(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), None, steps, C.c_double(tau),
+                             C.c_uint64(seed), C.c_int64(offset), _p(x), _p(lp), _p(cnt)))
+    return x, lp, cnt
+
+
+def rng_fill(B, n, steps, seed, offset=0):
+    g0 = np.empty((B, n, 2)); g = np.empty((steps, B, n, 2)); u = np.empty((steps, B))
+    _ck(lib().ff_rng_fill(None, C.c_int64(B), n, steps, C.c_uint64(seed), C.c_int64(offset), _p(g0), _p(g), _p(u)))
+    return g0, g, u
+
+
+def backflow(x, net):
+    x = _d(x); B, n, d = x.shape
+    v = np.empty_like(x); div = np.empty(B)
+    _ck(lib().ff_backflow_v_div(None, C.c_int64(B), n, d, C.byref(net.c), _p(x), _p(v), _p(div)))
+    return v, div
+
+
+def potential(x, Z, use_ho=True):
+    x = _d(x); B, n, d = x.shape
+    V = np.empty(B)
+    _ck(lib().ff_potential(None, C.c_int64(B), n, d, C.c_double(Z), int(use_ho), _p(x), _p(V)))
+    return V
+
+
+def mlp(r, w1, b1, w2):
+    r = _d(r).reshape(-1); w1, b1, w2 = _d(w1).reshape(-1), _d(b1), _d(w2).reshape(-1)
+    v = np.empty_like(r); dv = np.empty_like(r)
+    _ck(lib().ff_mlp_eval(None, C.c_int64(len(r)), len(b1), _p(w1), _p(b1), _p(w2), _p(r), _p(v), _p(dv)))
+    return v, dv
+
+
+def _ode(t0, t1, rtol, atol):
+    return FFOde(t0, t1, rtol, atol, 0)
+
+
+def cnf_generate(z, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    z = _d(z); B, n, d = z.shape
+    x = np.empty_like(z); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    _ck(lib().ff_cnf_generate(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z), _p(x), _p(stats)))
+    return x, stats
+
+
+def cnf_delta_logp(x, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    x = _d(x); B, n, d = x.shape
+    z = np.empty_like(x); dl = np.empty(B); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    _ck(lib().ff_cnf_delta_logp(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(x), _p(z), _p(dl), _p(stats)))
+    return z, dl, stats
+
+
+def cnf_adjoint(z0, a_z, a_d, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    z0, a_z, a_d = _d(z0), _d(a_z), _d(a_d); B, n, d = z0.shape
+    gx = np.empty_like(z0); gp = np.empty(net.nparams); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    ws = np.zeros(max(1, lib().ff_cnf_adjoint_workspace_bytes(C.c_int64(B), n, d, net.c.He, net.c.Hm) // 8))
+    _ck(lib().ff_cnf_adjoint(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z0), _p(a_z), _p(a_d),
+                             _p(gx), _p(gp), _p(ws), _p(stats)))
+    return gx, gp, stats
+
+
+def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None):
+    x = _d(x); B = x.shape[0]; n = nup + ndn
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    o = dict(logp=np.empty(B), grad=np.empty_like(x), lap=np.empty(B), V=np.empty(B), eloc=np.empty(B),
+             z=np.empty_like(x), dlogp=np.empty(B), glogp0=np.empty_like(x))
+    stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    wk = np.zeros(lib().ff_eloc_workspace_bytes(C.c_int64(B), n, 2) // 8)
+    _ck(lib().ff_eloc(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), C.byref(net.c), C.byref(ode), C.c_double(Z),
+                      int(use_ho), _p(x), _p(o["logp"]), _p(o["grad"]), _p(o["lap"]), _p(o["V"]), _p(o["eloc"]),
+                      _p(o["z"]), _p(o["dlogp"]), _p(o["glogp0"]), _p(wk), _p(stats)))
+    o["stats"] = stats
+    return o
+
+
+def moments(e, shift=0.0):
+    e = _d(e); out = np.empty(2)
+    _ck(lib().ff_reduce_moments(None, C.c_int64(len(e)), _p(e), C.c_double(shift), _p(out)))
+    return out

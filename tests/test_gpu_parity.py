@@ -1,0 +1,283 @@
+"""Parity tests proper: the hipcc-built kernels on a real MI355X, called through the C ABI (fermiflow_amd.native /
+the reference-named classes), against the golden vectors from the reference and against the oracle.
+
+Bars (BASELINE.json north_star): MCMC acceptance indices bit-exact; E_loc within 1e-5 relative in fp64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.common import mcmc_noise_from_seed, net_arrays, cnf_param_grads, gsvmc_param_grads
+
+pytestmark = pytest.mark.gpu
+ELOC_RTOL = 1e-5     # the bar of the north star; observed ~1e-9
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def T(a, dev, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_mlp(w, dev):
+    import fermiflow_amd as ff
+    m = ff.MLP(1, len(w[1]))
+    with torch.no_grad():
+        m.fc1.weight.copy_(torch.as_tensor(w[0]).reshape(-1, 1))
+        m.fc1.bias.copy_(torch.as_tensor(w[1]))
+        m.fc2.weight.copy_(torch.as_tensor(w[2]).reshape(1, -1))
+    return m.to(dev)
+
+
+def make_flow(eta, mu, dev):
+    import fermiflow_amd as ff
+    v = ff.Backflow(make_mlp(eta, dev), mu=make_mlp(mu, dev) if mu is not None else None)
+    return ff.CNF(v, (0.0, 1.0))
+
+
+# ------------------------------------------------------------------------------------------------ Slater
+def test_slater_fwd_bwd_laplacian(golden, dev):
+    import fermiflow_amd as ff
+    from fermiflow_amd import native
+    G = golden["g2_slater"]
+    h = ff.HO2D()
+    for n in (1, 3, 5, 6, 10):
+        orbs = tuple(h.orbitals[k] for k in G[f"n{n}_orb"])
+        x = T(G[f"n{n}_x"], dev).requires_grad_(True)
+        y = ff.LogAbsSlaterDet.apply(orbs, x)
+        y.sum().backward()
+        np.testing.assert_allclose(N(y), G[f"n{n}_logabsdet"], atol=1e-12)
+        np.testing.assert_allclose(N(x.grad), G[f"n{n}_grad"], rtol=1e-9, atol=1e-9)
+        tab = native.orbital_table(G[f"n{n}_orb"], dev)
+        lp, g, lap = native.logprob(tab, None, n, 0, x.detach(), derivs=True)
+        np.testing.assert_allclose(N(lap) / 2, G[f"n{n}_lap"], rtol=1e-9, atol=1e-7)
+    # several batch dims (src/slater.py:28) and both spins
+    bd = ff.FreeFermion(device=dev)
+    up = tuple(h.orbitals[k] for k in G["lp_up"]); dn = tuple(h.orbitals[k] for k in G["lp_dn"])
+    x = T(G["lp_x"], dev)
+    lp = bd.log_prob(up, dn, x.reshape(4, 5, 9, 2))
+    np.testing.assert_allclose(N(lp).reshape(-1), G["lp_logp"], atol=1e-11)
+    _, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, up, dn), x)
+    np.testing.assert_allclose(N(g), G["lp_grad"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(N(lap), G["lp_lap"], rtol=1e-9, atol=1e-6)
+    # multi-state primitive
+    states, _ = h.fermion_states(3, 0, 2.0)
+    coll = dict(zip(G["ms_keys"].tolist(), G["ms_counts"].tolist()))
+    x = T(G["ms_x"], dev).requires_grad_(True)
+    y = bd.log_prob_multstates(states, coll, x)
+    y.sum().backward()
+    np.testing.assert_allclose(N(y), G["ms_logp"], atol=1e-12)
+    np.testing.assert_allclose(N(x.grad), G["ms_grad"], rtol=1e-9, atol=1e-10)
+
+
+def test_known_answer_eigenfunctions_full_size(dev):
+    """reference tests/test_basedist.py:5-60 at BASELINE size: E_loc == sum of orbital energies for all
+    65536 random points (size-independent property)."""
+    from fermiflow_amd import native
+    torch.manual_seed(0)
+    x = torch.randn(65536, 9, 2, dtype=torch.float64, device=dev)
+    iu, idn = [0, 2, 5], [0, 1, 3, 4, 7, 9]
+    Es = [n + 1 for n in range(8) for _ in range(n + 1)]
+    lp, g, lap = native.logprob(native.orbital_table(iu, dev), native.orbital_table(idn, dev), 3, 6, x, derivs=True)
+    eloc = -0.25 * lap - 0.125 * (g ** 2).sum(dim=(1, 2)) + 0.5 * (x ** 2).sum(dim=(1, 2))
+    want = sum(Es[k] for k in iu) + sum(Es[k] for k in idn)
+    assert (eloc - want).abs().max().item() < 1e-6 * want
+
+
+# ------------------------------------------------------------------------------------------------ MCMC
+@pytest.mark.parametrize("name", ["u3d3", "u6d0", "u6d6", "u1d0", "u10d0"])
+def test_mcmc_bit_exact_vs_reference(golden, dev, name):
+    import fermiflow_amd as ff
+    G = golden["g1_mcmc"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name)
+    h = ff.HO2D()
+    bd = ff.FreeFermion(device=dev)
+    x, logp, acc = bd.sample_with_noise(h.orbitals[:nup], h.orbitals[:ndn], T(g0, dev), T(g, dev), T(u, dev))
+    assert (N(acc) == accept).all(), "acceptance indices differ from the reference"
+    assert (N(x) == G[name + "_x"]).all(), "final walkers are not bit-identical"
+    np.testing.assert_allclose(N(logp), G[name + "_logp"], atol=1e-12)
+
+
+def test_mcmc_full_size_properties(dev):
+    """65536 walkers x 100 steps: fused Philox kernel == noise-fed kernel bit for bit; oracle agrees on the
+    same noise (sampled rows); sharding does not change any walker; acceptance rate in the reference's range."""
+    from fermiflow_amd import native
+    B, S = 65536, 100
+    tu = native.orbital_table([0, 1, 2], dev)
+    x, logp, cnt = native.mcmc_sample(tu, tu, 3, 3, B, S, 0.1, 99, dev)
+    g0, g, u = native.rng_fill(B, 6, S, 99, dev)
+    x2, logp2, acc = native.mcmc_sample_noise(tu, tu, 3, 3, g0, g, u)
+    assert torch.equal(x, x2) and torch.equal(acc.sum(0).to(torch.int32), cnt)
+    rate = cnt.double().mean().item() / S
+    assert 0.70 < rate < 0.80, rate          # reference: 0.75 for (3,3)
+    rows = slice(1000, 1064)
+    xo, lo, ao = O.mcmc_noise(N(g0[rows]), N(g[:, rows]), N(u[:, rows]), 3, 3)
+    assert (ao == N(acc[:, rows])).all() and (xo == N(x[rows])).all()
+    xa, _, _ = native.mcmc_sample(tu, tu, 3, 3, B // 2, S, 0.1, 99, dev, walker_offset=0)
+    xb, _, _ = native.mcmc_sample(tu, tu, 3, 3, B // 2, S, 0.1, 99, dev, walker_offset=B // 2)
+    assert torch.equal(torch.cat([xa, xb]), x)
+    assert abs(g.mean().item()) < 1e-3 and abs(g.std().item() - 1) < 1e-3 and abs(u.mean().item() - 0.5) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ backflow
+def test_backflow_mlp_potentials(golden, dev):
+    import fermiflow_amd as ff
+    G = golden["g3_backflow"]
+    for k in range(int(G["ncase"])):
+        n, d, He, Hm = G[f"c{k}_cfg"]
+        eta, mu = net_arrays(G, f"c{k}_", Hm > 0)
+        v = ff.Backflow(make_mlp(eta, dev), mu=make_mlp(mu, dev) if mu is not None else None)
+        x = T(G[f"c{k}_x"], dev)
+        np.testing.assert_allclose(N(v(x)), G[f"c{k}_v"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(N(v.divergence(x)), G[f"c{k}_div"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(N(ff.HO().V(x)), G[f"c{k}_Vho"], rtol=1e-13)
+        np.testing.assert_allclose(N(ff.CoulombPairPotential(2.0).V(x)), G[f"c{k}_Vc"], rtol=1e-12)
+    m = make_mlp(net_arrays(G, "c0_")[0], dev)
+    r = T(G["mlp_r"], dev)[:, None]
+    np.testing.assert_allclose(N(m(r)).reshape(-1), G["mlp_eta"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(N(m.grad(r)).reshape(-1), G["mlp_deta"], rtol=1e-12, atol=1e-15)
+    # permutation equivariance (reference tests/test_equivariant_funs.py:20-23), n = 10, d = 3
+    eta, mu = net_arrays(G, "c3_")
+    v = ff.Backflow(make_mlp(eta, dev), mu=make_mlp(mu, dev))
+    x = torch.randn(1000, 10, 3, dtype=torch.float64, device=dev)
+    P = torch.randperm(10, device=dev)
+    assert torch.allclose(v(x[:, P, :]), v(x)[:, P, :], rtol=1e-10, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ CNF
+@pytest.mark.parametrize("tag,rt,at,tol", [("tol6", 1e-6, 1e-8, 2e-6), ("tol10", 1e-10, 1e-12, 5e-10)])
+def test_cnf_generate_logp_adjoint(golden, dev, tag, rt, at, tol):
+    G = golden["g4_cnf"]
+    eta, mu = net_arrays(G, "")
+    cnf = make_flow(eta, mu, dev)
+    cnf.rtol, cnf.atol = rt, at
+    x = cnf.generate(T(G[tag + "_z"], dev))
+    np.testing.assert_allclose(N(x), G[tag + "_x"], atol=tol)
+    xg = T(G[tag + "_x"], dev).requires_grad_(True)
+    z, dl = cnf.delta_logp(xg, params_require_grad=True)
+    np.testing.assert_allclose(N(z), G[tag + "_zback"], atol=tol)
+    np.testing.assert_allclose(N(dl), G[tag + "_dlogp"], atol=tol)
+    loss = (T(G[tag + "_cz"], dev) * z).sum() + (T(G[tag + "_cd"], dev) * dl).sum()
+    grads = torch.autograd.grad(loss, [xg] + list(cnf.parameters()))
+    np.testing.assert_allclose(N(grads[0]), G[tag + "_gx"], atol=10 * tol)
+    ref = cnf_param_grads(G, tag)
+    got = np.concatenate([N(g).reshape(-1) for g in grads[1:]])
+    np.testing.assert_allclose(got, ref, atol=10 * tol * np.abs(ref).max())
+
+
+def test_cnf_reversibility_full_size(golden, dev):
+    """generate followed by delta_logp returns to z (src/flow.py:57-69 check_reversibility) on 65536 walkers."""
+    G = golden["g4_cnf"]
+    cnf = make_flow(*net_arrays(G, ""), dev)
+    torch.manual_seed(1)
+    z = torch.randn(65536, 6, 2, dtype=torch.float64, device=dev)
+    x = cnf.generate(z)
+    zb, dl = cnf.delta_logp(x)
+    assert (zb - z).abs().max().item() < 2e-5
+    assert torch.isfinite(dl).all()
+    # a chunk against the oracle (its own batch-global step control): tolerance-level agreement
+    net = O.Net(*net_arrays(G, ""))
+    xo, _ = O.cnf_generate(N(z[:64]), net)
+    np.testing.assert_allclose(N(x[:64]), xo, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ E_loc
+@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu"])
+def test_local_energy_vs_reference(golden, dev, name):
+    import fermiflow_amd as ff
+    G = golden["g5_gsvmc"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    use_mu = bool(G[name + "_use_mu"])
+    eta, mu = net_arrays(G, name + "_", use_mu)
+    cnf = make_flow(eta, mu, dev)
+    model = ff.GSVMC(nup, ndn, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
+                     ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
+    x = T(G[name + "_x"], dev)
+    r = model.local_energy(x, want_stats=True)                     # reference default tolerances
+    assert int(r["stats"][3]) == 0
+    el = G[name + "_Eloc"]
+    assert (np.abs(N(r["eloc"]) - el) / np.abs(el)).max() < ELOC_RTOL
+    np.testing.assert_allclose(N(r["eloc"]), el, rtol=1e-7)         # what is actually achieved
+    np.testing.assert_allclose(N(r["logp"]), G[name + "_logp"], atol=1e-6)
+    np.testing.assert_allclose(N(r["grad"]), G[name + "_grad"], atol=1e-6)
+    np.testing.assert_allclose(N(r["lap"]), G[name + "_lap"], rtol=1e-7, atol=1e-5)
+    np.testing.assert_allclose(N(r["V"]), G[name + "_V"], rtol=1e-12)
+    logp, grad, lap = ff.y_grad_laplacian(model.logp, x)            # the reference's call, src/VMC.py:48
+    assert torch.equal(lap, r["lap"])
+    # theta-gradient of the surrogate from these walkers (src/VMC.py:58, FermionHO2D.py:71)
+    from fermiflow_amd import native
+    w = (r["eloc"] - r["eloc"].mean()) / B
+    _, gp = native.cnf_adjoint(cnf.v_wrapper.v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
+                               need_gx=False)
+    ref = gsvmc_param_grads(G, name, use_mu)
+    np.testing.assert_allclose(N(gp), ref, atol=1e-5 * max(np.abs(ref).max(), 1e-300))
+    np.testing.assert_allclose(((r["logp"] * w).sum()).item(), float(G[name + "_gradE"]), rtol=1e-5, atol=1e-12)
+
+
+def test_local_energy_full_size_known_answer(dev):
+    """65536 walkers, zero-initialised flow (the driver default, src/FermionHO2D.py:40-43), Z = 0: every
+    walker's E_loc is exactly the free-fermion energy 10 (nup = ndown = 3)  -> E = 10, E_std ~ 1e-14."""
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 3, 3, 0.0)
+    for p in model.parameters():
+        torch.nn.init.zeros_(p)
+    torch.manual_seed(3)
+    g = model(65536)
+    g.backward()
+    assert abs(model.E - 10.0) < 1e-9 and model.E_std < 1e-9
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_gsvmc_iteration_statistics_and_oracle(golden, dev):
+    """A full sweep from fresh walkers: per-walker E_loc agrees with the oracle on the very walkers the GPU
+    produced; E is consistent with the reference's value for this configuration (30.43 +- 4.29/sqrt(B))."""
+    import __graft_entry__ as Gm
+    G = golden["g5_gsvmc"]
+    model = Gm._model(dev, 3, 3, 2.0)
+    torch.manual_seed(5)
+    B = 8192
+    gE = model(B)
+    gE.backward()
+    net = O.Net(*net_arrays(G, "z2_nt_"))
+    idx = slice(0, 128)
+    ref = O.eloc(N(model.x[idx]), 3, 3, net, 2.0, rtol=1e-10, atol=1e-12)
+    rel = np.abs(N(model.Eloc[idx]) - ref["eloc"]) / np.abs(ref["eloc"])
+    assert rel.max() < ELOC_RTOL, rel.max()
+    assert abs(model.E - float(G["z2_nt_E"])) < 6 * 4.5 / np.sqrt(32)     # golden E is itself a 32-walker estimate
+    assert 3.0 < model.E_std < 7.0
+    np.testing.assert_allclose(model.E, model.Eloc.mean().item(), rtol=1e-13)
+    np.testing.assert_allclose(model.E_std, model.Eloc.std().item(), rtol=1e-10)
+
+
+def test_betavmc_vs_reference(golden, dev):
+    import fermiflow_amd as ff
+    G = golden["g6_betavmc"]
+    eta, mu = net_arrays(G, "")
+    for tag in ("boltz", "hot"):
+        cnf = make_flow(eta, mu, dev)
+        model = ff.BetaVMC(float(G[tag + "_beta"]), 3, 0, float(G[tag + "_dE"]), True, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
+                           ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+        model.to(dev)
+        assert model.Nstates == 21
+        assert (np.array([[o.k for o in s[0]] for s in model.states]) == G[tag + "_states"]).all()
+        ws = torch.as_tensor(np.repeat(G[tag + "_keys"], G[tag + "_counts"]), dtype=torch.int32, device=dev)
+        r = model.local_energy(T(G[tag + "_x"], dev), ws)
+        el = G[tag + "_Eloc"]
+        assert (np.abs(N(r["eloc"]) - el) / np.abs(el)).max() < ELOC_RTOL
+        np.testing.assert_allclose(N(r["logp"]), G[tag + "_logp"], atol=1e-6)
+        # a full native forward/backward runs and gives sane thermodynamics
+        torch.manual_seed(0)
+        gphi, gtheta = model(512)
+        (gphi + gtheta).backward()
+        np.testing.assert_allclose(model.S_analytical, float(G[tag + "_S_analytical"]), rtol=1e-12)
+        np.testing.assert_allclose(N(model.logp_states_all), G[tag + "_logp_states_all"], atol=1e-12)
+        assert np.isfinite([model.E, model.F, model.S]).all()
+        assert model.log_state_weights.grad is not None and all(p.grad is not None for p in cnf.parameters())

@@ -1,0 +1,88 @@
+"""The kernel SOURCES of fermiflow_amd/csrc compiled for the host (tests/hostsim: one OS thread per lane, real
+barriers) checked against the golden vectors and the oracle.  This exercises the kernels' logic -- lane
+mapping, LDS hand-offs, step control, reductions -- in the GPU-less build container; the `-m gpu` tests in
+test_gpu_parity.py are the parity tests proper (hipcc build, through the C ABI, on the MI355X)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.common import mcmc_noise_from_seed, net_arrays, cnf_param_grads, gsvmc_param_grads
+from tests.hostsim import simlib as S
+
+
+def test_slater_kernels(golden):
+    G = golden["g2_slater"]
+    for n in (3, 6, 10):
+        lad, gx = S.slater(G[f"n{n}_x"], G[f"n{n}_orb"], gout=np.ones(24))
+        np.testing.assert_allclose(lad, G[f"n{n}_logabsdet"], atol=1e-12)
+        np.testing.assert_allclose(gx, G[f"n{n}_grad"], rtol=1e-9, atol=1e-9)
+    lp, g, lap = S.logprob(G["lp_x"], 3, 6, tab_up=G["lp_up"], tab_dn=G["lp_dn"])
+    np.testing.assert_allclose(lp, G["lp_logp"], atol=1e-11)
+    np.testing.assert_allclose(g, G["lp_grad"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(lap, G["lp_lap"], rtol=1e-9, atol=1e-6)
+    ws = np.repeat(G["ms_keys"], G["ms_counts"])
+    lp, g, lap = S.logprob(G["ms_x"], 3, 0, tab_up=G["ms_states"], wstate=ws)
+    np.testing.assert_allclose(lp, G["ms_logp"], atol=1e-12)
+    np.testing.assert_allclose(lap, G["ms_lap"], rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["u3d3", "u6d6", "u10d0"])
+def test_mcmc_kernel_bit_exact(golden, name):
+    G = golden["g1_mcmc"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name)
+    x, logp, acc = S.mcmc_noise(g0, g, u, nup, ndn)
+    assert (acc == accept).all() and (x == G[name + "_x"]).all()
+
+
+def test_philox_mcmc_equals_noise_path():
+    g0, g, u = S.rng_fill(40, 6, 20, 1234, offset=5)
+    x1, _, acc1 = S.mcmc_noise(g0, g, u, 3, 3)
+    x2, _, cnt = S.mcmc(40, 3, 3, 20, 1234, offset=5)
+    assert (x1 == x2).all() and (acc1.sum(0) == cnt).all()
+    # sharding invariance: walkers 5..44 drawn as two shards
+    xa, _, _ = S.mcmc(15, 3, 3, 20, 1234, offset=5)
+    xb, _, _ = S.mcmc(25, 3, 3, 20, 1234, offset=20)
+    assert (np.concatenate([xa, xb]) == x2).all()
+    assert abs(g.mean()) < 0.02 and abs(g.std() - 1) < 0.02 and abs(u.mean() - 0.5) < 0.03
+
+
+def test_backflow_kernel(golden):
+    G = golden["g3_backflow"]
+    for k in (1, 2, 3):
+        n, d, He, Hm = G[f"c{k}_cfg"]
+        eta, mu = net_arrays(G, f"c{k}_", Hm > 0)
+        v, div = S.backflow(G[f"c{k}_x"], S.Net(eta, mu))
+        np.testing.assert_allclose(v, G[f"c{k}_v"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(div, G[f"c{k}_div"], rtol=1e-12, atol=1e-12)
+
+
+def test_cnf_kernels(golden):
+    G = golden["g4_cnf"]
+    net = S.Net(*net_arrays(G, ""))
+    tag, rt, at = "tol10", 1e-10, 1e-12
+    x, st = S.cnf_generate(G[tag + "_z"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(x, G[tag + "_x"], atol=2e-10)
+    z, dl, st = S.cnf_delta_logp(G[tag + "_x"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(z, G[tag + "_zback"], atol=2e-10)
+    np.testing.assert_allclose(dl, G[tag + "_dlogp"], atol=2e-10)
+    gx, gp, st = S.cnf_adjoint(G[tag + "_zback"], G[tag + "_cz"], G[tag + "_cd"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(gx, G[tag + "_gx"], atol=1e-9)
+    ref = cnf_param_grads(G, tag)
+    np.testing.assert_allclose(gp, ref, atol=1e-9 * np.abs(ref).max())
+    assert st[3] == 0
+
+
+@pytest.mark.parametrize("name", ["z2_zero", "z2_nt", "u6_nt", "z2_nomu"])
+def test_eloc_kernel(golden, name):
+    G = golden["g5_gsvmc"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    use_mu = bool(G[name + "_use_mu"])
+    net = S.Net(*net_arrays(G, name + "_", use_mu))
+    x = G[name + "_x"][:12]
+    r = S.eloc(x, nup, ndn, net, float(G[name + "_Z"]))           # reference default tolerances
+    np.testing.assert_allclose(r["eloc"], G[name + "_Eloc"][:12], rtol=1e-6)   # bar: 1e-5
+    np.testing.assert_allclose(r["grad"], G[name + "_grad"][:12], atol=1e-5)
+    onet = O.Net(*net_arrays(G, name + "_", use_mu))
+    ref = O.eloc(x, nup, ndn, onet, float(G[name + "_Z"]), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-6)
+    assert r["stats"][3] == 0

@@ -1,0 +1,129 @@
+"""The oracle (oracle/ff_oracle.c) against the golden vectors produced by the REFERENCE itself
+(tests/golden/make_golden.py) and against the reference's known-answer tests.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.common import mcmc_noise_from_seed, net_arrays, cnf_param_grads, gsvmc_param_grads
+
+
+def test_orbitals_and_slater(golden):
+    G = golden["g2_slater"]
+    v = O.orbitals(np.arange(36), G["orb_pts"])
+    np.testing.assert_allclose(v, G["orb_vals"], rtol=1e-14, atol=1e-16)
+    for n in (1, 3, 5, 6, 10):
+        lp, g, lap = O.logprob(G[f"n{n}_x"], n, 0, tab_up=G[f"n{n}_orb"])
+        np.testing.assert_allclose(lp / 2, G[f"n{n}_logabsdet"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(g / 2, G[f"n{n}_grad"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(lap / 2, G[f"n{n}_lap"], rtol=1e-9, atol=1e-7)
+    lp, g, lap = O.logprob(G["lp_x"], 3, 6, tab_up=G["lp_up"], tab_dn=G["lp_dn"])
+    np.testing.assert_allclose(lp, G["lp_logp"], atol=1e-11)
+    np.testing.assert_allclose(g, G["lp_grad"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(lap, G["lp_lap"], rtol=1e-9, atol=1e-6)
+    ws = np.repeat(G["ms_keys"], G["ms_counts"])
+    lp, g, lap = O.logprob(G["ms_x"], 3, 0, tab_up=G["ms_states"], wstate=ws)
+    np.testing.assert_allclose(lp, G["ms_logp"], atol=1e-12)
+    np.testing.assert_allclose(g, G["ms_grad"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(lap, G["ms_lap"], rtol=1e-9, atol=1e-8)
+
+
+def test_known_answer_eigenfunctions():
+    """reference tests/test_basedist.py:5-60: Slater determinants of HO2D orbitals are eigenfunctions,
+    E_loc == sum of orbital energies at random points."""
+    rng = np.random.RandomState(0)
+    Es = np.array([n + 1 for n in range(8) for _ in range(n + 1)])
+    for nup, ndn in ((5, 0), (3, 6), (1, 0), (10, 0)):
+        iu = np.sort(rng.choice(21, nup, replace=False)); idn = np.sort(rng.choice(21, ndn, replace=False))
+        x = rng.randn(20, nup + ndn, 2)
+        lp, g, lap = O.logprob(x, nup, ndn, tab_up=iu, tab_dn=idn if ndn else None)
+        eloc = -0.25 * lap - 0.125 * (g ** 2).sum(axis=(1, 2)) + 0.5 * (x ** 2).sum(axis=(1, 2))
+        np.testing.assert_allclose(eloc, Es[iu].sum() + Es[idn].sum(), rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["u3d3", "u6d0", "u6d6", "u1d0", "u10d0"])
+def test_mcmc_bit_exact(golden, name):
+    """FreeFermion.sample: accept masks and final walkers bit-identical to the reference."""
+    G = golden["g1_mcmc"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name)
+    x, logp, acc = O.mcmc_noise(g0, g, u, nup, ndn)
+    assert (acc == accept).all()
+    assert (x == G[name + "_x"]).all()
+    np.testing.assert_allclose(logp, G[name + "_logp"], atol=1e-13)
+
+
+def test_mcmc_self_contained_fixture(golden):
+    G = golden["g1_mcmc"]
+    x, logp, acc = O.mcmc_noise(G["u3d3_g0"], G["u3d3_g10"], G["u3d3_u10"], 3, 3)
+    accept = np.unpackbits(G["u3d3_accept"])[:100 * 64].reshape(100, 64)[:10]
+    assert (acc == accept).all()
+
+
+def test_backflow_potentials(golden):
+    G = golden["g3_backflow"]
+    for k in range(int(G["ncase"])):
+        n, d, He, Hm = G[f"c{k}_cfg"]
+        eta, mu = net_arrays(G, f"c{k}_", Hm > 0)
+        v, div = O.backflow(G[f"c{k}_x"], O.Net(eta, mu))
+        np.testing.assert_allclose(v, G[f"c{k}_v"], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(div, G[f"c{k}_div"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(O.potential(G[f"c{k}_x"], 2.0), G[f"c{k}_Vho"] + G[f"c{k}_Vc"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("tag,rt,at", [("tol6", 1e-6, 1e-8), ("tol10", 1e-10, 1e-12)])
+def test_cnf_same_step_sequence_as_reference(golden, tag, rt, at):
+    """generate / delta_logp / adjoint with the reference's batch-global scipy-RK45 control: agreement is at
+    rounding level (same nfev), not merely at tolerance level."""
+    G = golden["g4_cnf"]
+    net = O.Net(*net_arrays(G, ""))
+    x, _ = O.cnf_generate(G[tag + "_z"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(x, G[tag + "_x"], atol=1e-13)
+    z, dl, _ = O.cnf_delta_logp(G[tag + "_x"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(z, G[tag + "_zback"], atol=1e-13)
+    np.testing.assert_allclose(dl, G[tag + "_dlogp"], atol=1e-13)
+    gx, gp, _ = O.cnf_adjoint(G[tag + "_zback"], G[tag + "_dlogp"], G[tag + "_cz"], G[tag + "_cd"], net, rtol=rt, atol=at)
+    np.testing.assert_allclose(gx, G[tag + "_gx"], atol=1e-12)
+    ref = cnf_param_grads(G, tag)
+    np.testing.assert_allclose(gp, ref, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu"])
+def test_local_energy(golden, name):
+    """E_loc, logp, grad logp, laplacian logp per walker vs the reference's nested-adjoint autograd."""
+    G = golden["g5_gsvmc"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    use_mu = bool(G[name + "_use_mu"])
+    net = O.Net(*net_arrays(G, name + "_", use_mu))
+    r = O.eloc(G[name + "_x"], nup, ndn, net, float(G[name + "_Z"]), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r["eloc"], G[name + "_Eloc"], rtol=1e-9)
+    np.testing.assert_allclose(r["logp"], G[name + "_logp"], atol=1e-9)
+    np.testing.assert_allclose(r["grad"], G[name + "_grad"], atol=1e-8)
+    np.testing.assert_allclose(r["lap"], G[name + "_lap"], rtol=1e-9, atol=1e-7)
+    # reference default tolerance: still far inside the 1e-5 bar
+    r6 = O.eloc(G[name + "_x"], nup, ndn, net, float(G[name + "_Z"]), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(r6["eloc"], G[name + "_Eloc"], rtol=1e-7)
+
+
+def test_gsvmc_gradient(golden):
+    """theta-gradient of the surrogate loss (src/VMC.py:58 + FermionHO2D.py:71) from the golden walkers."""
+    G = golden["g5_gsvmc"]
+    name = "z2_nt"
+    net = O.Net(*net_arrays(G, name + "_"))
+    x, el = G[name + "_x"], G[name + "_Eloc"]
+    B = len(el)
+    z, dl, _ = O.cnf_delta_logp(x, net, rtol=1e-10, atol=1e-12)
+    lp0, g0, _ = O.logprob(z, 3, 3)
+    w = (el - el.mean()) / B
+    _, gp, _ = O.cnf_adjoint(z, dl, w[:, None, None] * g0, -w, net, rtol=1e-10, atol=1e-12)
+    ref = gsvmc_param_grads(G, name)
+    np.testing.assert_allclose(gp, ref, atol=1e-8 * np.abs(ref).max())
+    np.testing.assert_allclose(((lp0 - dl) * w).sum(), float(G[name + "_gradE"]), rtol=1e-8)
+
+
+def test_betavmc_walkers(golden):
+    G = golden["g6_betavmc"]
+    net = O.Net(*net_arrays(G, ""))
+    for tag in ("boltz", "hot"):
+        ws = np.repeat(G[tag + "_keys"], G[tag + "_counts"])
+        r = O.eloc(G[tag + "_x"], 3, 0, net, 2.0, rtol=1e-10, atol=1e-12, tab_up=G[tag + "_states"], wstate=ws)
+        np.testing.assert_allclose(r["eloc"], G[tag + "_Eloc"], rtol=1e-9)
+        np.testing.assert_allclose(r["eloc"].mean(), float(G[tag + "_E"]), rtol=1e-10)
