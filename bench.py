@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--nup", type=int, default=3)
     ap.add_argument("--ndown", type=int, default=3)
     ap.add_argument("--Z", type=float, default=2.0)
+    ap.add_argument("--lr", type=float, default=1e-4,
+                    help="Adam step; small so the synthetic weights (hence the ODE step counts) stay put over the run")
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel and CPU-baseline legs")
     args = ap.parse_args()
@@ -63,7 +65,7 @@ def main():
     torch.cuda.set_device(dev)
 
     model = G._model(dev, args.nup, args.ndown, args.Z)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
     B_glob = args.walkers_per_gpu * n_gpus
     torch.manual_seed(1234 + rank)
 

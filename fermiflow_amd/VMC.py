@@ -188,6 +188,8 @@ class BetaVMC(torch.nn.Module):
             Eloc = r["eloc"]
             self.E, self.E_std = Eloc.mean().item(), Eloc.std().item()
         state_indices = ws.to(torch.int64)
+        from torch.distributions.categorical import Categorical
+        self.state_dist = Categorical(logits=self.log_state_weights)      # with autograd (sample() ran under no_grad)
         logp_states = self.state_dist.log_prob(state_indices.to(self.log_state_weights.device)).to(device)
         with torch.no_grad():
             Floc = Eloc + logp_states.detach() / self.beta

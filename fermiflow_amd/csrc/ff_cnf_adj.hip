@@ -371,13 +371,20 @@ ff_ode_adj_kernel(ff_adj_args A) {
   }
 }
 
-__global__ void __launch_bounds__(64)
+// out[k] = sum over rows of rows[r][k]: one workgroup per parameter, fixed tree (deterministic)
+__global__ void __launch_bounds__(256)
 ff_rows_reduce_kernel(int nrows, int P, const double* __restrict__ rows, double* __restrict__ out) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= P) return;
+  __shared__ double sm[256];
+  const int k = blockIdx.x;
   double s = 0.0;
-  for (int r = 0; r < nrows; r++) s += rows[(int64_t)r * P + k];
-  out[k] = s;
+  for (int r = threadIdx.x; r < nrows; r += 256) s += rows[(int64_t)r * P + k];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = sm[0];
 }
 
 // =================================================================================================
@@ -436,7 +443,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   }
   FF_LAUNCH_CHECK();
   const int nrows = (int)adj_grid(B, G) * G;
-  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)((P + 63) / 64), 64, stream, nrows, P, (const double*)workspace, grad_params);
+  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, 256, stream, nrows, P, (const double*)workspace, grad_params);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -90,12 +90,10 @@ FF_D double ff_pick8(const double* h, int n) {
   return v;
 }
 
+// nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop.
 template <int NS>
-FF_D double ff_slater_logabsdet_reg(const int* __restrict__ orb, const double* x) {
+FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* x) {
   double D[NS][NS];
-  int nx[NS], ny[NS];
-#pragma unroll
-  for (int j = 0; j < NS; j++) ff_orb_decode(orb[j], nx[j], ny[j]);
 #pragma unroll
   for (int i = 0; i < NS; i++) {
     double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);

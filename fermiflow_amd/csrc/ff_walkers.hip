@@ -11,23 +11,28 @@
 
 #define FF_MAX_N 24  // particles per walker for the generic paths
 
+// x + tau*g exactly as torch computes it (two roundings): hipcc's default -ffp-contract=fast would fuse
+// the pair into one FMA and the walkers would no longer be bit-identical to the reference's.
 #ifdef FF_HOSTSIM
 FF_D double ff_mul_rn(double a, double b) { volatile double r = a * b; return r; }
 FF_D double ff_add_rn(double a, double b) { volatile double r = a + b; return r; }
 #else
-FF_D double ff_mul_rn(double a, double b) { return __dmul_rn(a, b); }
-FF_D double ff_add_rn(double a, double b) { return __dadd_rn(a, b); }
+// the empty asm makes the product opaque, so the backend cannot contract mul+add into v_fma_f64
+FF_D double ff_mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
+FF_D double ff_add_rn(double a, double b) { double r = a + b; asm volatile("" : "+v"(r)); return r; }
 #endif
 
 // ---------------------------------------------------------------------------------------------------
 // FreeFermion.sample (src/base_dist.py:58-71).  NU/ND > 0: compile-time spin sizes, everything in VGPRs.
 // NU = ND = -1: runtime sizes (private arrays).
+// ou/od: orbital indices (generic path) -- or, for compile-time sizes, ou = [nx | ny] degrees of the up
+// orbitals and od likewise for the down orbitals (decoded once, outside the step loop).
 template <int NU, int ND>
 FF_D double ff_logprob_value(int nup, int ndn, const int* ou, const int* od, const double* x) {
   double s = 0.0;
   if constexpr (NU >= 0) {
-    if constexpr (NU > 0) s += ff_slater_logabsdet_reg<NU>(ou, x);
-    if constexpr (ND > 0) s += ff_slater_logabsdet_reg<ND>(od, x + 2 * NU);
+    if constexpr (NU > 0) s += ff_slater_logabsdet_reg<NU>(ou, ou + NU, x);
+    if constexpr (ND > 0) s += ff_slater_logabsdet_reg<ND>(od, od + ND, x + 2 * NU);
   } else {
     if (nup) s += ff_slater_general(nup, ou, x, nullptr, nullptr);
     if (ndn) s += ff_slater_general(ndn, od, x + 2 * nup, nullptr, nullptr);
@@ -51,11 +56,17 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int st = wstate ? wstate[b] : 0;
-  int ou[MAXU], od[MAXD];
+  int ou[2 * MAXU], od[2 * MAXD];
 #pragma unroll
-  for (int j = 0; j < MAXU; j++) ou[j] = (j < nup) ? tab_up[st * nup + j] : 0;
+  for (int j = 0; j < MAXU; j++) {
+    const int k = (j < nup) ? tab_up[st * nup + j] : 0;
+    if constexpr (FIXED) ff_orb_decode(k, ou[j], ou[MAXU + j]); else ou[j] = k;
+  }
 #pragma unroll
-  for (int j = 0; j < MAXD; j++) od[j] = (j < ndn) ? tab_dn[st * ndn + j] : 0;
+  for (int j = 0; j < MAXD; j++) {
+    const int k = (j < ndn) ? tab_dn[st * ndn + j] : 0;
+    if constexpr (FIXED) ff_orb_decode(k, od[j], od[MAXD + j]); else od[j] = k;
+  }
 
   double x[MAXM], nx[MAXM];
   const uint64_t wid = (uint64_t)(woff + b);

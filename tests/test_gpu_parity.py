@@ -218,7 +218,7 @@ def test_local_energy_vs_reference(golden, dev, name):
     _, gp = native.cnf_adjoint(cnf.v_wrapper.v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
                                need_gx=False)
     ref = gsvmc_param_grads(G, name, use_mu)
-    np.testing.assert_allclose(N(gp), ref, atol=1e-5 * max(np.abs(ref).max(), 1e-300))
+    np.testing.assert_allclose(N(gp), ref, atol=1e-5 * max(np.abs(ref).max(), 1e-8))   # zero-flow case: gradient is rounding noise
     np.testing.assert_allclose(((r["logp"] * w).sum()).item(), float(G[name + "_gradE"]), rtol=1e-5, atol=1e-12)
 
 
