@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfermiflow_hip.so")
+LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
 SYMBOLS = [

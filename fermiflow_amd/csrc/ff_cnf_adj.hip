@@ -29,19 +29,21 @@ struct ff_adj_args {
   int32_t* stats;
 };
 
-template <int N, int D>
+// MAXU: hidden units owned per lane and net (ceil(H/M) for the widths at hand; <= ceil(FF_HMAX/M))
+template <int N, int D, int MAXU>
 __global__ void __launch_bounds__(FF_WAVE)
 ff_ode_adj_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
-  constexpr int MAXU = (FF_HMAX + M - 1) / M;  // hidden units owned per lane and net
   constexpr int NV = 2;
 
   __shared__ ff_wtab s_w[2][FF_HMAX];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G];
   __shared__ double s_rad[G][R], s_rinv[G][R], s_ca[G][R], s_cb[G][R];
-  __shared__ double s_ph[G][M][R][3], s_hd[G][R][3];
+  constexpr int CH = 8;   // radii per partial-head reduction chunk (keeps the LDS hand-off buffer small)
+  __shared__ double s_ph[G][M][CH][3], s_hd[G][R][3];
   __shared__ int s_pa[R], s_pb[R], s_any;
+  __shared__ double s_e2[64];
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
@@ -50,6 +52,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
   const int ai = i / D, ci = i % D;
 
   ff_load_weights(s_w, A.net, lane);
+  ff_fill_exp2_table(s_e2, lane);
   if (lane == 0) {
     int p = 0;
     for (int a = 0; a < N; a++)
@@ -76,7 +79,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b = grp * G + g;
     const bool valid = ingrp && b < A.B;
-    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV], yn[NV];
+    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
     y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
     y[1] = valid ? A.az_in[b * M + i] : 0.0;
     if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
@@ -139,10 +142,8 @@ ff_ode_adj_kernel(ff_adj_args A) {
           break;
         default:
 #pragma unroll
-          for (int v = 0; v < NV; v++) {
-            yn[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
-            in[v] = yn[v];
-          }
+          for (int v = 0; v < NV; v++)
+            in[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
           break;
       }
       // ------------------------------------------------------------------ publish z_i, a_i
@@ -180,38 +181,49 @@ ff_ode_adj_kernel(ff_adj_args A) {
       for (int t = 0; t < 2; t++) {
         const int H = t ? Hm : He;
         const int p_lo = t ? P : 0, p_hi = t ? nrad : P;
-        for (int p = p_lo; p < p_hi; p++) {
+        for (int pc = p_lo; pc < p_hi; pc += CH) {
+          const int pe = pc + CH < p_hi ? pc + CH : p_hi;
+          for (int p = pc; p < pe; p++) {
           const double r = s_rad[gg][p], ca = s_ca[gg][p], cb = s_cb[gg][p];
           double h0 = 0.0, h1 = 0.0, h2 = 0.0;
+          // this lane's MAXU units side by side (units beyond H are masked: their weights read as zero)
+          ff_wtab w[MAXU];
+          double a[MAXU], sgv[MAXU], mk[MAXU];
 #pragma unroll
           for (int j = 0; j < MAXU; j++) {
             const int k = i + j * M;
-            if (k < H) {
-              const ff_wtab w = s_w[t][k];
-              const double sg = ff_sigmoid(fma(w.w1, r, w.b1));
-              const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
-              h0 = fma(w.w2, sg, h0);
-              h1 = fma(w.w2w1, s1, h1);
-              h2 = fma(w.w2w1_2, s2, h2);
-              const double w1rs2 = w.w1 * r * s2;
-              cur[t][j][0] += w.w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
-              cur[t][j][1] += fma(ca * w.w2, s1, cb * w.w2w1 * s2);
-              cur[t][j][2] += fma(ca, sg, cb * w.w1 * s1);
-            }
+            w[j] = s_w[t][k < FF_HMAX ? k : FF_HMAX - 1];
+            mk[j] = k < H ? 1.0 : 0.0;
+            a[j] = fma(w[j].w1, r, w[j].b1);
           }
-          if (ingrp) { s_ph[g][i][p][0] = h0; s_ph[g][i][p][1] = h1; s_ph[g][i][p][2] = h2; }
+          ff_sigmoid_n<MAXU, false>(a, sgv, s_e2);
+#pragma unroll
+          for (int j = 0; j < MAXU; j++) {
+            const double sg = sgv[j];
+            const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
+            const double w2 = mk[j] * w[j].w2, w2w1 = w2 * w[j].w1;
+            h0 = fma(w2, sg, h0);
+            h1 = fma(w2w1, s1, h1);
+            h2 = fma(w2w1 * w[j].w1, s2, h2);
+            const double w1rs2 = w[j].w1 * r * s2;
+            cur[t][j][0] += w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
+            cur[t][j][1] += fma(ca * w2, s1, cb * w2w1 * s2);
+            cur[t][j][2] += mk[j] * fma(ca, sg, cb * w[j].w1 * s1);
+          }
+          if (ingrp) { s_ph[g][i][p - pc][0] = h0; s_ph[g][i][p - pc][1] = h1; s_ph[g][i][p - pc][2] = h2; }
+          }
+          __syncthreads();
+          // reduce this chunk's partial heads over the group's lanes
+          for (int e = i; e < (pe - pc) * 3; e += M) {
+            const int q = e / 3, m = e - 3 * q;
+            double tsum = 0.0;
+#pragma unroll
+            for (int l = 0; l < M; l++) tsum += s_ph[gg][l][q][m];
+            if (ingrp) s_hd[g][pc + q][m] = tsum;
+          }
+          __syncthreads();
         }
       }
-      __syncthreads();
-      // reduce the partial heads over the group's lanes
-      for (int e = i; e < nrad * 3; e += M) {
-        const int p = e / 3, m = e - 3 * p;
-        double t = 0.0;
-#pragma unroll
-        for (int l = 0; l < M; l++) t += s_ph[gg][l][p][m];
-        if (ingrp) s_hd[g][p][m] = t;
-      }
-      __syncthreads();
       // ------------------------------------------------------------------ component phase
       double out[NV];
       {
@@ -311,14 +323,14 @@ ff_ode_adj_kernel(ff_adj_args A) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
-          const double t = e / (atol + fmax(fabs(y[v]), fabs(yn[v])) * rtol);
+          const double t = e / (atol + fmax(fabs(y[v]), fabs(in[v])) * rtol);
           pe = fma(t, t, pe);
         }
         const double err = sqrt(group_sum(pe) / NT);
         const bool acc = S.decide(err, A.max_steps);
         if (acc) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) { y[v] = yn[v]; k0[v] = out[v]; }
+          for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
         }
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -392,19 +404,25 @@ extern void ff_set_error(const char* msg);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 
-#ifndef FF_PERSIST_BLOCKS
-#define FF_PERSIST_BLOCKS 2048
-#endif
+#include <stdlib.h>
+static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
 static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? FF_WAVE / M : 0; }
 static unsigned adj_grid(int64_t B, int G) {
   int64_t ngroups = (B + G - 1) / G;
-  return (unsigned)(ngroups < FF_PERSIST_BLOCKS ? ngroups : FF_PERSIST_BLOCKS);
+  const int64_t cap = ff_persist_blocks(4096);
+  return (unsigned)(ngroups < cap ? ngroups : cap);
 }
 
 template <int N, int D>
 static void launch_adj(void* stream, const ff_adj_args& a) {
-  FF_LAUNCH((ff_ode_adj_kernel<N, D>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+  constexpr int M = ff_geom<N, D>::M;
+  constexpr int MU_FULL = (FF_HMAX + M - 1) / M, MU_50 = (50 + M - 1) / M;   // 50 = the reference's default width
+  const int hmax = a.net.He > a.net.Hm ? a.net.He : a.net.Hm;
+  if (MU_50 < MU_FULL && hmax <= MU_50 * M)
+    FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_50>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+  else
+    FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_FULL>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
 }
 
 extern "C" {

@@ -19,6 +19,14 @@
 #include "ff_ode.h"
 #include "ff_slater.h"
 
+// FF_STAMPS: diagnostic build only (tools/kbench.py --stamps): per-phase s_memtime shares of the RHS loop,
+// added into stats[8..] as 64-bit counters.  Never defined in the product build.
+#ifdef FF_STAMPS
+#define FF_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_prev; stamp_prev = t_; } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
+
 struct ff_fwd_args {
   int64_t B;
   ff_net net;
@@ -50,11 +58,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   __shared__ double s_rad[G][R], s_rinv[G][R], s_hd[G][R][NH];
   __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
   __shared__ int s_pa[R], s_pb[R], s_any;
+  __shared__ double s_e2[64];
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
   const bool ingrp = g < G;
   const int gg = ingrp ? g : 0;  // safe LDS row for the idle tail lanes
+  ff_fill_exp2_table(s_e2, lane);
   const int ai = i / D, ci = i % D;
 
   ff_load_weights(s_w, A.net, lane);
@@ -73,11 +83,14 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const int64_t ngroups = (A.B + G - 1) / G;
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
+#ifdef FF_STAMPS
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b = grp * G + g;
     const bool valid = ingrp && b < A.B;
-    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV], yn[NV];
+    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) y[v] = 0.0;
     y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
@@ -105,54 +118,30 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll 1
     for (;;) {
       // ------------------------------------------------------------------ stage input
-      double in[NV];
+      // The candidate state of slot v for stage s.  Only the published slots are formed before the radius phase;
+      // the full vector is formed after it, so the hottest loop of the kernel runs without `in[]` live.
       const double h = S.h;
-      switch (s) {
-        case -2:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = y[v];
-          break;
-        case -1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h0v * S.dir, k0[v], y[v]);
-          break;
-        case 1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h * FF_A10, k0[v], y[v]);
-          break;
-        case 2:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
-          break;
-        case 3:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
-          break;
-        case 4:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
-          break;
-        case 5:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
-          break;
-        default:
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            yn[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
-            in[v] = yn[v];
-          }
-          break;
-      }
+      auto stage_in = [&](int v) -> double {
+        switch (s) {
+          case -2: return y[v];
+          case -1: return fma(h0v * S.dir, k0[v], y[v]);
+          case 1: return fma(h * FF_A10, k0[v], y[v]);
+          case 2: return fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
+          case 3: return fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
+          case 4: return fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
+          case 5: return fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
+          default: return fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
+        }
+      };
+      FF_STAMP(0);
       // ------------------------------------------------------------------ publish
       __syncthreads();
       if (ingrp) {
-        s_z[g][i] = in[0];
-        if constexpr (MODE == 2) s_kb[g][i] = in[M + 1];
+        s_z[g][i] = stage_in(0);
+        if constexpr (MODE == 2) s_kb[g][i] = stage_in(M + 1);
       }
       __syncthreads();
+      FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase
       for (int q = lane; q < G * nrad; q += FF_WAVE) {
         const int qg = q / nrad, p = q - qg * nrad;
@@ -165,7 +154,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         }
         const double r = sqrt(r2);
         double hd[NH];
-        ff_heads<NH>(s_w[bb >= 0 ? 0 : 1], bb >= 0 ? He : Hm, r, hd);
+        ff_heads<NH, (MODE < 2)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
         s_rad[qg][p] = r;
         s_rinv[qg][p] = ff_rcp(r);
 #pragma unroll
@@ -173,8 +162,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       }
       __syncthreads();
       nev++;
+      FF_STAMP(2);
       // ------------------------------------------------------------------ right-hand side
-      double out[NV];
+      double in[NV], out[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) in[v] = stage_in(v);   // at stage 6 this is the candidate new state
       const double* sz = s_z[gg];
       double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
       if constexpr (MODE == 2) {
@@ -259,25 +251,34 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rad[gg][p], D * s_hd[gg][p][0]), divv);
         }
       }
-      // component phase: coordinate (ai, ci)
+      FF_STAMP(3);
+      // component phase: coordinate (ai, ci).  Statically unrolled over the partner particle (the own
+      // index is masked out) so that all LDS reads are in flight together instead of one dependent trip per partner.
       double vi = 0.0, dvk = 0.0, gdi = 0.0;
-      for (int bq = 0; bq < N; bq++) {
-        if (bq == ai) continue;
-        const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
-        const int p = ff_pair_index(N, lo, hi);
-        const double rc = sz[ai * D + ci] - sz[bq * D + ci];
-        const double f0 = s_hd[gg][p][0];
-        vi = fma(f0, rc, vi);
-        if constexpr (MODE == 2) {
-          double rdk = 0.0;
+      {
+        const double zc = sz[ai * D + ci], kc = (MODE == 2) ? s_kb[gg][ai * D + ci] : 0.0;
+        double za[D], ka[D];
 #pragma unroll
-          for (int c = 0; c < D; c++)
-            rdk = fma(sz[ai * D + c] - sz[bq * D + c], s_kb[gg][ai * D + c] - s_kb[gg][bq * D + c], rdk);
-          const double ri = s_rinv[gg][p], f1 = s_hd[gg][p][NH > 1 ? 1 : 0], f2 = s_hd[gg][p][NH > 2 ? 2 : 0];
-          const double r1 = rdk * ri;
-          dvk += fma(f1 * r1, rc, f0 * (s_kb[gg][ai * D + ci] - s_kb[gg][bq * D + ci]));
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(2.0 * sp * ri, rc, gdi);
+        for (int c = 0; c < D; c++) { za[c] = sz[ai * D + c]; ka[c] = (MODE == 2) ? s_kb[gg][ai * D + c] : 0.0; }
+#pragma unroll
+        for (int bq = 0; bq < N; bq++) {
+          const bool self = (bq == ai);
+          const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
+          const int p = self ? 0 : ff_pair_index(N, lo, hi);
+          const double m = self ? 0.0 : 1.0;
+          const double rc = zc - sz[bq * D + ci];
+          const double f0 = m * s_hd[gg][p][0];
+          vi = fma(f0, rc, vi);
+          if constexpr (MODE == 2) {
+            double rdk = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; c++) rdk = fma(za[c] - sz[bq * D + c], ka[c] - s_kb[gg][bq * D + c], rdk);
+            const double ri = s_rinv[gg][p], f1 = m * s_hd[gg][p][NH > 1 ? 1 : 0], f2 = m * s_hd[gg][p][NH > 2 ? 2 : 0];
+            const double r1 = rdk * ri;
+            dvk += fma(f1 * r1, rc, f0 * (kc - s_kb[gg][bq * D + ci]));
+            const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
+            gdi = fma(2.0 * sp * ri, rc, gdi);
+          }
         }
       }
       if (has_mu) {
@@ -304,6 +305,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         out[M + 3] = -divv;
         out[M + 4] = -fma(gdi, in[M + 1], qdiv);
       }
+      FF_STAMP(4);
       // ------------------------------------------------------------------ consume
       if (s == -2) {
 #pragma unroll
@@ -355,13 +357,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
-          const double t = e * wgt(v) / (atol + fmax(fabs(y[v]), fabs(yn[v])) * rtol);
+          const double t = e * wgt(v) / (atol + fmax(fabs(y[v]), fabs(in[v])) * rtol);
           pe = fma(t, t, pe);
         }
         const double err = sqrt(group_sum(pe) / NT);
         if (S.decide(err, A.max_steps)) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) { y[v] = yn[v]; k0[v] = out[v]; }
+          for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
         }
         S.plan();
         if (lane == 0) s_any = 0;
@@ -372,6 +374,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         if (!any) break;
         s = 1;
       }
+      FF_STAMP(5);
     }
     // ---------------------------------------------------------------------- results
     if (valid) {
@@ -393,6 +396,10 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     }
     __syncthreads();
   }
+#ifdef FF_STAMPS
+  if (A.stats && lane == 0)
+    for (int q = 0; q < 6; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+#endif
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);
     atomicMax(&A.stats[1], acc_max);
@@ -482,15 +489,16 @@ extern void ff_set_error(const char* msg);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 
-#ifndef FF_PERSIST_BLOCKS
-#define FF_PERSIST_BLOCKS 2048  // 256 CUs x 8 single-wave workgroups
-#endif
+#include <stdlib.h>
+// persistent single-wave workgroups; FF_PERSIST_BLOCKS env overrides (tuning experiments)
+static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
 template <int N, int D, int MODE>
 static void launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
-  unsigned grid = (unsigned)(ngroups < FF_PERSIST_BLOCKS ? ngroups : FF_PERSIST_BLOCKS);
+  const int64_t cap = ff_persist_blocks(1 << 20);   // measured: one workgroup per walker group balances best
+  unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE>), grid, FF_WAVE, stream, a);
 }
 

@@ -47,12 +47,20 @@ FF_D double ff_rcp(double x) {
 #endif
 }
 
-// --- exp for |x| <= 708: Cody-Waite reduction + degree-13 Taylor/Horner, ~1 ulp ----------------------
+// --- exp for |x| <= 708.  Rounding and scaling use the integer pipe instead of the quarter-rate
+//     v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64: adding 1.5*2^52 leaves round(x*log2e) in the low mantissa word, and
+//     2^k is applied by adding k to the exponent field (the polynomial value is in [0.7,1.42], |k| <= 1010: always normal).
+FF_D double ff_scale2(double p, int k) {
+  return __hiloint2double(__double2hiint(p) + (k << 20), __double2loint(p));
+}
 FF_D double ff_exp(double x) {
   const double L2E = 1.4426950408889634074, LN2H = 6.93147180369123816490e-01, LN2L = 1.90821492927058770002e-10;
-  double k = rint(x * L2E);
-  double r = fma(-k, LN2H, x);
-  r = fma(-k, LN2L, r);
+  const double MAGIC = 6755399441055744.0;
+  const double t = fma(x, L2E, MAGIC);
+  const int k = __double2loint(t);
+  const double kf = t - MAGIC;
+  double r = fma(-kf, LN2H, x);
+  r = fma(-kf, LN2L, r);
   double p = 1.0 / 6227020800.0;
   p = fma(p, r, 1.0 / 479001600.0);
   p = fma(p, r, 1.0 / 39916800.0);
@@ -67,13 +75,135 @@ FF_D double ff_exp(double x) {
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
+  return ff_scale2(p, k);
 }
 
 // sigmoid(a) = 1/(1+exp(-a))  (torch.nn.Sigmoid, src/MLP.py:16)
 FF_D double ff_sigmoid(double a) {
   a = fmin(fmax(a, -700.0), 700.0);
   return ff_rcp(1.0 + ff_exp(-a));
+}
+
+// --- table-driven variant for kernels with >= 2 waves per SIMD (the LDS look-up sits in the dependent chain):
+//     x = (64 m + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^m * 2^(j/64) * (1 + r + ... + r^5/120);
+//     tab[j] = 2^(j/64) lives in LDS (ff_fill_exp2_table).  Relative error ~1.5e-16.
+FF_D void ff_fill_exp2_table(double* tab, int lane) {
+  if (lane < 64) tab[lane] = exp2((double)lane * (1.0 / 64.0));
+}
+FF_D double ff_exp_tab(double x, const double* __restrict__ tab) {
+  const double INV = 92.332482616893656 /* 64/ln2 */, C_HI = 0.010830424667801708 /* ln2/64, low 24 bits clear */,
+               C_LO = 2.8447437476627285e-11, MAGIC = 6755399441055744.0;
+  const double t = fma(x, INV, MAGIC);
+  const int k = __double2loint(t);
+  const double kf = t - MAGIC;
+  double r = fma(-kf, C_HI, x);
+  r = fma(-kf, C_LO, r);
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ff_scale2(tab[k & 63] * p, k >> 6);
+}
+template <bool TAB>
+FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
+  a = fmin(fmax(a, -700.0), 700.0);
+  return ff_rcp(1.0 + (TAB ? ff_exp_tab(-a, tab) : ff_exp(-a)));
+}
+
+// --- NV sigmoids side by side.  Written step by step over the NV lanes-of-work with scheduling fences in between:
+//     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
+//     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
+#ifdef FF_HOSTSIM
+#define FF_SCHED_FENCE() do { } while (0)
+#else
+#define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <int NV, bool TAB>
+FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict__ tab) {
+  const double MAGIC = 6755399441055744.0;
+  double x[NV], t[NV], r[NV], p[NV];
+  int k[NV];
+#pragma unroll
+  for (int q = 0; q < NV; q++) x[q] = -fmin(fmax(a_in[q], -700.0), 700.0);
+  if (TAB) {
+    const double INV = 92.332482616893656, C_HI = 0.010830424667801708, C_LO = 2.8447437476627285e-11;
+#pragma unroll
+    for (int q = 0; q < NV; q++) t[q] = fma(x[q], INV, MAGIC);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) { k[q] = __double2loint(t[q]); t[q] -= MAGIC; }
+#pragma unroll
+    for (int q = 0; q < NV; q++) r[q] = fma(-t[q], C_HI, x[q]);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) { r[q] = fma(-t[q], C_LO, r[q]); t[q] = tab[k[q] & 63]; }
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = fma(r[q], 1.0 / 120.0, 1.0 / 24.0);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = fma(p[q], r[q], 1.0 / 6.0);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = fma(p[q], r[q], 0.5);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = fma(p[q], r[q], 1.0);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = fma(p[q], r[q], 1.0);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = ff_scale2(t[q] * p[q], k[q] >> 6);
+  } else {
+    const double L2E = 1.4426950408889634074, LN2H = 6.93147180369123816490e-01, LN2L = 1.90821492927058770002e-10;
+    const double C[14] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                          1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+#pragma unroll
+    for (int q = 0; q < NV; q++) t[q] = fma(x[q], L2E, MAGIC);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) { k[q] = __double2loint(t[q]); t[q] -= MAGIC; }
+#pragma unroll
+    for (int q = 0; q < NV; q++) r[q] = fma(-t[q], LN2H, x[q]);
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) { r[q] = fma(-t[q], LN2L, r[q]); p[q] = fma(C[0], r[q], C[1]); }
+#pragma unroll
+    for (int c = 2; c < 14; c++) {
+      FF_SCHED_FENCE();
+#pragma unroll
+      for (int q = 0; q < NV; q++) p[q] = fma(p[q], r[q], C[c]);
+    }
+    FF_SCHED_FENCE();
+#pragma unroll
+    for (int q = 0; q < NV; q++) p[q] = ff_scale2(p[q], k[q]);
+  }
+  FF_SCHED_FENCE();
+#pragma unroll
+  for (int q = 0; q < NV; q++) p[q] += 1.0;
+  FF_SCHED_FENCE();
+#ifdef FF_HOSTSIM
+#pragma unroll
+  for (int q = 0; q < NV; q++) sg[q] = 1.0 / p[q];
+#else
+#pragma unroll
+  for (int q = 0; q < NV; q++) t[q] = __builtin_amdgcn_rcp(p[q]);
+  FF_SCHED_FENCE();
+#pragma unroll
+  for (int q = 0; q < NV; q++) r[q] = fma(-p[q], t[q], 1.0);
+  FF_SCHED_FENCE();
+#pragma unroll
+  for (int q = 0; q < NV; q++) t[q] = fma(r[q], t[q], t[q]);
+  FF_SCHED_FENCE();
+#pragma unroll
+  for (int q = 0; q < NV; q++) r[q] = fma(-p[q], t[q], 1.0);
+  FF_SCHED_FENCE();
+#pragma unroll
+  for (int q = 0; q < NV; q++) sg[q] = fma(r[q], t[q], t[q]);
+#endif
+  FF_SCHED_FENCE();
 }
 
 // number of (i<j) pairs before row i for n particles; pair index of (i,j), i<j

@@ -46,22 +46,25 @@ FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HMAX], const ff_net& net, int lane) 
 // side so that a single resident wave per SIMD still has independent work to issue every cycle.  The weight
 // table is zero-padded to FF_HMAX, so running the loop to the next multiple of 4 adds exact zeros.
 #define FF_HU 4
-template <int NH>
-FF_D void ff_heads(const ff_wtab* __restrict__ tab, int H, double r, double* hd) {
+template <int NH, bool TAB>
+FF_D void ff_heads(const ff_wtab* __restrict__ tab, const double* __restrict__ e2, int H, double r, double* hd) {
   double h0[FF_HU], h1[FF_HU], h2[FF_HU], h3[FF_HU];
 #pragma unroll
   for (int q = 0; q < FF_HU; q++) h0[q] = h1[q] = h2[q] = h3[q] = 0.0;
   for (int h = 0; h < H; h += FF_HU) {
+    ff_wtab w[FF_HU];
+    double a[FF_HU], s[FF_HU];
+#pragma unroll
+    for (int q = 0; q < FF_HU; q++) { w[q] = tab[h + q]; a[q] = fma(w[q].w1, r, w[q].b1); }
+    ff_sigmoid_n<FF_HU, TAB>(a, s, e2);
 #pragma unroll
     for (int q = 0; q < FF_HU; q++) {
-      const ff_wtab w = tab[h + q];
-      const double s = ff_sigmoid(fma(w.w1, r, w.b1));
-      h0[q] = fma(w.w2, s, h0[q]);
+      h0[q] = fma(w[q].w2, s[q], h0[q]);
       if (NH >= 2) {
-        const double s1 = s * (1.0 - s);
-        h1[q] = fma(w.w2w1, s1, h1[q]);
-        if (NH >= 3) h2[q] = fma(w.w2w1_2, s1 * fma(-2.0, s, 1.0), h2[q]);
-        if (NH >= 4) h3[q] = fma(w.w2w1_3, s1 * fma(-6.0, s1, 1.0), h3[q]);
+        const double s1 = s[q] * (1.0 - s[q]);
+        h1[q] = fma(w[q].w2w1, s1, h1[q]);
+        if (NH >= 3) h2[q] = fma(w[q].w2w1_2, s1 * fma(-2.0, s[q], 1.0), h2[q]);
+        if (NH >= 4) h3[q] = fma(w[q].w2w1_3, s1 * fma(-6.0, s1, 1.0), h3[q]);
       }
     }
   }

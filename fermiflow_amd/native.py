@@ -109,7 +109,7 @@ def potential(x, Z, use_ho):
 
 
 def _stats(device, want):
-    return torch.zeros(4, dtype=torch.int32, device=device) if want else None
+    return torch.zeros(32, dtype=torch.int32, device=device) if want else None   # [0..3] stats, [8..] diagnostic stamps
 
 
 def cnf_generate(net, z, t0, t1, rtol, atol, want_stats=False):

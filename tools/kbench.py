@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-kernel timing harness (development tool): times the three fused ODE kernels and the MCMC kernel at the
+BASELINE configuration with HIP events.  python tools/kbench.py [--B 65536] [--reps 5]"""
+import argparse, os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as G
+from fermiflow_amd import native
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=65536)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--nup", type=int, default=3)
+ap.add_argument("--ndown", type=int, default=3)
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+model = G._model(dev, a.nup, a.ndown, 2.0)
+net = model.cnf.v_wrapper.v.net()
+tu, td = model._tables(dev)
+n = a.nup + a.ndown
+z, _, _ = native.mcmc_sample(tu, td, a.nup, a.ndown, a.B, 100, 0.1, 1, dev)
+
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        out = fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.reps, out
+
+
+res = {"tag": a.tag, "B": a.B, "blocks": os.environ.get("FF_PERSIST_BLOCKS", "default")}
+res["mcmc_ms"], _ = timeit(lambda: native.mcmc_sample(tu, td, a.nup, a.ndown, a.B, 100, 0.1, 1, dev))
+res["generate_ms"], (x, st) = timeit(lambda: native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, want_stats=True))
+res["generate_evals"] = st[0].item() / a.B
+res["logp_ms"], (_, _, st) = timeit(lambda: native.cnf_delta_logp(net, x, 0.0, 1.0, 1e-6, 1e-8, want_stats=True))
+res["logp_evals"] = st[0].item() / a.B
+ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True)
+tot = 0.0
+for _ in range(a.reps):
+    r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=ev)
+    torch.cuda.synchronize(); tot += ev[0].elapsed_time(ev[1])
+res["eloc_pass1_ms"] = tot / a.reps
+res["eloc_evals"] = r["stats"][0].item() / a.B
+res["eloc_rej"] = r["stats"][2].item() / a.B
+w = (r["eloc"] - r["eloc"].mean()) / a.B
+res["adjoint_ms"], (_, gp, st) = timeit(lambda: native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
+                                                                   need_gx=False, want_stats=True))
+res["adjoint_evals"] = st[0].item() / a.B
+st8 = r["stats"][8:20].view(torch.int64)[:6].double()
+if st8.sum() > 0:
+    res["stamps_pct"] = [round(v, 1) for v in (100 * st8 / st8.sum()).tolist()]   # input, publish, radius, jets, component, consume
+res["E"] = r["eloc"].mean().item()
+res["gp_norm"] = gp.norm().item()
+print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))
