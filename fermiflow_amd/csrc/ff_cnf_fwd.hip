@@ -90,7 +90,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b = grp * G + g;
     const bool valid = ingrp && b < A.B;
-    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
+    // Stage storage, 5 vectors instead of the textbook 7 (y, k0..k5): c0..c2 hold k0..k2 up to stage 3; once k3 is
+    // known the remaining stage inputs and the error accumulator are formed and overwrite them:
+    //   c0 = input of stage 4, c1 = partial input of stage 5, c2 = partial y_new, c3 = partial error.
+    // k0 is therefore gone at the accept/reject decision: an accepted step takes k6 (FSAL), a rejected one
+    // re-evaluates f(y) (stage 0; rejections are ~1 % of the wave-steps).
+    double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) y[v] = 0.0;
     y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
@@ -123,14 +128,14 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       const double h = S.h;
       auto stage_in = [&](int v) -> double {
         switch (s) {
-          case -2: return y[v];
-          case -1: return fma(h0v * S.dir, k0[v], y[v]);
-          case 1: return fma(h * FF_A10, k0[v], y[v]);
-          case 2: return fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
-          case 3: return fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
-          case 4: return fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
-          case 5: return fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
-          default: return fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
+          case -2: case 0: return y[v];
+          case -1: return fma(h0v * S.dir, c0[v], y[v]);
+          case 1: return fma(h * FF_A10, c0[v], y[v]);
+          case 2: return fma(h, FF_A20 * c0[v] + FF_A21 * c1[v], y[v]);
+          case 3: return fma(h, FF_A30 * c0[v] + FF_A31 * c1[v] + FF_A32 * c2[v], y[v]);
+          case 4: return c0[v];
+          case 5: return c1[v];
+          default: return c2[v];
         }
       };
       FF_STAMP(0);
@@ -169,24 +174,34 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       for (int v = 0; v < NV; v++) in[v] = stage_in(v);   // at stage 6 this is the candidate new state
       const double* sz = s_z[gg];
       double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
+      double vi = 0.0, dvk = 0.0, gdi = 0.0;
       if constexpr (MODE == 2) {
-        // jet phase: this lane's direction u = in[1..M]
+        // jet phase: this lane's direction u = in[1..M].  One static sweep over the radii does three things:
+        //  - first-order jet of every pair term along u  -> du  (column of dJ/dt)
+        //  - quadratic part of the second-order jet      -> qv  (source of kbar), qdiv (source of lap Delta)
+        //  - the lane's own coordinate (ai,ci) of v, Dv[kbar], grad div (picked with selects), so no second,
+        //    latency-bound pass over LDS is needed.
+        // Scheduling fences every few radii keep hipcc from hoisting all LDS reads of the sweep at once
+        // (that would need > 400 VGPRs and spill to scratch).
         double du[M], qv[M];
 #pragma unroll
         for (int k = 0; k < M; k++) { du[k] = 0.0; qv[k] = 0.0; }
         const double* u = &in[1];
+        const double* sk = s_kb[gg];
         int p = 0;
 #pragma unroll
         for (int a = 0; a < N; a++) {
 #pragma unroll
           for (int bq = a + 1; bq < N; bq++) {
-            double rho[D], dl[D], rd = 0.0, dd = 0.0;
+            double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
 #pragma unroll
             for (int c = 0; c < D; c++) {
               rho[c] = sz[a * D + c] - sz[bq * D + c];
               dl[c] = u[a * D + c] - u[bq * D + c];
+              dk[c] = sk[a * D + c] - sk[bq * D + c];
               rd = fma(rho[c], dl[c], rd);
               dd = fma(dl[c], dl[c], dd);
+              rdk = fma(rho[c], dk[c], rdk);
             }
             const double r = s_rad[gg][p], ri = s_rinv[gg][p];
             const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2], f3 = s_hd[gg][p][3];
@@ -204,19 +219,31 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
             ddiv = fma(2.0 * sp, r1, ddiv);
             qdiv += 2.0 * fma(spp, r1s, sp * r2q);
             divv += 2.0 * fma(f1, r, D * f0);
+            // own coordinate: +term if this lane's particle is a, -term if it is bq
+            const double sgn = (ai == a) ? 1.0 : ((ai == bq) ? -1.0 : 0.0);
+            double rc = rho[0], dkc = dk[0];
+#pragma unroll
+            for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
+            const double F1k = f1 * (rdk * ri);
+            vi = fma(sgn * f0, rc, vi);
+            dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
+            gdi = fma(sgn * 2.0 * sp * ri, rc, gdi);
             p++;
+            if ((p & 3) == 0) FF_SCHED_FENCE();
           }
         }
         if (has_mu) {
 #pragma unroll
           for (int a = 0; a < N; a++) {
-            double rho[D], dl[D], rd = 0.0, dd = 0.0;
+            double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
 #pragma unroll
             for (int c = 0; c < D; c++) {
               rho[c] = sz[a * D + c];
               dl[c] = u[a * D + c];
+              dk[c] = sk[a * D + c];
               rd = fma(rho[c], dl[c], rd);
               dd = fma(dl[c], dl[c], dd);
+              rdk = fma(rho[c], dk[c], rdk);
             }
             const int pp = P + a;
             const double r = s_rad[gg][pp], ri = s_rinv[gg][pp];
@@ -233,6 +260,15 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
             ddiv = fma(sp, r1, ddiv);
             qdiv += fma(spp, r1s, sp * r2q);
             divv += fma(f1, r, D * f0);
+            const double sgn = (ai == a) ? 1.0 : 0.0;
+            double rc = rho[0], dkc = dk[0];
+#pragma unroll
+            for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
+            const double F1k = f1 * (rdk * ri);
+            vi = fma(sgn * f0, rc, vi);
+            dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
+            gdi = fma(sgn * sp * ri, rc, gdi);
+            if ((a & 3) == 3) FF_SCHED_FENCE();
           }
         }
 #pragma unroll
@@ -245,57 +281,24 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < M; j++) sumq += s_q[gg][j][i];
-      } else if constexpr (MODE == 1) {
-        for (int p = 0; p < nrad; p++) {
-          const double c = p < P ? 2.0 : 1.0;
-          divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rad[gg][p], D * s_hd[gg][p][0]), divv);
+        FF_STAMP(3);
+      } else {
+        if constexpr (MODE == 1) {
+          for (int p = 0; p < nrad; p++) {
+            const double c = p < P ? 2.0 : 1.0;
+            divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rad[gg][p], D * s_hd[gg][p][0]), divv);
+          }
         }
-      }
-      FF_STAMP(3);
-      // component phase: coordinate (ai, ci).  Statically unrolled over the partner particle (the own
-      // index is masked out) so that all LDS reads are in flight together instead of one dependent trip per partner.
-      double vi = 0.0, dvk = 0.0, gdi = 0.0;
-      {
-        const double zc = sz[ai * D + ci], kc = (MODE == 2) ? s_kb[gg][ai * D + ci] : 0.0;
-        double za[D], ka[D];
-#pragma unroll
-        for (int c = 0; c < D; c++) { za[c] = sz[ai * D + c]; ka[c] = (MODE == 2) ? s_kb[gg][ai * D + c] : 0.0; }
+        // component phase (generate / delta_logp): coordinate (ai, ci) of v
+        const double zc = sz[ai * D + ci];
 #pragma unroll
         for (int bq = 0; bq < N; bq++) {
           const bool self = (bq == ai);
           const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
           const int p = self ? 0 : ff_pair_index(N, lo, hi);
-          const double m = self ? 0.0 : 1.0;
-          const double rc = zc - sz[bq * D + ci];
-          const double f0 = m * s_hd[gg][p][0];
-          vi = fma(f0, rc, vi);
-          if constexpr (MODE == 2) {
-            double rdk = 0.0;
-#pragma unroll
-            for (int c = 0; c < D; c++) rdk = fma(za[c] - sz[bq * D + c], ka[c] - s_kb[gg][bq * D + c], rdk);
-            const double ri = s_rinv[gg][p], f1 = m * s_hd[gg][p][NH > 1 ? 1 : 0], f2 = m * s_hd[gg][p][NH > 2 ? 2 : 0];
-            const double r1 = rdk * ri;
-            dvk += fma(f1 * r1, rc, f0 * (kc - s_kb[gg][bq * D + ci]));
-            const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-            gdi = fma(2.0 * sp * ri, rc, gdi);
-          }
+          vi = fma(self ? 0.0 : s_hd[gg][p][0], zc - sz[bq * D + ci], vi);
         }
-      }
-      if (has_mu) {
-        const int p = P + ai;
-        const double rc = sz[ai * D + ci];
-        const double f0 = s_hd[gg][p][0];
-        vi = fma(f0, rc, vi);
-        if constexpr (MODE == 2) {
-          double rdk = 0.0;
-#pragma unroll
-          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c], s_kb[gg][ai * D + c], rdk);
-          const double ri = s_rinv[gg][p], f1 = s_hd[gg][p][NH > 1 ? 1 : 0], f2 = s_hd[gg][p][NH > 2 ? 2 : 0];
-          const double r1 = rdk * ri;
-          dvk += fma(f1 * r1, rc, f0 * s_kb[gg][ai * D + ci]);
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(sp * ri, rc, gdi);
-        }
+        if (has_mu) vi = fma(s_hd[gg][P + ai][0], zc, vi);
       }
       out[0] = vi;
       if constexpr (MODE == 1) out[1] = -divv;
@@ -309,13 +312,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       // ------------------------------------------------------------------ consume
       if (s == -2) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k0[v] = out[v];
+        for (int v = 0; v < NV; v++) c0[v] = out[v];
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double isc = wgt(v) / (atol + fabs(y[v]) * rtol);
           p0 = fma(y[v] * isc, y[v] * isc, p0);
-          p1 = fma(k0[v] * isc, k0[v] * isc, p1);
+          p1 = fma(c0[v] * isc, c0[v] * isc, p1);
         }
         const double d0 = sqrt(group_sum(p0) / NT);
         d1v = sqrt(group_sum(p1) / NT);
@@ -325,54 +328,74 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - k0[v]) * wgt(v) / (atol + fabs(y[v]) * rtol);
+          const double t = (out[v] - c0[v]) * wgt(v) / (atol + fabs(y[v]) * rtol);
           p2 = fma(t, t, p2);
         }
         const double d2 = sqrt(group_sum(p2) / NT) / h0v;
         S.init_habs(h0v, d1v, d2);
         S.plan();
         s = 1;
+      } else if (s == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) c0[v] = out[v];
+        s = 1;
       } else if (s == 1) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k1[v] = out[v];
+        for (int v = 0; v < NV; v++) c1[v] = out[v];
         s = 2;
       } else if (s == 2) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k2[v] = out[v];
+        for (int v = 0; v < NV; v++) c2[v] = out[v];
         s = 3;
       } else if (s == 3) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k3[v] = out[v];
+        for (int v = 0; v < NV; v++) {
+          const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v];
+          c0[v] = fma(h, FF_A40 * k0v + FF_A41 * k1v + FF_A42 * k2v + FF_A43 * k3v, y[v]);
+          c1[v] = fma(h, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, y[v]);
+          c2[v] = fma(h, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, y[v]);
+          c3[v] = h * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+        }
         s = 4;
       } else if (s == 4) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k4[v] = out[v];
+        for (int v = 0; v < NV; v++) {
+          c1[v] = fma(h * FF_A54, out[v], c1[v]);
+          c2[v] = fma(h * FF_B4, out[v], c2[v]);
+          c3[v] = fma(h * FF_E4, out[v], c3[v]);
+        }
         s = 5;
       } else if (s == 5) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) k5[v] = out[v];
+        for (int v = 0; v < NV; v++) {
+          c2[v] = fma(h * FF_B5, out[v], c2[v]);
+          c3[v] = fma(h * FF_E5, out[v], c3[v]);
+        }
         s = 6;
       } else {
         double pe = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
+          const double e = fma(h * FF_E6, out[v], c3[v]);
           const double t = e * wgt(v) / (atol + fmax(fabs(y[v]), fabs(in[v])) * rtol);
           pe = fma(t, t, pe);
         }
         const double err = sqrt(group_sum(pe) / NT);
-        if (S.decide(err, A.max_steps)) {
+        const bool was_active = !S.done;
+        const bool acc = S.decide(err, A.max_steps);
+        if (acc) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
+          for (int v = 0; v < NV; v++) { y[v] = in[v]; c0[v] = out[v]; }
         }
         S.plan();
+        // wave-wide: anybody still integrating?  anybody rejected (then everyone passes through stage 0)?
         if (lane == 0) s_any = 0;
         __syncthreads();
-        if (!S.done) s_any = 1;
+        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
         const int any = s_any;
         if (!any) break;
-        s = 1;
+        s = (any & 2) ? 0 : 1;
       }
       FF_STAMP(5);
     }
