@@ -37,7 +37,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
   constexpr int NV = 2;
 
-  __shared__ ff_wtab s_w[2][FF_HMAX];
+  __shared__ ff_wtab s_w[2][FF_HPAD];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G];
   __shared__ double s_rad[G][R], s_rinv[G][R], s_ca[G][R], s_cb[G][R];
   constexpr int CH = 8;   // radii per partial-head reduction chunk (keeps the LDS hand-off buffer small)
@@ -274,22 +274,22 @@ ff_ode_adj_kernel(ff_adj_args A) {
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double isc = 1.0 / (atol + fabs(y[v]) * rtol);
+          const double isc = ff_rcp(fma(fabs(y[v]), rtol, atol));
           p0 = fma(y[v] * isc, y[v] * isc, p0);
           p1 = fma(k0[v] * isc, k0[v] * isc, p1);
         }
-        const double d0 = sqrt(group_sum(p0) / NT);
-        d1v = sqrt(group_sum(p1) / NT);
+        const double d0 = sqrt(group_sum(p0) * (1.0 / NT));
+        d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - k0[v]) / (atol + fabs(y[v]) * rtol);
+          const double t = (out[v] - k0[v]) * ff_rcp(fma(fabs(y[v]), rtol, atol));
           p2 = fma(t, t, p2);
         }
-        const double d2 = sqrt(group_sum(p2) / NT) / h0v;
+        const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
         S.plan();
         s = 1;
@@ -323,10 +323,10 @@ ff_ode_adj_kernel(ff_adj_args A) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
-          const double t = e / (atol + fmax(fabs(y[v]), fabs(in[v])) * rtol);
+          const double t = e * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
           pe = fma(t, t, pe);
         }
-        const double err = sqrt(group_sum(pe) / NT);
+        const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool acc = S.decide(err, A.max_steps);
         if (acc) {
 #pragma unroll

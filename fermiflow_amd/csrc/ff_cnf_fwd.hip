@@ -53,7 +53,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   // [M+2] dDelta/dx_i, [M+3] Delta, [M+4] L_i
   constexpr int IDL = MODE == 1 ? 1 : M + 3;  // slot of the replicated Delta
 
-  __shared__ ff_wtab s_w[2][FF_HMAX];
+  __shared__ ff_wtab s_w[2][FF_HPAD];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M];
   __shared__ double s_rad[G][R], s_rinv[G][R], s_hd[G][R][NH];
   __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
@@ -97,7 +97,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     // re-evaluates f(y) (stage 0; rejections are ~1 % of the wave-steps).
     double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
 #pragma unroll
-    for (int v = 0; v < NV; v++) y[v] = 0.0;
+    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
     y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
     if constexpr (MODE == 2) {
 #pragma unroll
@@ -123,27 +123,37 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll 1
     for (;;) {
       // ------------------------------------------------------------------ stage input
-      // The candidate state of slot v for stage s.  Only the published slots are formed before the radius phase;
-      // the full vector is formed after it, so the hottest loop of the kernel runs without `in[]` live.
+      // The candidate state for stage s (a single wave-uniform switch; code size matters: the whole RHS loop has
+      // to stay inside the 64 KB instruction cache that two CUs share).  Only the two published slots are formed
+      // before the radius phase; the full vector is formed after it, so the radius loop runs without `in[]` live.
       const double h = S.h;
-      auto stage_in = [&](int v) -> double {
-        switch (s) {
-          case -2: case 0: return y[v];
-          case -1: return fma(h0v * S.dir, c0[v], y[v]);
-          case 1: return fma(h * FF_A10, c0[v], y[v]);
-          case 2: return fma(h, FF_A20 * c0[v] + FF_A21 * c1[v], y[v]);
-          case 3: return fma(h, FF_A30 * c0[v] + FF_A31 * c1[v] + FF_A32 * c2[v], y[v]);
-          case 4: return c0[v];
-          case 5: return c1[v];
-          default: return c2[v];
-        }
+      // in = gy*y + g0*c0 + g1*c1 + g2*c2 with wave-uniform stage coefficients: one code path for all stages
+      // (c1..c3 are zero-initialised, so unused terms are exact zeros)
+      double gy = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      switch (s) {
+        case -1: g0 = h0v * S.dir; break;
+        case 1: g0 = h * FF_A10; break;
+        case 2: g0 = h * FF_A20; g1 = h * FF_A21; break;
+        case 3: g0 = h * FF_A30; g1 = h * FF_A31; g2 = h * FF_A32; break;
+        case 4: gy = 0.0; g0 = 1.0; break;
+        case 5: gy = 0.0; g1 = 1.0; break;
+        case 6: gy = 0.0; g2 = 1.0; break;
+        default: break;   // -2, 0: the state itself
+      }
+      auto form = [&](double* dst, const int v0, const int v1, const int stride) {
+#pragma unroll
+        for (int v = v0; v < v1; v += stride) dst[v] = fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v])));
       };
       FF_STAMP(0);
       // ------------------------------------------------------------------ publish
       __syncthreads();
-      if (ingrp) {
-        s_z[g][i] = stage_in(0);
-        if constexpr (MODE == 2) s_kb[g][i] = stage_in(M + 1);
+      {
+        double pub[NV];
+        form(pub, 0, MODE == 2 ? M + 2 : 1, MODE == 2 ? M + 1 : 1);   // slots 0 and (MODE 2) M+1 only
+        if (ingrp) {
+          s_z[g][i] = pub[0];
+          if constexpr (MODE == 2) s_kb[g][i] = pub[M + 1];
+        }
       }
       __syncthreads();
       FF_STAMP(1);
@@ -170,8 +180,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       FF_STAMP(2);
       // ------------------------------------------------------------------ right-hand side
       double in[NV], out[NV];
-#pragma unroll
-      for (int v = 0; v < NV; v++) in[v] = stage_in(v);   // at stage 6 this is the candidate new state
+      form(in, 0, NV, 1);   // at stage 6 this is the candidate new state
       const double* sz = s_z[gg];
       double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
       double vi = 0.0, dvk = 0.0, gdi = 0.0;
@@ -316,22 +325,22 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double isc = wgt(v) / (atol + fabs(y[v]) * rtol);
+          const double isc = wgt(v) * ff_rcp(fma(fabs(y[v]), rtol, atol));
           p0 = fma(y[v] * isc, y[v] * isc, p0);
           p1 = fma(c0[v] * isc, c0[v] * isc, p1);
         }
-        const double d0 = sqrt(group_sum(p0) / NT);
-        d1v = sqrt(group_sum(p1) / NT);
+        const double d0 = sqrt(group_sum(p0) * (1.0 / NT));
+        d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - c0[v]) * wgt(v) / (atol + fabs(y[v]) * rtol);
+          const double t = (out[v] - c0[v]) * wgt(v) * ff_rcp(fma(fabs(y[v]), rtol, atol));
           p2 = fma(t, t, p2);
         }
-        const double d2 = sqrt(group_sum(p2) / NT) / h0v;
+        const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
         S.plan();
         s = 1;
@@ -377,10 +386,10 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double e = fma(h * FF_E6, out[v], c3[v]);
-          const double t = e * wgt(v) / (atol + fmax(fabs(y[v]), fabs(in[v])) * rtol);
+          const double t = e * wgt(v) * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
           pe = fma(t, t, pe);
         }
-        const double err = sqrt(group_sum(pe) / NT);
+        const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
         if (acc) {

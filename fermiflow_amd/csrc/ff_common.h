@@ -17,6 +17,7 @@
 #define FF_MAX_ORB 36      // HO2D().orbitals has 36 entries (src/orbitals.py:81)
 #define FF_MAX_NS 12       // largest single-spin determinant handled natively
 #define FF_HMAX 64         // hidden width supported by the fused ODE kernels (reference default: 50)
+#define FF_HPAD (FF_HMAX + 8)  // LDS weight table length: zero-padded so unrolled unit loops may overrun H
 
 #ifdef FF_HOSTSIM
 #include "../../tests/hostsim/hip_shim.h"

@@ -25,8 +25,8 @@ struct ff_geom {
 // per-hidden-unit weight record staged in LDS (48 B, 16-B aligned -> three ds_read_b128)
 struct __attribute__((aligned(16))) ff_wtab { double w1, b1, w2, w2w1, w2w1_2, w2w1_3; };
 
-FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HMAX], const ff_net& net, int lane) {
-  for (int h = lane; h < FF_HMAX; h += FF_WAVE) {
+FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HPAD], const ff_net& net, int lane) {
+  for (int h = lane; h < FF_HPAD; h += FF_WAVE) {
     ff_wtab e = {0, 0, 0, 0, 0, 0}, m = {0, 0, 0, 0, 0, 0};
     if (h < net.He) {
       e.w1 = net.ew1[h]; e.b1 = net.eb1[h]; e.w2 = net.ew2[h];
@@ -45,7 +45,7 @@ FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HMAX], const ff_net& net, int lane) 
 // The exp/rcp chain of one hidden unit is ~45 dependent fp64 instructions; four units are evaluated side by
 // side so that a single resident wave per SIMD still has independent work to issue every cycle.  The weight
 // table is zero-padded to FF_HMAX, so running the loop to the next multiple of 4 adds exact zeros.
-#define FF_HU 4
+#define FF_HU 5
 template <int NH, bool TAB>
 FF_D void ff_heads(const ff_wtab* __restrict__ tab, const double* __restrict__ e2, int H, double r, double* hd) {
   double h0[FF_HU], h1[FF_HU], h2[FF_HU], h3[FF_HU];
@@ -68,10 +68,13 @@ FF_D void ff_heads(const ff_wtab* __restrict__ tab, const double* __restrict__ e
       }
     }
   }
-  hd[0] = (h0[0] + h0[1]) + (h0[2] + h0[3]);
-  if (NH >= 2) hd[1] = (h1[0] + h1[1]) + (h1[2] + h1[3]);
-  if (NH >= 3) hd[2] = (h2[0] + h2[1]) + (h2[2] + h2[3]);
-  if (NH >= 4) hd[3] = (h3[0] + h3[1]) + (h3[2] + h3[3]);
+  double t0 = h0[0], t1 = h1[0], t2 = h2[0], t3 = h3[0];
+#pragma unroll
+  for (int q = 1; q < FF_HU; q++) { t0 += h0[q]; t1 += h1[q]; t2 += h2[q]; t3 += h3[q]; }
+  hd[0] = t0;
+  if (NH >= 2) hd[1] = t1;
+  if (NH >= 3) hd[2] = t2;
+  if (NH >= 4) hd[3] = t3;
 }
 
 // Dormand-Prince tableau
@@ -102,6 +105,17 @@ FF_D void ff_heads(const ff_wtab* __restrict__ tab, const double* __restrict__ e
 #define FF_E5 (-22.0 / 525)
 #define FF_E6 (1.0 / 40)
 
+// x^(+-1/5) for the step-size controller: single-precision log/exp hardware ops (3 instructions instead of
+// ~200 for the fp64 pow); 1e-6 relative accuracy is irrelevant for a step-size factor, and every lane of a
+// walker's group computes the identical value.
+FF_D double ff_pow02(double x, float e) {
+#ifdef FF_HOSTSIM
+  return (double)powf((float)x, e);
+#else
+  return (double)__powf((float)x, e);
+#endif
+}
+
 // per-walker step-size bookkeeping (identical on all lanes of a walker's group)
 struct ff_stepper {
   double t, tb, dir, interval, habs, h, tnew;
@@ -118,7 +132,7 @@ struct ff_stepper {
     return fmin(v, interval);
   }
   FF_D void init_habs(double h0v, double d1, double d2) {
-    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0v * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0v * 1e-3) : ff_pow02(0.01 / fmax(d1, d2), 0.2f);
     habs = fmin(fmin(100.0 * h0v, h1), interval);
   }
   FF_D void plan() {  // choose h for the next attempt
@@ -134,13 +148,13 @@ struct ff_stepper {
     natt++;
     bool acc = err < 1.0;
     if (acc) {
-      double f = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+      double f = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * ff_pow02(err, -0.2f));
       if (rejected) f = fmin(1.0, f);
       habs *= f; t = tnew; rejected = 0; nacc++;
       if (dir * (t - tb) >= 0.0) done = true;
     } else {
       if (!(err == err)) { fail = 1; done = true; }
-      else { habs *= fmax(0.2, 0.9 * pow(err, -0.2)); rejected = 1; nrej++; }
+      else { habs *= fmax(0.2, 0.9 * ff_pow02(err, -0.2f)); rejected = 1; nrej++; }
     }
     if (!done && natt >= max_steps) { fail = 1; done = true; }
     return acc;
