@@ -27,6 +27,11 @@
 #define FF_STAMP(i) do { } while (0)
 #endif
 
+// which kernels use the LDS-table exp (ff_exp_tab): tuning knob, see tools/kbench.py A/B runs
+#ifndef FF_TAB_MODE
+#define FF_TAB_MODE(MODE) true
+#endif
+
 struct ff_fwd_args {
   int64_t B;
   ff_net net;
@@ -169,7 +174,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         }
         const double r = sqrt(r2);
         double hd[NH];
-        ff_heads<NH, (MODE < 2)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
+        ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
         s_rad[qg][p] = r;
         s_rinv[qg][p] = ff_rcp(r);
 #pragma unroll
