@@ -69,12 +69,13 @@ ff_ode_adj_kernel(ff_adj_args A) {
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
 
-  // parameter-gradient accumulators of this lane's units: [net][unit][w1,b1,w2]
-  double fin[2][MAXU][3];
-#pragma unroll
-  for (int t = 0; t < 2; t++)
-#pragma unroll
-    for (int j = 0; j < MAXU; j++) fin[t][j][0] = fin[t][j][1] = fin[t][j][2] = 0.0;
+  // This lane's slice of the parameter-gradient row of (workgroup, group-slot): entries of its own units only,
+  // so accepted steps are added with plain (non-atomic) read-modify-writes; the API zeroes the rows first.
+  double* const myrow = A.rows + ((int64_t)blockIdx.x * G + (ingrp ? g : 0)) * (3 * He + 3 * Hm);
+  auto row_add = [&](int t, int j, int c, double v) {
+    const int k = i + j * M, H = t ? Hm : He;
+    if (ingrp && k < H) myrow[(t ? 3 * He : 0) + c * H + k] += v;
+  };
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b = grp * G + g;
@@ -83,13 +84,14 @@ ff_ode_adj_kernel(ff_adj_args A) {
     y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
     y[1] = valid ? A.az_in[b * M + i] : 0.0;
     if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
-    double tent[2][MAXU][3], fsal[2][MAXU][3];
+    // tent = B0*k0_theta + sum_{s=2..5} B_s*k_s_theta of the step under way (dropped if the step is rejected)
+    double tent[2][MAXU][3];
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int j = 0; j < MAXU; j++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) { tent[t][j][c] = 0.0; fsal[t][j][c] = 0.0; }
+        for (int c = 0; c < 3; c++) tent[t][j][c] = 0.0;
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     int s = -2, nev = 0;
@@ -110,7 +112,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
       double in[NV];
       const double h = S.h;
       switch (s) {
-        case -2:
+        case -2: case 0:
 #pragma unroll
           for (int v = 0; v < NV; v++) in[v] = y[v];
           break;
@@ -270,7 +272,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
 #pragma unroll
           for (int j = 0; j < MAXU; j++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) fsal[t][j][c] = cur[t][j][c];
+            for (int c = 0; c < 3; c++) tent[t][j][c] = FF_B0 * cur[t][j][c];
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -292,6 +294,16 @@ ff_ode_adj_kernel(ff_adj_args A) {
         const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
         S.plan();
+        s = 1;
+      } else if (s == 0) {   // re-evaluated f(y) after a rejection (k0 and its parameter integrand)
+#pragma unroll
+        for (int v = 0; v < NV; v++) k0[v] = out[v];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int j = 0; j < MAXU; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) tent[t][j][c] = FF_B0 * cur[t][j][c];
         s = 1;
       } else if (s >= 1 && s <= 5) {
         const double bw = s == 1 ? 0.0 : (s == 2 ? FF_B2 : (s == 3 ? FF_B3 : (s == 4 ? FF_B4 : FF_B5)));
@@ -327,6 +339,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
           pe = fma(t, t, pe);
         }
         const double err = sqrt(group_sum(pe) * (1.0 / NT));
+        const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
         if (acc) {
 #pragma unroll
@@ -338,20 +351,17 @@ ff_ode_adj_kernel(ff_adj_args A) {
           for (int j = 0; j < MAXU; j++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-              if (acc) {
-                fin[t][j][c] = fma(h, fma(FF_B0, fsal[t][j][c], tent[t][j][c]), fin[t][j][c]);
-                fsal[t][j][c] = cur[t][j][c];
-              }
-              tent[t][j][c] = 0.0;
+              if (acc) row_add(t, j, c, h * tent[t][j][c]);
+              tent[t][j][c] = acc ? FF_B0 * cur[t][j][c] : 0.0;   // FSAL: k6_theta opens the next step
             }
         S.plan();
         if (lane == 0) s_any = 0;
         __syncthreads();
-        if (!S.done) s_any = 1;
+        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
         const int any = s_any;
         if (!any) break;
-        s = 1;
+        s = (any & 2) ? 0 : 1;   // somebody rejected: the whole wave passes through stage 0
       }
     }
     if (valid) {
@@ -365,16 +375,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     }
     __syncthreads();
   }
-  // per-(workgroup, group-slot) rows; summed deterministically by ff_rows_reduce_kernel
-  if (ingrp) {
-    double* row = A.rows + ((int64_t)blockIdx.x * G + g) * (3 * He + 3 * Hm);
-#pragma unroll
-    for (int j = 0; j < MAXU; j++) {
-      const int k = i + j * M;
-      if (k < He) { row[k] = fin[0][j][0]; row[He + k] = fin[0][j][1]; row[2 * He + k] = fin[0][j][2]; }
-      if (k < Hm) { row[3 * He + k] = fin[1][j][0]; row[3 * He + Hm + k] = fin[1][j][1]; row[3 * He + 2 * Hm + k] = fin[1][j][2]; }
-    }
-  }
+  // (rows are summed deterministically by ff_rows_reduce_kernel)
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);
     atomicMax(&A.stats[1], acc_max);
@@ -451,6 +452,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
   FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2)
