@@ -27,6 +27,13 @@
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), __VA_ARGS__)
 #endif
 
+// a value the program knows to be wave-uniform -> scalar register (lets loops on it be scalar loops)
+#ifdef FF_HOSTSIM
+#define FF_UNIFORM(x) (x)
+#else
+#define FF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 #define FF_D __device__ __forceinline__
 #define FF_HD __host__ __device__ __forceinline__
 

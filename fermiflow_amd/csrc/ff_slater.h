@@ -68,40 +68,40 @@ FF_D void ff_orbital(int k, double x, double y, double gauss /* pi^-1/2 exp(-r^2
 FF_D double ff_gauss2d(double x, double y) { return FF_PI_SQRT_INV * exp(-0.5 * (x * x + y * y)); }
 
 // --------------------------------------------------------------------------------------------------
-// Register-resident log|det| for compile-time NS (MCMC hot loop).  The normalised Hermite functions of
-// one coordinate are produced together by the three-term recurrence
+// Register-resident log|det| for compile-time NS (MCMC hot loop).  The normalised Hermite function of degree n
+// comes from the three-term recurrence
 //   h_0 = 1, h_1 = sqrt(2) x, h_{m+1} = sqrt(2/(m+1)) x h_m - sqrt(m/(m+1)) h_{m-1}
-// (same polynomials as src/orbitals.py:66-73, no table loads) and picked per orbital with a select chain, so
-// everything stays in VGPRs.  LU with partial pivoting; all indices static, row exchange by predicated swaps.
-FF_D void ff_herm_all(double x, double* h /* [8] */) {
-  const double a[7] = {1.4142135623730951, 1.0, 0.81649658092772603, 0.70710678118654752, 0.63245553203367588,
-                       0.57735026918962576, 0.53452248382484879};  // sqrt(2/(m+1)), m = 0..6
-  const double b[7] = {0.0, 0.70710678118654752, 0.81649658092772603, 0.86602540378443865, 0.89442719099991588,
-                       0.91287092917527686, 0.92582009977255146};  // sqrt(m/(m+1))
-  h[0] = 1.0;
-  h[1] = a[0] * x;
-#pragma unroll
-  for (int m = 1; m < 7; m++) h[m + 1] = fma(a[m] * x, h[m], -b[m] * h[m - 1]);
-}
-FF_D double ff_pick8(const double* h, int n) {
-  double v = h[0];
-#pragma unroll
-  for (int m = 1; m < 8; m++) v = (n == m) ? h[m] : v;
-  return v;
+// (same polynomials as src/orbitals.py:66-73).  LU with partial pivoting; all indices static, row exchange by
+// predicated swaps, so the determinant stays in VGPRs.
+// (no table of all degrees + select: hipcc turns such a select chain into a runtime-indexed private array,
+//  i.e. scratch traffic on every Metropolis step; the short recurrence loop keeps two live values instead)
+__constant__ double FF_REC_A[7] = {1.4142135623730951, 1.0, 0.81649658092772603, 0.70710678118654752, 0.63245553203367588,
+                                   0.57735026918962576, 0.53452248382484879};  // sqrt(2/(m+1)), m = 0..6
+__constant__ double FF_REC_B[7] = {0.0, 0.70710678118654752, 0.81649658092772603, 0.86602540378443865, 0.89442719099991588,
+                                   0.91287092917527686, 0.92582009977255146};  // sqrt(m/(m+1))
+// degree n <= md, md WAVE-UNIFORM (scalar trip count: no exec-masked loop, two live values, result by select)
+FF_D double ff_herm_rec(int n, double x, int md) {
+  double hm = 1.0, h = FF_REC_A[0] * x;
+  double res = (n == 0) ? 1.0 : h;
+  for (int m = 1; m < md; m++) {
+    const double hn = fma(FF_REC_A[m] * x, h, -FF_REC_B[m] * hm);
+    hm = h;
+    h = hn;
+    res = (n == m + 1) ? h : res;
+  }
+  return res;
 }
 
-// nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop.
+// nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop;
+// md: a wave-uniform upper bound of those degrees.
 template <int NS>
-FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* x) {
+FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* x, int md) {
   double D[NS][NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) {
     double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
-    double hx[8], hy[8];
-    ff_herm_all(x[2 * i], hx);
-    ff_herm_all(x[2 * i + 1], hy);
 #pragma unroll
-    for (int j = 0; j < NS; j++) D[i][j] = gs * ff_pick8(hx, nx[j]) * ff_pick8(hy, ny[j]);
+    for (int j = 0; j < NS; j++) D[i][j] = gs * ff_herm_rec(nx[j], x[2 * i], md) * ff_herm_rec(ny[j], x[2 * i + 1], md);
   }
   double acc = 0.0;
 #pragma unroll

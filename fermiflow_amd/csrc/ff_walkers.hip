@@ -28,11 +28,11 @@ FF_D double ff_add_rn(double a, double b) { double r = a + b; asm volatile("" : 
 // ou/od: orbital indices (generic path) -- or, for compile-time sizes, ou = [nx | ny] degrees of the up
 // orbitals and od likewise for the down orbitals (decoded once, outside the step loop).
 template <int NU, int ND>
-FF_D double ff_logprob_value(int nup, int ndn, const int* ou, const int* od, const double* x) {
+FF_D double ff_logprob_value(int nup, int ndn, const int* ou, const int* od, const double* x, int md) {
   double s = 0.0;
   if constexpr (NU >= 0) {
-    if constexpr (NU > 0) s += ff_slater_logabsdet_reg<NU>(ou, ou + NU, x);
-    if constexpr (ND > 0) s += ff_slater_logabsdet_reg<ND>(od, od + ND, x + 2 * NU);
+    if constexpr (NU > 0) s += ff_slater_logabsdet_reg<NU>(ou, ou + NU, x, md);
+    if constexpr (ND > 0) s += ff_slater_logabsdet_reg<ND>(od, od + ND, x + 2 * NU, md);
   } else {
     if (nup) s += ff_slater_general(nup, ou, x, nullptr, nullptr);
     if (ndn) s += ff_slater_general(ndn, od, x + 2 * nup, nullptr, nullptr);
@@ -53,8 +53,12 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
   const int n = nup + ndn, M = 2 * n;
   constexpr int MAXM = FIXED ? 2 * (NU + ND) : 2 * FF_MAX_N;
   constexpr int MAXU = FIXED ? (NU > 0 ? NU : 1) : FF_MAX_NS, MAXD = FIXED ? (ND > 0 ? ND : 1) : FF_MAX_NS;
+  __shared__ int s_md;
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  if (threadIdx.x == 0) s_md = 0;
+  __syncthreads();
+  const bool live = b < B;
+  if (!live) b = B - 1;          // idle tail lanes shadow the last walker (they take part in the barriers)
   const int st = wstate ? wstate[b] : 0;
   int ou[2 * MAXU], od[2 * MAXD];
 #pragma unroll
@@ -67,6 +71,17 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
     const int k = (j < ndn) ? tab_dn[st * ndn + j] : 0;
     if constexpr (FIXED) ff_orb_decode(k, od[j], od[MAXD + j]); else od[j] = k;
   }
+  // largest Hermite degree in the workgroup, as a scalar (wave-uniform loop bounds in ff_herm_rec)
+  int md = 0;
+  if constexpr (FIXED) {
+#pragma unroll
+    for (int j = 0; j < 2 * MAXU; j++) md = (j % MAXU < nup && ou[j] > md) ? ou[j] : md;
+#pragma unroll
+    for (int j = 0; j < 2 * MAXD; j++) md = (j % MAXD < ndn && od[j] > md) ? od[j] : md;
+    atomicMax(&s_md, md);
+    __syncthreads();
+    md = FF_UNIFORM(s_md);
+  }
 
   double x[MAXM], nx[MAXM];
   const uint64_t wid = (uint64_t)(woff + b);
@@ -77,7 +92,7 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
 #pragma unroll
     for (int j = 0; j < MAXM / 2; j++) if (j < n) ff_normal_pair(seed, wid, 0u, (uint32_t)j, x[2 * j], x[2 * j + 1]);
   }
-  double logp = ff_logprob_value<NU, ND>(nup, ndn, ou, od, x);
+  double logp = ff_logprob_value<NU, ND>(nup, ndn, ou, od, x, md);
   int nacc = 0;
   for (int s = 0; s < steps; s++) {
     if (NOISE) {
@@ -94,7 +109,7 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
           nx[2 * j + 1] = ff_add_rn(x[2 * j + 1], ff_mul_rn(tau, z1));
         }
     }
-    double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx);
+    double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx, md);
     double p = exp(nl - logp);
     double uu = NOISE ? u[(int64_t)s * B + b] : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
     bool acc = uu < p;  // NaN p -> reject, +inf p -> accept (IEEE), as torch
@@ -104,8 +119,9 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
       logp = nl;
       nacc++;
     }
-    if (accept) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+    if (accept && live) accept[(int64_t)s * B + b] = acc ? 1 : 0;
   }
+  if (!live) return;
 #pragma unroll
   for (int i = 0; i < MAXM; i++) if (i < M) x_out[b * M + i] = x[i];
   if (logp_out) logp_out[b] = logp;
