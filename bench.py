@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per RHS evaluation of one walker in the local-energy kernel ("Kernels"):
-FLOP_PER_SIGMOID_UNIT = 30      # 1 exp + 1 rcp + ~8 FMA-class ops
+FLOP_PER_SIGMOID_UNIT = 30      # 1 exp + 1 rcp + ~8 FMA-class ops      (FERMIFLOW_RADIAL=exact)
+FLOP_PER_TABLE_RADIUS = 60      # 4 heads x 5 Horner FMAs + index/offset arithmetic     (FERMIFLOW_RADIAL=table, default)
 FLOP_PER_JET_TERM = 55          # counted from the jet-phase source: one (direction, radius) term
 PEAK_FP64_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (vendor)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -107,14 +108,16 @@ def main():
     evals = sum(int(s[0].item()) for s in prof["eloc_stats"]) / args.steps          # RHS evaluations summed over walkers
     n = args.nup + args.ndown
     M, R, H = 2 * n, n * (n - 1) // 2 + n, 50
-    flop_per_eval = R * H * FLOP_PER_SIGMOID_UNIT + M * R * FLOP_PER_JET_TERM
+    from fermiflow_amd import _lib as L
+    radial = L.RADIAL_MODE
+    flop_per_eval = (R * H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else R * FLOP_PER_TABLE_RADIUS) + M * R * FLOP_PER_JET_TERM
     achieved = evals * flop_per_eval / (k_ms * 1e-3) / 1e12
     roofline = {"kernel": f"ff_ode_fwd_kernel<{n},2,2> (local-energy sensitivities)", "bound": "mfma",
                 "note": "fp64 VALU-bound; on MI355X the fp64 vector and fp64 MFMA peaks coincide (78.6 TFLOP/s); "
                         "MFMA is not used: the MLP is 1->50->1 (no dense GEMM)",
                 "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / args.walkers_per_gpu,
-                "flop_per_walker_eval": flop_per_eval}
+                "flop_per_walker_eval": flop_per_eval, "radial_functions": radial}
 
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",
            "value": B_glob * 100 * args.steps / dt, "unit": "walker-steps/s", "n_gpus": n_gpus, "steps": args.steps,

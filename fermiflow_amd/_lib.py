@@ -14,7 +14,7 @@ _LIB = None
 
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
-    "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential",
+    "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
     "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint",
     "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments",
 ]
@@ -22,7 +22,8 @@ SYMBOLS = [
 
 class FFNet(C.Structure):
     _fields_ = [("He", C.c_int32), ("ew1", C.c_void_p), ("eb1", C.c_void_p), ("ew2", C.c_void_p),
-                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p)]
+                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p),
+                ("radial_table", C.c_void_p)]
 
 
 class FFOde(C.Structure):
@@ -42,6 +43,7 @@ def lib():
         _LIB.ff_last_error.restype = C.c_char_p
         _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
         _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
+        _LIB.ff_radial_table_bytes.restype = C.c_size_t
     return _LIB
 
 
@@ -83,10 +85,14 @@ def f64(v):
     return C.c_double(float(v))
 
 
-class Net:
-    """Device pointers of the backflow's two scalar MLPs (keeps the tensors alive)."""
+RADIAL_MODE = os.environ.get("FERMIFLOW_RADIAL", "table")   # "table" (default) | "exact": how the ODE kernels evaluate eta, mu
 
-    def __init__(self, eta, mu=None):
+
+class Net:
+    """Device pointers of the backflow's two scalar MLPs (keeps the tensors alive).  With radial="table" the
+    per-launch radial table (csrc/ff_radial.h) is built here, on the current stream, for exactly these weights."""
+
+    def __init__(self, eta, mu=None, radial=None):
         self.t = []
 
         def three(m):
@@ -97,8 +103,13 @@ class Net:
         m = three(mu) if mu is not None else (None, None, None)
         self.He = e[0].numel()
         self.Hm = m[0].numel() if mu is not None else 0
-        self.c = FFNet(self.He, ptr(e[0]), ptr(e[1]), ptr(e[2]), self.Hm, ptr(m[0]), ptr(m[1]), ptr(m[2]))
+        self.c = FFNet(self.He, ptr(e[0]), ptr(e[1]), ptr(e[2]), self.Hm, ptr(m[0]), ptr(m[1]), ptr(m[2]), None)
         self.device = e[0].device
+        if (radial or RADIAL_MODE) == "table":
+            tab = torch.empty(lib().ff_radial_table_bytes() // 8, dtype=torch.float64, device=self.device)
+            check(lib().ff_radial_table_build(stream(), C.byref(self.c), ptr(tab)), "ff_radial_table_build")
+            self.t.append(tab)
+            self.c.radial_table = tab.data_ptr()
 
     @property
     def nparams(self):

@@ -18,6 +18,7 @@
 #include "ff_common.h"
 #include "ff_ode.h"
 #include "ff_slater.h"
+#include "ff_radial.h"
 
 // FF_STAMPS: diagnostic build only (tools/kbench.py --stamps): per-phase s_memtime shares of the RHS loop,
 // added into stats[8..] as 64-bit counters.  Never defined in the product build.
@@ -83,6 +84,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? (P + N) : P;
+  const double* __restrict__ rtab = A.net.radial_table;
+  const bool use_tab = rtab != nullptr && rtab[3] == 0.0;
+  const double tab_inv_h = use_tab ? rtab[0] : 0.0, tab_h = use_tab ? rtab[1] : 0.0;
   const double rtol = A.rtol, atol = A.atol;
   constexpr double NT = MODE == 0 ? M : (MODE == 1 ? M + 1 : M * (M + 4) + 1);
   const int64_t ngroups = (A.B + G - 1) / G;
@@ -174,7 +178,8 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         }
         const double r = sqrt(r2);
         double hd[NH];
-        ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
+        if (!(use_tab && ff_heads_table<NH>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd)))
+          ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
         s_rad[qg][p] = r;
         s_rinv[qg][p] = ff_rcp(r);
 #pragma unroll
@@ -558,6 +563,19 @@ static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode
 }
 
 extern "C" {
+
+size_t ff_radial_table_bytes(void) { return sizeof(double) * (size_t)FF_TAB_DOUBLES; }
+
+int ff_radial_table_build(void* stream, const ff_net* net, double* table) {
+  FF_CHECK(net && table, FF_EINVAL, "ff_radial_table_build: null pointer");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_radial_table_build: bad net");
+  FF_LAUNCH(ff_table_header_kernel, 1, 64, stream, *net, table);
+  FF_LAUNCH_CHECK();
+  FF_LAUNCH(ff_table_build_kernel, (unsigned)((2 * FF_TAB_NMAX + 127) / 128), 128, stream, *net, table);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
 
 int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z,
                     double* x_out, int32_t* stats) {

@@ -1,0 +1,107 @@
+// ff_radial.h -- tabulated radial functions eta(r), mu(r) and their derivatives for the fused ODE kernels.
+//
+// Inside one launch the MLP weights are fixed, so eta and mu (src/MLP.py:30-45) are fixed analytic functions of one
+// variable -- exactly the situation in which QMC codes tabulate their radial functions.  A small kernel evaluates
+// eta^(0..8) and mu^(0..8) on a uniform grid (spacing h = 2^-k chosen from max|w1| so that the truncation error of the
+// expansion below stays ~1e-16 relative to the function's own scale); the ODE kernels then evaluate the NH derivative
+// heads of a radius as 5th-order Taylor expansions about the nearest node:
+//     f^(m)(r) = sum_{k=0..5} T[j][m+k] dr^k / k!,   dr = r - j h,  |dr| <= h/2,  remainder <= (h/2)^6/720 |f^(m+6)|.
+// Cost per radius: ~30 fp64 instructions instead of H (=50) exp/rcp chains (~2000).  Radii beyond the table
+// (r >= FF_TAB_RMAX), non-finite radii, or weights too stiff for the largest grid fall back to the direct evaluation.
+// The table is rebuilt by every call that receives new weights (a few microseconds).
+#pragma once
+#include "ff_common.h"
+
+#define FF_TAB_RMAX 32.0
+#define FF_TAB_ROW 10                       // doubles per node (9 used; 80-byte rows keep 16-byte alignment)
+#define FF_TAB_MAXLOG 9                     // finest grid: h = 2^-9
+#define FF_TAB_NMAX (32 * (1 << FF_TAB_MAXLOG) + 1)
+#define FF_TAB_HDR 8                        // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used
+#define FF_TAB_DOUBLES (FF_TAB_HDR + 2 * FF_TAB_NMAX * FF_TAB_ROW)
+
+// sigma^(n)(a) as a polynomial in s = sigma(a): P_0 = s, P_{n+1} = P_n'(s) s (1 - s)
+__constant__ double FF_SIGPOLY[9][10] = {
+    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -1, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -3, 2, 0, 0, 0, 0, 0, 0},
+    {0, 1, -7, 12, -6, 0, 0, 0, 0, 0},
+    {0, 1, -15, 50, -60, 24, 0, 0, 0, 0},
+    {0, 1, -31, 180, -390, 360, -120, 0, 0, 0},
+    {0, 1, -63, 602, -2100, 3360, -2520, 720, 0, 0},
+    {0, 1, -127, 1932, -10206, 25200, -31920, 20160, -5040, 0},
+    {0, 1, -255, 6050, -46620, 166824, -317520, 332640, -181440, 40320}};
+
+// header: grid spacing from the stiffest first-layer weight (single workgroup)
+__global__ void __launch_bounds__(64) ff_table_header_kernel(ff_net net, double* __restrict__ tab) {
+  __shared__ double sm[64];
+  double w = 0.0;
+  for (int h = threadIdx.x; h < net.He; h += 64) w = fmax(w, fabs(net.ew1[h]));
+  for (int h = threadIdx.x; h < net.Hm; h += 64) w = fmax(w, fabs(net.mw1[h]));
+  sm[threadIdx.x] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 64; q++) w = fmax(w, sm[q]);
+    // (w h/2)^6/720 <~ 1e-15  <=>  w h <= 0.06
+    int lg = 6;
+    while (lg < FF_TAB_MAXLOG && w * ldexp(1.0, -lg) > 0.06) lg++;
+    const bool bad = !(w * ldexp(1.0, -lg) <= 0.06);   // also catches NaN weights
+    tab[0] = ldexp(1.0, lg);
+    tab[1] = ldexp(1.0, -lg);
+    tab[2] = (double)(32 * (1 << lg) + 1);
+    tab[3] = bad ? 1.0 : 0.0;
+  }
+}
+
+// one lane per (net, node): f^(0..8)(r_j) = sum_h w2 w1^n sigma^(n)(w1 r_j + b1)
+__global__ void __launch_bounds__(128) ff_table_build_kernel(ff_net net, double* __restrict__ tab) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = idx / FF_TAB_NMAX, j = idx - t * FF_TAB_NMAX;
+  const int nodes = (int)tab[2];
+  if (t > 1 || j >= nodes || tab[3] != 0.0) return;
+  const int H = t ? net.Hm : net.He;
+  const double* w1 = t ? net.mw1 : net.ew1;
+  const double* b1 = t ? net.mb1 : net.eb1;
+  const double* w2 = t ? net.mw2 : net.ew2;
+  const double r = (double)j * tab[1];
+  double acc[9];
+#pragma unroll
+  for (int n = 0; n < 9; n++) acc[n] = 0.0;
+  for (int h = 0; h < H; h++) {
+    const double s = ff_sigmoid(fma(w1[h], r, b1[h]));
+    double wp = w2[h];
+#pragma unroll
+    for (int n = 0; n < 9; n++) {
+      double p = FF_SIGPOLY[n][n + 1];
+#pragma unroll
+      for (int c = n; c >= 1; c--) p = fma(p, s, FF_SIGPOLY[n][c]);
+      acc[n] = fma(wp, p * s, acc[n]);
+      wp *= w1[h];
+    }
+  }
+  double* row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + j) * FF_TAB_ROW;
+#pragma unroll
+  for (int n = 0; n < 9; n++) row[n] = acc[n];
+  row[9] = 0.0;
+}
+
+// NH derivative heads of net t (0 eta, 1 mu) at radius r from the table; returns false if r is off the table
+template <int NH>
+FF_D bool ff_heads_table(const double* __restrict__ tab, double inv_h, double h, int t, double r, double* hd) {
+  if (!(r < FF_TAB_RMAX)) return false;
+  const double jf = rint(r * inv_h);
+  const double dr = fma(-jf, h, r);
+  const double* __restrict__ row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + (int)jf) * FF_TAB_ROW;
+  double T[NH + 5];
+#pragma unroll
+  for (int e = 0; e < NH + 5; e++) T[e] = row[e];
+  const double d2 = dr * 0.5, d3 = dr * (1.0 / 3.0), d4 = dr * 0.25, d5 = dr * 0.2;
+#pragma unroll
+  for (int m = 0; m < NH; m++) {
+    double v = fma(T[m + 5], d5, T[m + 4]);
+    v = fma(v, d4, T[m + 3]);
+    v = fma(v, d3, T[m + 2]);
+    v = fma(v, d2, T[m + 1]);
+    hd[m] = fma(v, dr, T[m]);
+  }
+  return true;
+}

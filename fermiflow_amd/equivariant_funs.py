@@ -16,8 +16,8 @@ class Backflow(torch.nn.Module):
         self.eta = eta
         self.mu = mu
 
-    def net(self):
-        return L.Net(self.eta, self.mu)
+    def net(self, radial=None):
+        return L.Net(self.eta, self.mu, radial=radial)
 
     def forward(self, x):
         v, _ = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=True, need_div=False)
@@ -28,7 +28,7 @@ class Backflow(torch.nn.Module):
         return div
 
     def _e_e(self, x):
-        return native.backflow_v_div(L.Net(self.eta, None), x.detach().contiguous(), True, False)[0]
+        return native.backflow_v_div(L.Net(self.eta, None, radial="exact"), x.detach().contiguous(), True, False)[0]
 
     def _e_e_divergence(self, x):
-        return native.backflow_v_div(L.Net(self.eta, None), x.detach().contiguous(), False, True)[1]
+        return native.backflow_v_div(L.Net(self.eta, None, radial="exact"), x.detach().contiguous(), False, True)[1]

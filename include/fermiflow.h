@@ -29,6 +29,8 @@ extern "C" {
 typedef struct ff_net {
   int32_t He; const double *ew1, *eb1, *ew2;
   int32_t Hm; const double *mw1, *mb1, *mw2;
+  const double* radial_table;   /* optional: built by ff_radial_table_build for THESE weights; NULL = evaluate the
+                                   sigmoids directly in every kernel (see fermiflow_amd/csrc/ff_radial.h) */
 } ff_net;
 
 /* ODE controls of solve_ivp_nnmodule (src/NeuralODE/nnModule.py:161-162: rtol=1e-6, atol=1e-8). */
@@ -78,6 +80,13 @@ int ff_mlp_eval(void* stream, int64_t N, int H, const double* w1, const double* 
 int ff_backflow_v_div(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div);
 /* HO.V + CoulombPairPotential(Z).V (src/potentials.py:13, 23-47); use_ho = 0 drops the trap term. */
 int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V);
+
+/* Tabulate eta^(0..8), mu^(0..8) on a uniform grid for the weights in `net` (net->radial_table is ignored);
+ * `table` must hold ff_radial_table_bytes() bytes.  Used by ff_cnf_generate / ff_cnf_delta_logp / ff_eloc when
+ * net->radial_table points at it: radii on the table are then evaluated by 5th-order Taylor expansion about the
+ * nearest node (truncation ~1e-16 relative), all others directly. */
+size_t ff_radial_table_bytes(void);
+int ff_radial_table_build(void* stream, const ff_net* net, double* table);
 
 /* ---- CNF: fused adaptive Dormand-Prince 5(4) integrations, one walker group per wave ------------ */
 /* stats (int32 [4], may be NULL; caller zeroes): [0] += RHS evaluations summed over walkers,

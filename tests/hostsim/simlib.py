@@ -13,7 +13,8 @@ _LIB = None
 
 class FFNet(C.Structure):
     _fields_ = [("He", C.c_int32), ("ew1", C.c_void_p), ("eb1", C.c_void_p), ("ew2", C.c_void_p),
-                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p)]
+                ("Hm", C.c_int32), ("mw1", C.c_void_p), ("mb1", C.c_void_p), ("mw2", C.c_void_p),
+                ("radial_table", C.c_void_p)]
 
 
 class FFOde(C.Structure):
@@ -54,13 +55,18 @@ def _ck(st):
 
 
 class Net:
-    def __init__(self, eta, mu=None):
+    def __init__(self, eta, mu=None, table=False):
         self.e = [_d(np.reshape(a, -1)) for a in eta]
         self.m = [_d(np.reshape(a, -1)) for a in mu] if mu is not None else None
         self.c = FFNet(len(self.e[0]), _p(self.e[0]), _p(self.e[1]), _p(self.e[2]),
                        len(self.m[0]) if self.m else 0,
                        _p(self.m[0]) if self.m else None, _p(self.m[1]) if self.m else None,
-                       _p(self.m[2]) if self.m else None)
+                       _p(self.m[2]) if self.m else None, None)
+        if table:
+            lib().ff_radial_table_bytes.restype = C.c_size_t
+            self.tab = np.zeros(lib().ff_radial_table_bytes() // 8)
+            _ck(lib().ff_radial_table_build(None, C.byref(self.c), _p(self.tab)))
+            self.c.radial_table = self.tab.ctypes.data
 
     @property
     def nparams(self):

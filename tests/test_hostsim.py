@@ -86,3 +86,31 @@ def test_eloc_kernel(golden, name):
     ref = O.eloc(x, nup, ndn, onet, float(G[name + "_Z"]), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-6)
     assert r["stats"][3] == 0
+
+
+def test_radial_table_matches_direct_evaluation(golden):
+    """ff_radial.h: the tabulated eta/mu heads reproduce the direct sigmoid evaluation to ~1e-13 in every
+    fused kernel that uses them (generate, delta_logp, local energy)."""
+    G = golden["g5_gsvmc"]
+    name = "z2_nt"
+    eta, mu = net_arrays(G, name + "_")
+    exact, tab = S.Net(eta, mu), S.Net(eta, mu, table=True)
+    assert tab.tab[3] == 0.0 and tab.tab[0] == 64.0          # grid 1/64 for these weights (max |w1| ~ 0.8)
+    x = G[name + "_x"][:10]
+    xe, _ = S.cnf_generate(x, exact, rtol=1e-9, atol=1e-11); xt, _ = S.cnf_generate(x, tab, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(xt, xe, atol=1e-12)
+    ze, de, _ = S.cnf_delta_logp(x, exact, rtol=1e-9, atol=1e-11); zt, dt, _ = S.cnf_delta_logp(x, tab, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(zt, ze, atol=1e-12); np.testing.assert_allclose(dt, de, atol=1e-12)
+    re = S.eloc(x, 3, 3, exact, 2.0, rtol=1e-9, atol=1e-11); rt = S.eloc(x, 3, 3, tab, 2.0, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(rt["eloc"], re["eloc"], rtol=1e-11)
+    np.testing.assert_allclose(rt["lap"], re["lap"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(rt["eloc"], G[name + "_Eloc"][:10], rtol=1e-8)
+    # stiff weights switch to a finer grid; absurdly stiff ones disable the table (flag) and results stay exact
+    stiff = (eta[0] * 10.0, eta[1], eta[2])
+    t2 = S.Net(stiff, mu, table=True)
+    assert t2.tab[3] == 0.0 and t2.tab[0] >= 128.0
+    xe2, _ = S.cnf_generate(x, S.Net(stiff, mu), rtol=1e-9, atol=1e-11); xt2, _ = S.cnf_generate(x, t2, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(xt2, xe2, atol=1e-11)
+    wild = (eta[0] * 1e4, eta[1], eta[2])
+    t3 = S.Net(wild, mu, table=True)
+    assert t3.tab[3] == 1.0
