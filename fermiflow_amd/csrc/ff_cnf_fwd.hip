@@ -18,6 +18,7 @@
 #include "ff_common.h"
 #include "ff_ode.h"
 #include "ff_slater.h"
+#define FF_RADIAL_BUILD_KERNELS
 #include "ff_radial.h"
 
 // FF_STAMPS: diagnostic build only (tools/kbench.py --stamps): per-phase s_memtime shares of the RHS loop,
@@ -48,8 +49,11 @@ struct ff_fwd_args {
   int32_t* stats;
 };
 
+#ifndef FF_FWD_WAVES_PER_SIMD
+#define FF_FWD_WAVES_PER_SIMD 1
+#endif
 template <int N, int D, int MODE>
-__global__ void __launch_bounds__(FF_WAVE)
+__global__ void __launch_bounds__(FF_WAVE, FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;

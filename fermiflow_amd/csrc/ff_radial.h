@@ -16,21 +16,48 @@
 #define FF_TAB_ROW 10                       // doubles per node (9 used; 80-byte rows keep 16-byte alignment)
 #define FF_TAB_MAXLOG 9                     // finest grid: h = 2^-9
 #define FF_TAB_NMAX (32 * (1 << FF_TAB_MAXLOG) + 1)
-#define FF_TAB_HDR 8                        // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used
+#define FF_TAB_HDR 8                        // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used,
+                                            // [4] 1.0 if the adjoint's deposit grid must not be used
 #define FF_TAB_DOUBLES (FF_TAB_HDR + 2 * FF_TAB_NMAX * FF_TAB_ROW)
 
 // sigma^(n)(a) as a polynomial in s = sigma(a): P_0 = s, P_{n+1} = P_n'(s) s (1 - s)
-__constant__ double FF_SIGPOLY[9][10] = {
-    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -1, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -3, 2, 0, 0, 0, 0, 0, 0},
-    {0, 1, -7, 12, -6, 0, 0, 0, 0, 0},
-    {0, 1, -15, 50, -60, 24, 0, 0, 0, 0},
-    {0, 1, -31, 180, -390, 360, -120, 0, 0, 0},
-    {0, 1, -63, 602, -2100, 3360, -2520, 720, 0, 0},
-    {0, 1, -127, 1932, -10206, 25200, -31920, 20160, -5040, 0},
-    {0, 1, -255, 6050, -46620, 166824, -317520, 332640, -181440, 40320}};
+__constant__ double FF_SIGPOLY[13][14] = {
+    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -7, 12, -6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -15, 50, -60, 24, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -31, 180, -390, 360, -120, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, -63, 602, -2100, 3360, -2520, 720, 0, 0, 0, 0, 0, 0},
+    {0, 1, -127, 1932, -10206, 25200, -31920, 20160, -5040, 0, 0, 0, 0, 0},
+    {0, 1, -255, 6050, -46620, 166824, -317520, 332640, -181440, 40320, 0, 0, 0, 0},
+    {0, 1, -511, 18660, -204630, 1020600, -2739240, 4233600, -3780000, 1814400, -362880, 0, 0, 0},
+    {0, 1, -1023, 57002, -874500, 5921520, -21538440, 46070640, -59875200, 46569600, -19958400, 3628800, 0, 0},
+    {0, 1, -2047, 173052, -3669006, 33105600, -158838240, 451725120, -801496080, 898128000, -618710400, 239500800, -39916800, 0},
+    {0, 1, -4095, 523250, -15195180, 180204024, -1118557440, 4115105280, -9574044480, 14495120640, -14270256000, 8821612800, -3113510400, 479001600}};
 
+// sigma^(0..NMAXD)(a) from s = sigma(a)
+template <int NMAXD>
+FF_D void ff_sigma_derivs(double s, double* out) {
+#pragma unroll
+  for (int n = 0; n <= NMAXD; n++) {
+    double p = FF_SIGPOLY[n][n + 1];
+#pragma unroll
+    for (int c = n; c >= 1; c--) p = fma(p, s, FF_SIGPOLY[n][c]);
+    out[n] = p * s;
+  }
+}
+
+// ---- "deposit" grid of the tabulated adjoint (ff_cnf_adj.hip): the parameter gradient of
+//   sum_records w [ca f(r) + cb f'(r)]  with  f(r) = sum_k T[j][k] dr^k/k!  is  sum_{j,k} Wacc[j][k] dT[j][k]/dtheta,
+// so the kernel only accumulates Wacc (coefficients ca dr^k/k! + cb dr^(k-1)/(k-1)!) on a coarse grid, h_d = 1/16,
+// expansion order 11, and one small kernel contracts Wacc with dT/dtheta at the end.  Usable while max|w1| h_d <= 0.6.
+#define FF_DEP_INVH 16.0
+#define FF_DEP_NLDS 128                     // nodes kept in LDS (r < 8); the rest (r < 32) goes to a global table
+#define FF_DEP_NTOT 512
+#define FF_DEP_ROW 12                       // T_0 .. T_11
+
+#ifdef FF_RADIAL_BUILD_KERNELS   // defined by the one translation unit that owns ff_radial_table_build
 // header: grid spacing from the stiffest first-layer weight (single workgroup)
 __global__ void __launch_bounds__(64) ff_table_header_kernel(ff_net net, double* __restrict__ tab) {
   __shared__ double sm[64];
@@ -49,6 +76,7 @@ __global__ void __launch_bounds__(64) ff_table_header_kernel(ff_net net, double*
     tab[1] = ldexp(1.0, -lg);
     tab[2] = (double)(32 * (1 << lg) + 1);
     tab[3] = bad ? 1.0 : 0.0;
+    tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.6) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
   }
 }
 
@@ -68,13 +96,11 @@ __global__ void __launch_bounds__(128) ff_table_build_kernel(ff_net net, double*
   for (int n = 0; n < 9; n++) acc[n] = 0.0;
   for (int h = 0; h < H; h++) {
     const double s = ff_sigmoid(fma(w1[h], r, b1[h]));
-    double wp = w2[h];
+    double sd[9], wp = w2[h];
+    ff_sigma_derivs<8>(s, sd);
 #pragma unroll
     for (int n = 0; n < 9; n++) {
-      double p = FF_SIGPOLY[n][n + 1];
-#pragma unroll
-      for (int c = n; c >= 1; c--) p = fma(p, s, FF_SIGPOLY[n][c]);
-      acc[n] = fma(wp, p * s, acc[n]);
+      acc[n] = fma(wp, sd[n], acc[n]);
       wp *= w1[h];
     }
   }
@@ -83,6 +109,8 @@ __global__ void __launch_bounds__(128) ff_table_build_kernel(ff_net net, double*
   for (int n = 0; n < 9; n++) row[n] = acc[n];
   row[9] = 0.0;
 }
+
+#endif  // FF_RADIAL_BUILD_KERNELS
 
 // NH derivative heads of net t (0 eta, 1 mu) at radius r from the table; returns false if r is off the table
 template <int NH>

@@ -114,3 +114,26 @@ def test_radial_table_matches_direct_evaluation(golden):
     wild = (eta[0] * 1e4, eta[1], eta[2])
     t3 = S.Net(wild, mu, table=True)
     assert t3.tab[3] == 1.0
+
+
+def test_tabulated_adjoint_matches_direct(golden):
+    """ff_ode_adjtab_kernel + deposit/contract kernels vs the direct adjoint kernel and the reference gradients."""
+    G = golden["g4_cnf"]
+    eta, mu = net_arrays(G, "")
+    exact, tab = S.Net(eta, mu), S.Net(eta, mu, table=True)
+    assert tab.tab[4] == 0.0
+    tag, rt, at = "tol10", 1e-10, 1e-12
+    gx_e, gp_e, st_e = S.cnf_adjoint(G[tag + "_zback"], G[tag + "_cz"], G[tag + "_cd"], exact, rtol=rt, atol=at)
+    gx_t, gp_t, st_t = S.cnf_adjoint(G[tag + "_zback"], G[tag + "_cz"], G[tag + "_cd"], tab, rtol=rt, atol=at)
+    np.testing.assert_allclose(gx_t, gx_e, atol=1e-11)
+    np.testing.assert_allclose(gp_t, gp_e, atol=1e-10 * np.abs(gp_e).max())
+    ref = cnf_param_grads(G, tag)
+    np.testing.assert_allclose(gp_t, ref, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(gx_t, G[tag + "_gx"], atol=1e-9)
+    # stiff weights: the deposit grid is refused on the device and the direct kernel serves the call
+    stiff = (eta[0] * 20.0, eta[1], eta[2])
+    t2 = S.Net(stiff, mu, table=True)
+    assert t2.tab[4] == 1.0 and t2.tab[3] == 0.0
+    _, gp_e2, _ = S.cnf_adjoint(G[tag + "_zback"][:5], G[tag + "_cz"][:5], G[tag + "_cd"][:5], S.Net(stiff, mu), rtol=1e-8, atol=1e-10)
+    _, gp_t2, _ = S.cnf_adjoint(G[tag + "_zback"][:5], G[tag + "_cz"][:5], G[tag + "_cd"][:5], t2, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gp_t2, gp_e2, atol=1e-9 * np.abs(gp_e2).max())
