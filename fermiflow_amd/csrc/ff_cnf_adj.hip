@@ -399,10 +399,10 @@ ff_rows_reduce_kernel(ff_net net, int nrows, int P, const double* __restrict__ r
   __shared__ double sm[256];
   const int k = blockIdx.x;
   double s = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += 256) s += rows[(int64_t)r * P + k];
+  for (int r = threadIdx.x; r < nrows; r += blockDim.x) s += rows[(int64_t)r * P + k];
   sm[threadIdx.x] = s;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
     __syncthreads();
   }
@@ -749,17 +749,26 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   }
 }
 
-// Wtot[t][j < NLDS][k] = sum over workgroups of their private tables (fixed order); j >= NLDS was added in place
-__global__ void __launch_bounds__(256)
+// Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
+// One workgroup per entry, lanes stride over the private tables, fixed-tree reduction (deterministic).
+__global__ void __launch_bounds__(128)
 ff_dep_reduce_kernel(ff_net net, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot) {
   const double* rtab = net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * FF_DEP_NLDS * FF_DEP_ROW) return;
+  __shared__ double sm[128];
+  const int e = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblocks; b++) s += rows[(size_t)b * 2 * FF_DEP_NLDS * FF_DEP_ROW + e];
-  const int t = e / (FF_DEP_NLDS * FF_DEP_ROW), rem = e - t * FF_DEP_NLDS * FF_DEP_ROW;
-  wtot[(size_t)t * FF_DEP_NTOT * FF_DEP_ROW + rem] = s;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += rows[(size_t)b * 2 * FF_DEP_NLDS * FF_DEP_ROW + e];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int t = e / (FF_DEP_NLDS * FF_DEP_ROW), rem = e - t * FF_DEP_NLDS * FF_DEP_ROW;
+    wtot[(size_t)t * FF_DEP_NTOT * FF_DEP_ROW + rem] = sm[0];
+  }
 }
 
 // grad[theta] = sum_{j,k} Wtot[t][j][k] dT[t][j][k]/dtheta,  T[j][k] = sum_h w2 w1^k sigma^(k)(w1 r_j + b1);
@@ -773,7 +782,7 @@ ff_dep_contract_kernel(ff_net net, const double* __restrict__ wtot, double* __re
   const int H = t ? net.Hm : net.He;
   const double w1 = (t ? net.mw1 : net.ew1)[hu], b1 = (t ? net.mb1 : net.eb1)[hu], w2 = (t ? net.mw2 : net.ew2)[hu];
   double gw1 = 0.0, gb1 = 0.0, gw2 = 0.0;
-  for (int j = threadIdx.x; j < FF_DEP_NTOT; j += 256) {
+  for (int j = threadIdx.x; j < FF_DEP_NTOT; j += blockDim.x) {
     const double rj = (double)j * (1.0 / FF_DEP_INVH);
     double sd[13];
     ff_sigma_derivs<12>(ff_sigmoid(fma(w1, rj, b1)), sd);
@@ -791,7 +800,7 @@ ff_dep_contract_kernel(ff_net net, const double* __restrict__ wtot, double* __re
   }
   sm[0][threadIdx.x] = gw1; sm[1][threadIdx.x] = gb1; sm[2][threadIdx.x] = gw2;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w)
       for (int c = 0; c < 3; c++) sm[c][threadIdx.x] += sm[c][threadIdx.x + w];
     __syncthreads();
@@ -872,13 +881,13 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   }
   FF_LAUNCH_CHECK();
   const int nblk = (int)adj_grid(B, G);
-  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, 256, stream, *net, nblk * G, P, (const double*)workspace, grad_params);
+  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, nblk * G, P, (const double*)workspace, grad_params);
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
     double* wtot = (double*)workspace + (size_t)nblk * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + 255) / 256), 256, stream, *net, nblk, (const double*)workspace, wtot);
+    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, nblk, (const double*)workspace, wtot);
     FF_LAUNCH_CHECK();
-    FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), 256, stream, *net, (const double*)wtot, grad_params);
+    FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)wtot, grad_params);
     FF_LAUNCH_CHECK();
   }
   return FF_OK;

@@ -34,6 +34,13 @@
 #define FF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// reduction kernels run with blockDim-generic trees; the host simulator uses tiny workgroups (thread creation cost)
+#ifdef FF_HOSTSIM
+#define FF_RBLOCK(n) 4
+#else
+#define FF_RBLOCK(n) (n)
+#endif
+
 #define FF_D __device__ __forceinline__
 #define FF_HD __host__ __device__ __forceinline__
 

@@ -17,7 +17,12 @@ class Backflow(torch.nn.Module):
         self.mu = mu
 
     def net(self, radial=None):
-        return L.Net(self.eta, self.mu, radial=radial)
+        """Device view of the weights (+ the radial table built for them); cached until a parameter changes, so the
+        three kernels of one iteration share one table."""
+        key = (radial or L.RADIAL_MODE,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_net_key", None) != key:
+            self._net_key, self._net = key, L.Net(self.eta, self.mu, radial=radial)
+        return self._net
 
     def forward(self, x):
         v, _ = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=True, need_div=False)
