@@ -311,3 +311,33 @@ def test_radial_table_equals_direct_evaluation_and_is_deterministic(golden, dev)
     assert rel < 1e-9, rel
     assert (gxt - gxe).abs().max().item() < 1e-9 * gxe.abs().max().item()
     assert (gpt - gpe).abs().max().item() < 1e-9 * gpe.abs().max().item()
+
+
+def test_config4_six_plus_six(golden, dev):
+    """BASELINE config 4 shape (nup = ndown = 6, n = 12): local energy and theta-gradient on the GPU vs the oracle
+    (no reference vectors at this size: a reference E_loc here costs minutes per walker)."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    G = golden["g5_gsvmc"]
+    model = Gm._model(dev, 6, 6, 2.0)
+    torch.manual_seed(21)
+    B = 512
+    g = model(B)
+    g.backward()
+    assert np.isfinite(model.E) and 0 < model.E_std < 60
+    net = O.Net(*net_arrays(G, "z2_nt_"))
+    xs = N(model.x[:6])
+    ref = O.eloc(xs, 6, 6, net, 2.0, rtol=1e-9, atol=1e-11)
+    rel = np.abs(N(model.Eloc[:6]) - ref["eloc"]) / np.abs(ref["eloc"])
+    assert rel.max() < ELOC_RTOL, rel.max()
+    # gradient of the surrogate on these 6 walkers: GPU adjoint vs oracle adjoint
+    v = model.cnf.v_wrapper.v
+    tu, td = model._tables(dev)
+    r = native.eloc(tu, td, 6, 6, v.net(), model.x[:6], 0.0, 1.0, 1e-6, 1e-8, 2.0, True)
+    w = (r["eloc"] - r["eloc"].mean()) / 6
+    _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8, need_gx=False)
+    zo, dlo, _ = O.cnf_delta_logp(xs, net, rtol=1e-9, atol=1e-11)
+    _, g0o, _ = O.logprob(zo, 6, 6)
+    wo = N(w)
+    _, gpo, _ = O.cnf_adjoint(zo, dlo, wo[:, None, None] * g0o, -wo, net, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
