@@ -65,10 +65,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 
   __shared__ ff_wtab s_w[2][FF_HPAD];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M];
-  __shared__ double s_rad[G][R], s_rinv[G][R], s_hd[G][R][NH];
+  __shared__ __attribute__((aligned(16))) double s_rr[G][R][2];   // radius and its reciprocal
+  __shared__ __attribute__((aligned(16))) double s_hd[G][R][NH];
   __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
   __shared__ int s_pa[R], s_pb[R], s_any;
   __shared__ double s_e2[64];
+  __shared__ double s_yv[MODE == 2 ? NV : 1][FF_WAVE], s_cv[MODE == 2 ? NV : 1][FF_WAVE];
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
@@ -97,7 +99,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
 #ifdef FF_STAMPS
-  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -108,7 +110,10 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     //   c0 = input of stage 4, c1 = partial input of stage 5, c2 = partial y_new, c3 = partial error.
     // k0 is therefore gone at the accept/reject decision: an accepted step takes k6 (FSAL), a rejected one
     // re-evaluates f(y) (stage 0; rejections are ~1 % of the wave-steps).
-    double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
+    // In the local-energy kernel y and c3 (touched a few times per step) live in lane-private LDS columns: that is
+    // what lets the remaining state fit VGPRs + AGPRs without scratch round trips in every evaluation.
+    ff_lane_vec<NV, (MODE == 2)> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
+    double c0[NV], c1[NV], c2[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
     y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
@@ -184,8 +189,8 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         double hd[NH];
         if (!(use_tab && ff_heads_table<NH>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd)))
           ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
-        s_rad[qg][p] = r;
-        s_rinv[qg][p] = ff_rcp(r);
+        s_rr[qg][p][0] = r;
+        s_rr[qg][p][1] = ff_rcp(r);
 #pragma unroll
         for (int m = 0; m < NH; m++) s_hd[qg][p][m] = hd[m];
       }
@@ -195,6 +200,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       // ------------------------------------------------------------------ right-hand side
       double in[NV], out[NV];
       form(in, 0, NV, 1);   // at stage 6 this is the candidate new state
+      FF_STAMP(6);
       const double* sz = s_z[gg];
       double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
       double vi = 0.0, dvk = 0.0, gdi = 0.0;
@@ -210,90 +216,78 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int k = 0; k < M; k++) { du[k] = 0.0; qv[k] = 0.0; }
         const double* u = &in[1];
-        const double* sk = s_kb[gg];
-        int p = 0;
+        // coordinates and kbar of the walker in registers; (r, 1/r, eta..eta''') of the radii stream through a
+        // two-deep register buffer: the LDS reads of chunk c+1 are issued before chunk c is computed, so the single
+        // resident wave does not sit out an LDS round trip per radius
+        double zr[M], kr[M];
 #pragma unroll
-        for (int a = 0; a < N; a++) {
+        for (int k = 0; k < M; k++) { zr[k] = sz[k]; kr[k] = s_kb[gg][k]; }
+        constexpr int CH = 4, RT = P + N, NCH = (RT + CH - 1) / CH;
+        constexpr ff_pair_table<N> PT{};
+        double hb[2][CH][6];
+        auto load_chunk = [&](int c, double (*buf)[6]) {
 #pragma unroll
-          for (int bq = a + 1; bq < N; bq++) {
-            double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
+          for (int q = 0; q < CH; q++) {
+            const int p = c * CH + q;
+            if (p < RT) {
+              buf[q][0] = s_rr[gg][p][0]; buf[q][1] = s_rr[gg][p][1];
 #pragma unroll
-            for (int c = 0; c < D; c++) {
-              rho[c] = sz[a * D + c] - sz[bq * D + c];
-              dl[c] = u[a * D + c] - u[bq * D + c];
-              dk[c] = sk[a * D + c] - sk[bq * D + c];
-              rd = fma(rho[c], dl[c], rd);
-              dd = fma(dl[c], dl[c], dd);
-              rdk = fma(rho[c], dk[c], rdk);
+              for (int m = 0; m < 4; m++) buf[q][2 + m] = s_hd[gg][p][m];
             }
-            const double r = s_rad[gg][p], ri = s_rinv[gg][p];
-            const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2], f3 = s_hd[gg][p][3];
-            const double r1 = rd * ri, r1s = r1 * r1;
-            const double r2q = (dd - r1s) * ri;
-            const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
-#pragma unroll
-            for (int c = 0; c < D; c++) {
-              const double g1 = fma(F1, rho[c], f0 * dl[c]);
-              const double g2 = fma(F2, rho[c], 2.0 * F1 * dl[c]);
-              du[a * D + c] += g1; du[bq * D + c] -= g1;
-              qv[a * D + c] += g2; qv[bq * D + c] -= g2;
-            }
-            const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
-            ddiv = fma(2.0 * sp, r1, ddiv);
-            qdiv += 2.0 * fma(spp, r1s, sp * r2q);
-            divv += 2.0 * fma(f1, r, D * f0);
-            // own coordinate: +term if this lane's particle is a, -term if it is bq
-            const double sgn = (ai == a) ? 1.0 : ((ai == bq) ? -1.0 : 0.0);
-            double rc = rho[0], dkc = dk[0];
-#pragma unroll
-            for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
-            const double F1k = f1 * (rdk * ri);
-            vi = fma(sgn * f0, rc, vi);
-            dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
-            gdi = fma(sgn * 2.0 * sp * ri, rc, gdi);
-            p++;
-            if ((p & 3) == 0) FF_SCHED_FENCE();
           }
-        }
-        if (has_mu) {
+        };
+        load_chunk(0, hb[0]);
 #pragma unroll
-          for (int a = 0; a < N; a++) {
-            double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
+        for (int c = 0; c < NCH; c++) {
+          if (c + 1 < NCH) load_chunk(c + 1, hb[(c + 1) & 1]);
 #pragma unroll
-            for (int c = 0; c < D; c++) {
-              rho[c] = sz[a * D + c];
-              dl[c] = u[a * D + c];
-              dk[c] = sk[a * D + c];
-              rd = fma(rho[c], dl[c], rd);
-              dd = fma(dl[c], dl[c], dd);
-              rdk = fma(rho[c], dk[c], rdk);
+          for (int q = 0; q < CH; q++) {
+            const int p = c * CH + q;
+            if (p < RT && (p < P || has_mu)) {
+              const bool pair = p < P;
+              const int a = pair ? PT.a[p < P ? p : 0] : p - P, bq = pair ? PT.b[p < P ? p : 0] : 0;
+              const double cf = pair ? 2.0 : 1.0;
+              double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
+#pragma unroll
+              for (int cc = 0; cc < D; cc++) {
+                rho[cc] = pair ? zr[a * D + cc] - zr[bq * D + cc] : zr[a * D + cc];
+                dl[cc] = pair ? u[a * D + cc] - u[bq * D + cc] : u[a * D + cc];
+                dk[cc] = pair ? kr[a * D + cc] - kr[bq * D + cc] : kr[a * D + cc];
+                rd = fma(rho[cc], dl[cc], rd);
+                dd = fma(dl[cc], dl[cc], dd);
+                rdk = fma(rho[cc], dk[cc], rdk);
+              }
+              const double* hq = hb[c & 1][q];
+              const double r = hq[0], ri = hq[1], f0 = hq[2], f1 = hq[3], f2 = hq[4], f3 = hq[5];
+              const double r1 = rd * ri, r1s = r1 * r1;
+              const double r2q = (dd - r1s) * ri;
+              const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+#pragma unroll
+              for (int cc = 0; cc < D; cc++) {
+                const double g1 = fma(F1, rho[cc], f0 * dl[cc]);
+                const double g2 = fma(F2, rho[cc], 2.0 * F1 * dl[cc]);
+                du[a * D + cc] += g1;
+                qv[a * D + cc] += g2;
+                if (pair) { du[bq * D + cc] -= g1; qv[bq * D + cc] -= g2; }
+              }
+              const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
+              ddiv = fma(cf * sp, r1, ddiv);
+              qdiv += cf * fma(spp, r1s, sp * r2q);
+              divv += cf * fma(f1, r, D * f0);
+              // own coordinate (ai, ci): +term if this lane's particle is a, -term if it is the partner
+              const double sgn = (ai == a) ? 1.0 : ((pair && ai == bq) ? -1.0 : 0.0);
+              double rc = rho[0], dkc = dk[0];
+#pragma unroll
+              for (int cc = 1; cc < D; cc++) { rc = (ci == cc) ? rho[cc] : rc; dkc = (ci == cc) ? dk[cc] : dkc; }
+              const double F1k = f1 * (rdk * ri);
+              vi = fma(sgn * f0, rc, vi);
+              dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
+              gdi = fma(sgn * cf * sp * ri, rc, gdi);
             }
-            const int pp = P + a;
-            const double r = s_rad[gg][pp], ri = s_rinv[gg][pp];
-            const double f0 = s_hd[gg][pp][0], f1 = s_hd[gg][pp][1], f2 = s_hd[gg][pp][2], f3 = s_hd[gg][pp][3];
-            const double r1 = rd * ri, r1s = r1 * r1;
-            const double r2q = (dd - r1s) * ri;
-            const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
-#pragma unroll
-            for (int c = 0; c < D; c++) {
-              du[a * D + c] += fma(F1, rho[c], f0 * dl[c]);
-              qv[a * D + c] += fma(F2, rho[c], 2.0 * F1 * dl[c]);
-            }
-            const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
-            ddiv = fma(sp, r1, ddiv);
-            qdiv += fma(spp, r1s, sp * r2q);
-            divv += fma(f1, r, D * f0);
-            const double sgn = (ai == a) ? 1.0 : 0.0;
-            double rc = rho[0], dkc = dk[0];
-#pragma unroll
-            for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
-            const double F1k = f1 * (rdk * ri);
-            vi = fma(sgn * f0, rc, vi);
-            dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
-            gdi = fma(sgn * sp * ri, rc, gdi);
-            if ((a & 3) == 3) FF_SCHED_FENCE();
           }
+          FF_SCHED_FENCE();
         }
+        FF_STAMP(7);
 #pragma unroll
         for (int k = 0; k < M; k++) out[1 + k] = du[k];
         // transpose-reduce the quadratic sources: lane c needs sum_j qv_j[c]
@@ -309,7 +303,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         if constexpr (MODE == 1) {
           for (int p = 0; p < nrad; p++) {
             const double c = p < P ? 2.0 : 1.0;
-            divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rad[gg][p], D * s_hd[gg][p][0]), divv);
+            divv = fma(c, fma(s_hd[gg][p][NH > 1 ? 1 : 0], s_rr[gg][p][0], D * s_hd[gg][p][0]), divv);
           }
         }
         // component phase (generate / delta_logp): coordinate (ai, ci) of v
@@ -444,7 +438,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   }
 #ifdef FF_STAMPS
   if (A.stats && lane == 0)
-    for (int q = 0; q < 6; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+    for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
 #endif
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);

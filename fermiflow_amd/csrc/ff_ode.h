@@ -22,6 +22,36 @@ struct ff_geom {
   static constexpr int RA = R > 0 ? R : 1;
 };
 
+// A per-lane vector of NV doubles that lives either in registers or in a lane-private LDS column (slot-major
+// [NV][64] layout: conflict-free).  Indexing syntax is the same, so the integrator code does not care.
+template <int NV, bool IN_LDS>
+struct ff_lane_vec;
+template <int NV>
+struct ff_lane_vec<NV, false> {
+  double r[NV];
+  FF_D ff_lane_vec(double*, int) {}
+  FF_D double& operator[](int v) { return r[v]; }
+  FF_D const double& operator[](int v) const { return r[v]; }
+};
+template <int NV>
+struct ff_lane_vec<NV, true> {
+  double* col;
+  FF_D ff_lane_vec(double* base, int lane) : col(base + lane) {}
+  FF_D double& operator[](int v) { return col[v * FF_WAVE]; }
+  FF_D const double& operator[](int v) const { return col[v * FF_WAVE]; }
+};
+
+// (a, b) of the p-th pair in the order a < b, a-major: compile-time table for statically unrolled sweeps
+template <int N>
+struct ff_pair_table {
+  int a[N * (N - 1) / 2 + 1], b[N * (N - 1) / 2 + 1];
+  constexpr ff_pair_table() : a(), b() {
+    int p = 0;
+    for (int i = 0; i < N; i++)
+      for (int j = i + 1; j < N; j++) { a[p] = i; b[p] = j; p++; }
+  }
+};
+
 // per-hidden-unit weight record staged in LDS (48 B, 16-B aligned -> three ds_read_b128)
 struct __attribute__((aligned(16))) ff_wtab { double w1, b1, w2, w2w1, w2w1_2, w2w1_3; };
 

@@ -94,11 +94,26 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
   }
   double logp = ff_logprob_value<NU, ND>(nup, ndn, ou, od, x, md);
   int nacc = 0;
-  for (int s = 0; s < steps; s++) {
-    if (NOISE) {
-      const double* gs = g + ((int64_t)s * B + b) * M;
+  // parity mode: the noise of step s+1 is requested from HBM before step s is computed (one step of software
+  // pipelining: a walker's chain is serial, so without it every step would expose a full HBM round trip)
+  double gq[MAXM], uq = 0.0;
+  if (NOISE && steps > 0) {
 #pragma unroll
-      for (int i = 0; i < MAXM; i++) if (i < M) nx[i] = ff_add_rn(x[i], ff_mul_rn(tau, gs[i]));
+    for (int i = 0; i < MAXM; i++) if (i < M) gq[i] = g[b * M + i];
+    uq = u[b];
+  }
+  for (int s = 0; s < steps; s++) {
+    double ucur = 0.0;
+    if (NOISE) {
+#pragma unroll
+      for (int i = 0; i < MAXM; i++) if (i < M) nx[i] = ff_add_rn(x[i], ff_mul_rn(tau, gq[i]));
+      ucur = uq;
+      if (s + 1 < steps) {
+        const double* gs = g + ((int64_t)(s + 1) * B + b) * M;
+#pragma unroll
+        for (int i = 0; i < MAXM; i++) if (i < M) gq[i] = gs[i];
+        uq = u[(int64_t)(s + 1) * B + b];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < MAXM / 2; j++)
@@ -111,7 +126,7 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
     }
     double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx, md);
     double p = exp(nl - logp);
-    double uu = NOISE ? u[(int64_t)s * B + b] : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
+    double uu = NOISE ? ucur : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
     bool acc = uu < p;  // NaN p -> reject, +inf p -> accept (IEEE), as torch
     if (acc) {
 #pragma unroll

@@ -52,9 +52,9 @@ w = (r["eloc"] - r["eloc"].mean()) / a.B
 res["adjoint_ms"], (_, gp, st) = timeit(lambda: native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
                                                                    need_gx=False, want_stats=True))
 res["adjoint_evals"] = st[0].item() / a.B
-st8 = r["stats"][8:20].view(torch.int64)[:6].double()
+st8 = r["stats"][8:26].view(torch.int64)[:9].double()
 if st8.sum() > 0:
-    res["stamps_pct"] = [round(v, 1) for v in (100 * st8 / st8.sum()).tolist()]   # input, publish, radius, jets, component, consume
+    res["stamps_pct"] = [round(v, 1) for v in (100 * st8 / st8.sum()).tolist()]   # 0 coef, 1 publish, 2 radius, 3 transpose(after sweep), 4 -, 5 consume, 6 form in[], 7 sweep
 res["E"] = r["eloc"].mean().item()
 res["gp_norm"] = gp.norm().item()
 print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))
