@@ -19,7 +19,12 @@ def world():
 
 def all_reduce_sum_(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and dist.get_backend() == "gloo":      # test set-up: several ranks sharing one GPU over gloo
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 

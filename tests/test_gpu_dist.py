@@ -1,0 +1,52 @@
+"""Walker data parallelism on the GPU: two ranks (sharing the one GPU of the test box, gloo for the tiny all-reduces;
+production uses nccl = RCCL, one GPU per rank) must reproduce the single-process iteration on the same global batch:
+identical walkers (Philox counters are global walker indices), same E / E_std, same parameter gradient."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(rank, world, port, B, out):
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    model = G._model(dev, 3, 3, 2.0)
+    torch.manual_seed(123)
+    g = model(B)
+    g.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    out[rank] = (model.E, model.E_std, g.item(), grads, model.x[:4].cpu().numpy(), model.x.shape[0])
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank():
+    B = 4096
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, B, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), B, two), nprocs=2, join=True)
+    E, Es, g, grads, x0, n = one[0]
+    assert n == B
+    for r in (0, 1):
+        E2, Es2, g2, grads2, x02, n2 = two[r]
+        assert n2 == B // 2
+        assert abs(E2 - E) < 1e-12 * abs(E) and abs(Es2 - Es) < 1e-11 * Es
+        assert abs(g2 - g) < 1e-10 * max(1.0, abs(g))
+        np.testing.assert_allclose(grads2, grads, rtol=0, atol=1e-10 * np.abs(grads).max())
+    assert (two[0][4] == x0).all()          # rank 0's first walkers are the global first walkers, bit for bit
