@@ -221,5 +221,58 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
   FF_SCHED_FENCE();
 }
 
+// --- log(x) for the Metropolis kernel (Box-Muller radius, log|det|): exponent split + atanh series
+//     log m = 2 s (1 + z/3 + ... + z^10/21), s = (m-1)/(m+1), z = s^2, m in [sqrt(1/2), sqrt(2)); ~1 ulp.
+//     Zero, denormal, negative and non-finite arguments take the library routine.
+FF_D double ff_log(double x) {
+  if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
+  int hi = __double2hiint(x);
+  int e = (hi >> 20) - 1023;
+  double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(x));   // [1, 2)
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  const double s = (m - 1.0) * ff_rcp(m + 1.0), z = s * s;
+  double p = 1.0 / 21.0;
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  p = fma(p, z, 1.0);
+  const double ef = (double)e;
+  return fma(ef, 6.93147180369123816490e-01, fma(2.0 * s, p, ef * 1.90821492927058770002e-10));
+}
+
+// --- sin(pi t), cos(pi t) for t in [0, 2): quadrant split + Taylor on |pi r| <= pi/4
+FF_D void ff_sincospi(double t, double* sn, double* cs) {
+  const double q = rint(t * 2.0);            // nearest multiple of 1/2
+  const double r = fma(q, -0.5, t) * 3.14159265358979323846;
+  const double r2 = r * r;
+  double ps = -1.0 / 1307674368000.0;        // -1/15!
+  ps = fma(ps, r2, 1.0 / 6227020800.0);
+  ps = fma(ps, r2, -1.0 / 39916800.0);
+  ps = fma(ps, r2, 1.0 / 362880.0);
+  ps = fma(ps, r2, -1.0 / 5040.0);
+  ps = fma(ps, r2, 1.0 / 120.0);
+  ps = fma(ps, r2, -1.0 / 6.0);
+  ps = fma(ps * r2, r, r);
+  double pc = 1.0 / 20922789888000.0;        // 1/16!
+  pc = fma(pc, r2, -1.0 / 87178291200.0);
+  pc = fma(pc, r2, 1.0 / 479001600.0);
+  pc = fma(pc, r2, -1.0 / 3628800.0);
+  pc = fma(pc, r2, 1.0 / 40320.0);
+  pc = fma(pc, r2, -1.0 / 720.0);
+  pc = fma(pc, r2, 1.0 / 24.0);
+  pc = fma(pc, r2, -0.5);
+  pc = fma(pc, r2, 1.0);
+  const int k = ((int)q) & 3;                // angle = k*pi/2 + pi r
+  const double s0 = (k & 1) ? pc : ps, c0 = (k & 1) ? ps : pc;
+  *sn = (k & 2) ? -s0 : s0;
+  *cs = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // number of (i<j) pairs before row i for n particles; pair index of (i,j), i<j
 FF_HD int ff_pair_index(int n, int i, int j) { return i * (2 * n - i - 1) / 2 + (j - i - 1); }

@@ -29,9 +29,9 @@ FF_D void ff_normal_pair(uint64_t key, uint64_t walker, uint32_t step, uint32_t 
   ff_u4 r = ff_philox(key, walker, step, slot);
   double u1 = (double)(ff_bits53(r.x, r.y) + 1) * 1.1102230246251565e-16;  // (0,1]
   double u2 = (double)ff_bits53(r.z, r.w) * 1.1102230246251565e-16;        // [0,1)
-  double rad = sqrt(-2.0 * log(u1));
+  double rad = sqrt(-2.0 * ff_log(u1));
   double s, c;
-  sincospi(2.0 * u2, &s, &c);
+  ff_sincospi(2.0 * u2, &s, &c);
   z0 = rad * c;
   z1 = rad * s;
 }

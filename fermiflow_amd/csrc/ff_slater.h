@@ -66,6 +66,8 @@ FF_D void ff_orbital(int k, double x, double y, double gauss /* pi^-1/2 exp(-r^2
 }
 
 FF_D double ff_gauss2d(double x, double y) { return FF_PI_SQRT_INV * exp(-0.5 * (x * x + y * y)); }
+// same, with the in-house exp (argument clamped: exp(-708) is already a denormal-free 3e-308)
+FF_D double ff_gauss2d_fast(double x, double y) { return FF_PI_SQRT_INV * ff_exp(fmax(-0.5 * (x * x + y * y), -708.0)); }
 
 // --------------------------------------------------------------------------------------------------
 // Register-resident log|det| for compile-time NS (MCMC hot loop).  The normalised Hermite function of degree n
@@ -99,11 +101,11 @@ FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* 
   double D[NS][NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) {
-    double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
+    double gs = ff_gauss2d_fast(x[2 * i], x[2 * i + 1]);
 #pragma unroll
     for (int j = 0; j < NS; j++) D[i][j] = gs * ff_herm_rec(nx[j], x[2 * i], md) * ff_herm_rec(ny[j], x[2 * i + 1], md);
   }
-  double acc = 0.0;
+  double prod = 1.0;   // |det| as the product of the pivots: one log per determinant (NS <= 6: no over/underflow)
 #pragma unroll
   for (int c = 0; c < NS; c++) {
     int p = c;
@@ -124,7 +126,7 @@ FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* 
       }
     }
     double piv = D[c][c];
-    acc += log(fabs(piv));
+    prod *= fabs(piv);
     double ip = 1.0 / piv;
 #pragma unroll
     for (int r = c + 1; r < NS; r++) {
@@ -133,7 +135,7 @@ FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* 
       for (int j = c + 1; j < NS; j++) D[r][j] = fma(-f, D[c][j], D[r][j]);
     }
   }
-  return acc;
+  return ff_log(prod);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -125,7 +125,11 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
         }
     }
     double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx, md);
-    double p = exp(nl - logp);
+    // p = exp(new_logp - logp) with torch's edge semantics: NaN stays NaN (rejects), -inf gives exactly 0
+    const double dlp = nl - logp;
+    double p = exp(0.0);
+    if constexpr (FIXED) p = !(dlp == dlp) ? dlp : (dlp < -708.0 ? 0.0 : ff_exp(fmin(dlp, 708.0)));
+    else p = exp(dlp);
     double uu = NOISE ? ucur : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
     bool acc = uu < p;  // NaN p -> reject, +inf p -> accept (IEEE), as torch
     if (acc) {
