@@ -26,7 +26,9 @@ struct ff_adj_args {
   const double* az_in;  // (B, M)  incoming gradient wrt z(t0)
   const double* ad_in;  // (B)     incoming gradient wrt Delta
   double* gx_out;       // (B, M)  gradient wrt x = z(t1); may be NULL
-  double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials
+  double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials (direct kernel)
+  double* trows;        // (gridDim.x, 2, FF_DEP_NLDS, FF_DEP_ROW) private coefficient tables, then Wtot (tabulated kernel)
+  double* off_table;    // one double, zeroed per call: set to 1 when a radius falls off the deposit table
   int32_t* stats;
 };
 
@@ -37,9 +39,10 @@ ff_ode_adj_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
   constexpr int NV = 2;
-  {  // a usable radial table means the tabulated kernel (ff_ode_adjtab_kernel) serves this call
+  {  // a usable radial table means the tabulated kernel (ff_ode_adjtab_kernel) served this call -- unless it met a
+     // radius beyond the table and raised off_table, in which case this kernel redoes the call by direct evaluation
     const double* rt = A.net.radial_table;
-    if (rt && rt[3] == 0.0 && rt[4] == 0.0) return;
+    if (rt && rt[3] == 0.0 && rt[4] == 0.0 && *A.off_table == 0.0) return;
   }
 
   __shared__ ff_wtab s_w[2][FF_HPAD];
@@ -391,10 +394,11 @@ ff_ode_adj_kernel(ff_adj_args A) {
 
 // out[k] = sum over rows of rows[r][k]: one workgroup per parameter, fixed tree (deterministic)
 __global__ void __launch_bounds__(256)
-ff_rows_reduce_kernel(ff_net net, int nrows, int P, const double* __restrict__ rows, double* __restrict__ out) {
+ff_rows_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows, int P, const double* __restrict__ rows,
+                      double* __restrict__ out) {
   {
     const double* rt = net.radial_table;
-    if (rt && rt[3] == 0.0 && rt[4] == 0.0) return;
+    if (rt && rt[3] == 0.0 && rt[4] == 0.0 && *off_table == 0.0) return;
   }
   __shared__ double sm[256];
   const int k = blockIdx.x;
@@ -474,7 +478,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const int64_t ngroups = (A.B + G - 1) / G;
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
-  double* const ovf = A.rows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
+  double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b = grp * G + g;
@@ -570,6 +574,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           s_hd[qg][p][0] = hd[0]; s_hd[qg][p][1] = hd[1]; s_hd[qg][p][2] = hd[2];
           // parameter integrand  ca * df(r)/dtheta + cb * df'(r)/dtheta, deposited about node jd of the coarse grid
           double jf = rint(r * FF_DEP_INVH);
+          if (!(jf <= (double)(FF_DEP_NTOT - 1)) && (grp * G + qg) < A.B) *A.off_table = 1.0;   // beyond the table (or NaN): direct kernel redoes the call
           jf = fmin(jf, (double)(FF_DEP_NTOT - 1));
           cur[sl].j = (r == r) ? (int)jf : 0;
           cur[sl].dr = fma(-jf, 1.0 / FF_DEP_INVH, r);
@@ -738,7 +743,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   }
   // flush the workgroup-private coefficient table
   {
-    double* row = A.rows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
+    double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[e];
   }
   if (A.stats && (ev_sum || fail_any)) {
@@ -752,9 +757,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
 // Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
 // One workgroup per entry, lanes stride over the private tables, fixed-tree reduction (deterministic).
 __global__ void __launch_bounds__(128)
-ff_dep_reduce_kernel(ff_net net, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot) {
+ff_dep_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nblocks, const double* __restrict__ rows,
+                     double* __restrict__ wtot) {
   const double* rtab = net.radial_table;
-  if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;
+  if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0)) return;
   __shared__ double sm[128];
   const int e = blockIdx.x;
   double s = 0.0;
@@ -774,9 +780,9 @@ ff_dep_reduce_kernel(ff_net net, int nblocks, const double* __restrict__ rows, d
 // grad[theta] = sum_{j,k} Wtot[t][j][k] dT[t][j][k]/dtheta,  T[j][k] = sum_h w2 w1^k sigma^(k)(w1 r_j + b1);
 // one workgroup per hidden unit, lanes over the nodes, fixed-tree reduction
 __global__ void __launch_bounds__(256)
-ff_dep_contract_kernel(ff_net net, const double* __restrict__ wtot, double* __restrict__ grad) {
+ff_dep_contract_kernel(ff_net net, const double* __restrict__ off_table, const double* __restrict__ wtot, double* __restrict__ grad) {
   const double* rtab = net.radial_table;
-  if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;
+  if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0)) return;
   __shared__ double sm[3][256];
   const int t = blockIdx.x < (unsigned)net.He ? 0 : 1, hu = t ? blockIdx.x - net.He : blockIdx.x;
   const int H = t ? net.Hm : net.He;
@@ -843,11 +849,13 @@ static size_t adj_table_doubles(int64_t B, int G) {
   return (size_t)adj_grid(B, G) * 2 * FF_DEP_NLDS * FF_DEP_ROW + (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW;
 }
 
+// workspace = [direct rows | private tables + Wtot | off-table flag]
+static size_t adj_direct_doubles(int64_t B, int G, int He, int Hm) { return (size_t)adj_grid(B, G) * G * (size_t)(3 * He + 3 * Hm); }
+
 size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
   int G = adj_G(n, d);
   if (G == 0 || B <= 0) return 0;
-  size_t direct = (size_t)adj_grid(B, G) * G * (size_t)(3 * He + 3 * Hm), table = adj_table_doubles(B, G);
-  return sizeof(double) * (direct > table ? direct : table);
+  return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, G) + 1);
 }
 
 int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
@@ -868,6 +876,12 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  {
+    const int Gq = adj_G(n, d);
+    if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
+    a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
+    a.off_table = a.trows + adj_table_doubles(B, Gq);
+  }
   if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
   // both variants are enqueued; on the device exactly one of them runs, chosen by the radial-table header
@@ -881,13 +895,15 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   }
   FF_LAUNCH_CHECK();
   const int nblk = (int)adj_grid(B, G);
-  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, nblk * G, P, (const double*)workspace, grad_params);
+  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk * G, P, (const double*)a.rows, grad_params);
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
-    double* wtot = (double*)workspace + (size_t)nblk * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, nblk, (const double*)workspace, wtot);
+    double* wtot = a.trows + (size_t)nblk * 2 * FF_DEP_NLDS * FF_DEP_ROW;
+    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, (const double*)a.off_table, nblk,
+              (const double*)a.trows, wtot);
     FF_LAUNCH_CHECK();
-    FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)wtot, grad_params);
+    FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)a.off_table,
+              (const double*)wtot, grad_params);
     FF_LAUNCH_CHECK();
   }
   return FF_OK;

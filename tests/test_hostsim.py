@@ -137,3 +137,21 @@ def test_tabulated_adjoint_matches_direct(golden):
     _, gp_e2, _ = S.cnf_adjoint(G[tag + "_zback"][:5], G[tag + "_cz"][:5], G[tag + "_cd"][:5], S.Net(stiff, mu), rtol=1e-8, atol=1e-10)
     _, gp_t2, _ = S.cnf_adjoint(G[tag + "_zback"][:5], G[tag + "_cz"][:5], G[tag + "_cd"][:5], t2, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(gp_t2, gp_e2, atol=1e-9 * np.abs(gp_e2).max())
+
+
+def test_radii_beyond_the_table_fall_back_to_direct_evaluation(golden):
+    """walkers spread over +-60 (pair distances far beyond FF_TAB_RMAX = 32): the forward kernels evaluate those radii
+    directly, the tabulated adjoint raises its off-table flag and the direct adjoint kernel redoes the call."""
+    G = golden["g4_cnf"]
+    eta, mu = net_arrays(G, "")
+    exact, tab = S.Net(eta, mu), S.Net(eta, mu, table=True)
+    rng = np.random.RandomState(5)
+    z = rng.randn(7, 6, 2) * 25.0
+    cz, cd = rng.randn(7, 6, 2), rng.randn(7)
+    assert np.sqrt(((z[:, :, None] - z[:, None]) ** 2).sum(-1)).max() > 40
+    xe, _ = S.cnf_generate(z, exact, rtol=1e-9, atol=1e-11); xt, _ = S.cnf_generate(z, tab, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(xt, xe, rtol=1e-12, atol=1e-11)
+    gx_e, gp_e, _ = S.cnf_adjoint(z, cz, cd, exact, rtol=1e-9, atol=1e-11)
+    gx_t, gp_t, _ = S.cnf_adjoint(z, cz, cd, tab, rtol=1e-9, atol=1e-11)
+    np.testing.assert_array_equal(gp_t, gp_e)        # same kernel served both calls
+    np.testing.assert_array_equal(gx_t, gx_e)
