@@ -545,9 +545,9 @@ static void launch_fwd(void* stream, const ff_fwd_args& a) {
 template <int MODE>
 static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a) {
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
-  FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2)
+  FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
 #undef FF_ND
-  ff_set_error("fused CNF kernels are instantiated for (n,d) in {(2,2),(3,2),(4,2),(6,2),(12,2)}");
+  ff_set_error("fused CNF kernels are instantiated for (n,d) in {2,3,4,5,6,8,10,12} x {2}");
   return FF_EUNSUPPORTED;
 }
 

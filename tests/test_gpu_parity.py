@@ -341,3 +341,31 @@ def test_config4_six_plus_six(golden, dev):
     wo = N(w)
     _, gpo, _ = O.cnf_adjoint(zo, dlo, wo[:, None, None] * g0o, -wo, net, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
+
+
+@pytest.mark.parametrize("nup,ndn", [(2, 0), (2, 2), (5, 0), (4, 4), (10, 0)])
+def test_other_particle_numbers_vs_oracle(golden, dev, nup, ndn):
+    """every fused-kernel instantiation (n in {2,3,4,5,6,8,10,12}): flow, local energy and adjoint vs the oracle."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    G = golden["g5_gsvmc"]
+    n = nup + ndn
+    model = Gm._model(dev, nup, ndn, 1.0)
+    net = O.Net(*net_arrays(G, "z2_nt_"))
+    torch.manual_seed(100 + n)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (6,))
+    v = model.cnf.v_wrapper.v
+    x = native.cnf_generate(v.net(), z, 0.0, 1.0, 1e-8, 1e-10)
+    xo, _ = O.cnf_generate(N(z), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(x), xo, atol=1e-7)
+    r = model.local_energy(x, want_stats=True)
+    assert int(r["stats"][3]) == 0
+    ref = O.eloc(N(x), nup, ndn, net, 1.0, rtol=1e-9, atol=1e-11)
+    assert (np.abs(N(r["eloc"]) - ref["eloc"]) / np.abs(ref["eloc"])).max() < ELOC_RTOL
+    np.testing.assert_allclose(N(r["grad"]), ref["grad"], atol=2e-5 * max(1.0, np.abs(ref["grad"]).max()))
+    w = (r["eloc"] - r["eloc"].mean()) / 6
+    _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-8, 1e-10, need_gx=False)
+    zo, dlo, _ = O.cnf_delta_logp(N(x), net, rtol=1e-10, atol=1e-12)
+    _, g0o, _ = O.logprob(zo, nup, ndn)
+    _, gpo, _ = O.cnf_adjoint(zo, dlo, N(w)[:, None, None] * g0o, -N(w), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
