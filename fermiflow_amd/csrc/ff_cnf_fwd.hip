@@ -70,7 +70,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
   __shared__ int s_pa[R], s_pb[R], s_any;
   __shared__ double s_e2[64];
-  __shared__ double s_yv[MODE == 2 ? NV : 1][FF_WAVE], s_cv[MODE == 2 ? NV : 1][FF_WAVE];
+  // lane-private LDS columns for y and the error accumulator: only while 4 workgroups still fit a CU's LDS
+  constexpr bool LDS_STATE = (MODE == 2 && M <= 12);
+  __shared__ double s_yv[LDS_STATE ? NV : 1][FF_WAVE], s_cv[LDS_STATE ? NV : 1][FF_WAVE];
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
@@ -112,7 +114,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     // re-evaluates f(y) (stage 0; rejections are ~1 % of the wave-steps).
     // In the local-energy kernel y and c3 (touched a few times per step) live in lane-private LDS columns: that is
     // what lets the remaining state fit VGPRs + AGPRs without scratch round trips in every evaluation.
-    ff_lane_vec<NV, (MODE == 2)> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
+    ff_lane_vec<NV, LDS_STATE> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
     double c0[NV], c1[NV], c2[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
@@ -219,10 +221,17 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         // coordinates and kbar of the walker in registers; (r, 1/r, eta..eta''') of the radii stream through a
         // two-deep register buffer: the LDS reads of chunk c+1 are issued before chunk c is computed, so the single
         // resident wave does not sit out an LDS round trip per radius
-        double zr[M], kr[M];
+        // (for M > 12 the coordinates stay in LDS: 2*M more live doubles would push the kernel into scratch)
+        constexpr bool ZK_REG = (M <= 12);
+        double zr_[ZK_REG ? M : 1], kr_[ZK_REG ? M : 1];
+        if constexpr (ZK_REG) {
 #pragma unroll
-        for (int k = 0; k < M; k++) { zr[k] = sz[k]; kr[k] = s_kb[gg][k]; }
-        constexpr int CH = 4, RT = P + N, NCH = (RT + CH - 1) / CH;
+          for (int k = 0; k < M; k++) { zr_[k] = sz[k]; kr_[k] = s_kb[gg][k]; }
+        }
+        const double* zr = ZK_REG ? zr_ : sz;
+        const double* kr = ZK_REG ? kr_ : s_kb[gg];
+        constexpr bool PREF = (M <= 12);   // look-ahead only where the registers are there for it
+        constexpr int CH = PREF ? 4 : 2, RT = P + N, NCH = (RT + CH - 1) / CH;
         constexpr ff_pair_table<N> PT{};
         double hb[2][CH][6];
         auto load_chunk = [&](int c, double (*buf)[6]) {
@@ -236,10 +245,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
             }
           }
         };
-        load_chunk(0, hb[0]);
+        if constexpr (PREF) load_chunk(0, hb[0]);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-          if (c + 1 < NCH) load_chunk(c + 1, hb[(c + 1) & 1]);
+          if constexpr (PREF) { if (c + 1 < NCH) load_chunk(c + 1, hb[(c + 1) & 1]); }
+          else load_chunk(c, hb[0]);
 #pragma unroll
           for (int q = 0; q < CH; q++) {
             const int p = c * CH + q;
@@ -257,7 +267,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
                 dd = fma(dl[cc], dl[cc], dd);
                 rdk = fma(rho[cc], dk[cc], rdk);
               }
-              const double* hq = hb[c & 1][q];
+              const double* hq = hb[PREF ? (c & 1) : 0][q];
               const double r = hq[0], ri = hq[1], f0 = hq[2], f1 = hq[3], f2 = hq[4], f3 = hq[5];
               const double r1 = rd * ri, r1s = r1 * r1;
               const double r2q = (dd - r1s) * ri;
