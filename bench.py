@@ -68,7 +68,7 @@ def main():
     model = G._model(dev, args.nup, args.ndown, args.Z)
     opt = torch.optim.Adam(model.parameters(), lr=args.lr)
     B_glob = args.walkers_per_gpu * n_gpus
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)      # same Philox key on every rank; streams are separated by the global walker index
 
     def step():
         gradE = model(B_glob)
