@@ -146,11 +146,18 @@ class BetaVMC(torch.nn.Module):
         self.sp_potential = sp_potential
 
     def sample(self, sample_shape, nframes=None):
+        """Draw the many-body state of every walker of the GLOBAL batch (CPU generator, so every rank draws the same
+        list), sort by state as the reference does (src/VMC.py:94-96) and keep this rank's contiguous shard."""
         from torch.distributions.categorical import Categorical
         self.state_dist = Categorical(logits=self.log_state_weights)
-        state_indices = self.state_dist.sample(sample_shape)
-        self.state_indices_collection = Counter(sorted(state_indices.tolist()))
-        z = self.basedist.sample_multstates(self.states, self.state_indices_collection, sample_shape)
+        cpu_dist = Categorical(logits=self.log_state_weights.detach().cpu())
+        all_idx = sorted(cpu_dist.sample(sample_shape).tolist())
+        rank, world = D.world()
+        off, cnt = D.shard(len(all_idx), rank, world)
+        self.state_indices_collection = Counter(all_idx[off:off + cnt])
+        self.basedist.walker_offset = off
+        self._nglobal = len(all_idx)
+        z = self.basedist.sample_multstates(self.states, self.state_indices_collection, (cnt,))
         x = self.cnf.generate(z, nframes=nframes)
         return z, x
 
@@ -179,37 +186,45 @@ class BetaVMC(torch.nn.Module):
         return torch.tensor(list(self.state_indices_collection.elements()), dtype=torch.int32, device=device)
 
     def forward(self, batch):
-        """Single-process finite-temperature sweep (src/VMC.py:114-171)."""
+        """Finite-temperature sweep (src/VMC.py:114-171).  Under torch.distributed `batch` is the global walker count;
+        the per-state sums and both gradients are all-reduced (2*Nstates + Nstates + 3(He+Hm) doubles)."""
         with torch.no_grad():
             _, x = self.sample((batch,))
             device = x.device
             ws = self._walker_state(device)
+            nloc, nglob = ws.numel(), self._nglobal
             r = self.local_energy(x, ws)
             Eloc = r["eloc"]
-            self.E, self.E_std = Eloc.mean().item(), Eloc.std().item()
-        state_indices = ws.to(torch.int64)
-        from torch.distributions.categorical import Categorical
-        self.state_dist = Categorical(logits=self.log_state_weights)      # with autograd (sample() ran under no_grad)
-        logp_states = self.state_dist.log_prob(state_indices.to(self.log_state_weights.device)).to(device)
-        with torch.no_grad():
-            Floc = Eloc + logp_states.detach() / self.beta
-            self.F, self.F_std = Floc.mean().item(), Floc.std().item()
-            self.S = -logp_states.detach().mean().item()
-            self.logp_states_all = self.state_dist.log_prob(
-                torch.arange(self.Nstates, device=self.log_state_weights.device)).detach()
-            self.S_analytical = -(self.logp_states_all * self.logp_states_all.exp()).sum().item()
-        gradF_phi = (logp_states * (Floc - self.F)).mean()
-        with torch.no_grad():
-            # per-state baseline (src/VMC.py:164-169): segmented mean over the state-sorted walkers
-            sums = torch.zeros(self.Nstates, dtype=torch.float64, device=device).index_add_(0, state_indices, Eloc)
-            cnts = torch.zeros(self.Nstates, dtype=torch.float64, device=device).index_add_(
-                0, state_indices, torch.ones_like(Eloc))
-            Eloc_x_mean = (sums / cnts.clamp(min=1.0))[state_indices]
-            w = (Eloc - Eloc_x_mean) / batch
+            self.E, self.E_std, _ = D.global_mean_std(Eloc.sum(), nloc, lambda m: ((Eloc - m) ** 2).sum())
+            state_indices = ws.to(torch.int64)
+            logits = self.log_state_weights.detach().to(device)
+            logp_all = torch.log_softmax(logits, dim=0)
+            logp_states = logp_all[state_indices]
+            Floc = Eloc + logp_states / self.beta
+            self.F, self.F_std, _ = D.global_mean_std(Floc.sum(), nloc, lambda m: ((Floc - m) ** 2).sum())
+            # per-state sums: entropy estimate, baseline of the theta-gradient, gradient wrt the state logits
+            cF = (Floc - self.F) / nglob
+            stat = torch.zeros(4, self.Nstates, dtype=torch.float64, device=device)
+            stat[0].index_add_(0, state_indices, Eloc)
+            stat[1].index_add_(0, state_indices, torch.ones_like(Eloc))
+            stat[2].index_add_(0, state_indices, cF)
+            stat[3, 0] = (logp_states * cF).sum()           # value of gradF_phi (local part)
+            D.all_reduce_sum_(stat)
+            sums, cnts, cF_state = stat[0], stat[1], stat[2]
+            self.S = -(cnts * logp_all).sum().item() / nglob
+            self.logp_states_all = logp_all.to(self.log_state_weights.device)
+            self.S_analytical = -(logp_all * logp_all.exp()).sum().item()
+            # d/dlogits sum_b cF_b log_softmax(logits)[s_b] = cF_state - softmax * sum(cF_state)
+            g_phi = (cF_state - logp_all.exp() * cF_state.sum()).to(self.log_state_weights.device)
+            Eloc_x_mean = (sums / cnts.clamp(min=1.0))[state_indices]       # per-state baseline (src/VMC.py:164-169)
+            w = (Eloc - Eloc_x_mean) / nglob
             v, params = _flow_params(self.cnf)
             t0, t1 = self.cnf.t_span
             _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
                                        self.cnf.rtol, self.cnf.atol, need_gx=False)
-            val = (r["logp"] * w).sum()
-        gradF_theta = _ScalarWithParamGrads.apply(val, _split_like(gp, params), *params)
+            buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
+            D.all_reduce_sum_(buf)
+        self.Eloc, self.x = Eloc, x
+        gradF_phi = _ScalarWithParamGrads.apply(stat[3, 0].to(self.log_state_weights.device), [g_phi], self.log_state_weights)
+        gradF_theta = _ScalarWithParamGrads.apply(buf[0], _split_like(buf[1:], params), *params)
         return gradF_phi, gradF_theta

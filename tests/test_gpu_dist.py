@@ -50,3 +50,39 @@ def test_two_ranks_equal_one_rank():
         assert abs(g2 - g) < 1e-10 * max(1.0, abs(g))
         np.testing.assert_allclose(grads2, grads, rtol=0, atol=1e-10 * np.abs(grads).max())
     assert (two[0][4] == x0).all()          # rank 0's first walkers are the global first walkers, bit for bit
+
+
+def _run_beta(rank, world, port, B, out):
+    import torch.distributed as dist
+    import fermiflow_amd as ff
+    import __graft_entry__ as G
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    gs = G._model(dev, 3, 0, 2.0)
+    model = ff.BetaVMC(2.0, 3, 0, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), gs.cnf,
+                       ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+    model.to(dev)
+    torch.manual_seed(77)
+    gphi, gtheta = model(B)
+    (gphi + gtheta).backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    out[rank] = (model.E, model.E_std, model.F, model.F_std, model.S, gphi.item(), gtheta.item(), grads)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_betavmc_two_ranks_equal_one_rank():
+    B = 2048
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    mp.spawn(_run_beta, args=(1, 0, B, one), nprocs=1, join=True)
+    mp.spawn(_run_beta, args=(2, _free_port(), B, two), nprocs=2, join=True)
+    ref = one[0]
+    for r in (0, 1):
+        got = two[r]
+        for a, b in zip(got[:7], ref[:7]):
+            assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (a, b)
+        np.testing.assert_allclose(got[7], ref[7], rtol=0, atol=1e-10 * np.abs(ref[7]).max())

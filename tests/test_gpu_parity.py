@@ -281,6 +281,17 @@ def test_betavmc_vs_reference(golden, dev):
         np.testing.assert_allclose(N(model.logp_states_all), G[tag + "_logp_states_all"], atol=1e-12)
         assert np.isfinite([model.E, model.F, model.S]).all()
         assert model.log_state_weights.grad is not None and all(p.grad is not None for p in cnf.parameters())
+        # gradient wrt the state logits against autograd on the same walkers (src/VMC.py:162)
+        ws2 = model._walker_state(dev).to(torch.int64)
+        lw = model.log_state_weights.detach().clone().requires_grad_(True)
+        lps = torch.log_softmax(lw, dim=0)[ws2]
+        Floc = model.Eloc + lps.detach() / model.beta
+        (lps * (Floc - model.F)).mean().backward()
+        gtheta_before = [p.grad.clone() for p in cnf.parameters()]
+        model.zero_grad()
+        gphi.backward()
+        np.testing.assert_allclose(N(model.log_state_weights.grad), N(lw.grad), atol=1e-12 * max(1.0, lw.grad.abs().max().item()))
+        assert all(p.grad is None or (p.grad == 0).all() for p in cnf.parameters())      # gradF_phi does not touch the flow
 
 
 # ------------------------------------------------------------------------------------------------ radial tables
