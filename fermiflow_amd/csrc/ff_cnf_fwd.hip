@@ -458,6 +458,362 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   }
 }
 
+
+// ===================================================================================================
+// Local-energy sensitivities for larger walkers (M = N*D > 12): TWO lanes per direction.
+// With one lane per direction the lane state is M+5 doubles and no longer fits the register file next to the working
+// set (n = 12: 29 doubles x 5 stage vectors).  Here lane (i, h) holds the half of the column u_i = dz/dx_i that belongs
+// to the particles of half h (h = 0: particles [0, N/2), h = 1: the rest), so the lane state is M/2 + 5 doubles again.
+// The two lanes of a direction publish their halves to LDS; a lane sweeps the pairs inside its half two-sided and the
+// pairs across the halves one-sided (the partner lane does the other side), counting the scalar sources of cross
+// pairs half each.  z_i, kbar_i and the own-coordinate picks live on the lane whose half contains particle(i).
+// Delta, grad Delta and lap Delta are kept as per-lane partial sums (their equations are linear) and combined at the
+// end.  L = 2M lanes per walker, G = 64 / L walkers per wave.
+template <int N, int D>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_eloc_split_kernel(ff_fwd_args A) {
+  static_assert(N % 2 == 0, "split kernel needs an even particle number");
+  constexpr int M = N * D, NP = N / 2, MH = NP * D, L = 2 * M, G = FF_WAVE / L;
+  constexpr int P = N * (N - 1) / 2, R = P + N;
+  constexpr int NV = MH + 5;   // [0] z_i (owner lanes), [1..MH] u half, [MH+1] kbar_i (owner), [MH+2] dDelta part, [MH+3] Delta part, [MH+4] lap part
+  static_assert(G >= 1, "walker does not fit a wave");
+
+  __shared__ ff_wtab s_w[2][FF_HPAD];
+  __shared__ double s_e2[64];
+  __shared__ double s_z[G][M], s_kb[G][M], s_err[G][L];
+  __shared__ double s_u[G][M][M + 1];
+  __shared__ __attribute__((aligned(16))) double s_rr[G][R][2];
+  __shared__ __attribute__((aligned(16))) double s_hd[G][R][4];
+  __shared__ double s_q[G][M][2][MH + 1];
+  __shared__ double s_yv[NV][FF_WAVE], s_cv[NV][FF_WAVE];
+  __shared__ int s_pa[R], s_pb[R], s_any;
+
+  const int lane = threadIdx.x;
+  const int g = lane / L, idx = lane % L;
+  const int h = idx / M, i = idx % M;            // half, direction
+  const bool ingrp = g < G;
+  const int gg = ingrp ? g : 0;
+  const int ai = i / D, ci = i % D;              // particle / component of direction i
+  const bool owner = (ai / NP) == h;             // this lane carries z_i, kbar_i and the own-coordinate picks
+  const int la = owner ? ai - h * NP : -1;       // local index of particle(i) inside this half
+  ff_load_weights(s_w, A.net, lane);
+  ff_fill_exp2_table(s_e2, lane);
+  if (lane == 0) {
+    int p = 0;
+    for (int a = 0; a < N; a++)
+      for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
+    for (int a = 0; a < N; a++) { s_pa[P + a] = a; s_pb[P + a] = -1; }
+  }
+  __syncthreads();
+  const int He = A.net.He, Hm = A.net.Hm;
+  const bool has_mu = Hm > 0;
+  const int nrad = has_mu ? R : P;
+  const double* __restrict__ rtab = A.net.radial_table;
+  const bool use_tab = rtab != nullptr && rtab[3] == 0.0;
+  const double tab_inv_h = use_tab ? rtab[0] : 0.0, tab_h = use_tab ? rtab[1] : 0.0;
+  const double rtol = A.rtol, atol = A.atol;
+  constexpr double NT = 2.0 * M + (double)M * M + 3.0 * L;   // z, kbar (owners), u, and three partial scalars per lane
+  const int64_t ngroups = (A.B + G - 1) / G;
+  long long ev_sum = 0;
+  int acc_max = 0, rej_sum = 0, fail_any = 0;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t b = grp * G + g;
+    const bool valid = ingrp && b < A.B;
+    ff_lane_vec<NV, true> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
+    double c0[NV], c1[NV], c2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
+    if (owner) y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
+#pragma unroll
+    for (int k = 0; k < MH; k++) y[1 + k] = (h * MH + k == i) ? 1.0 : 0.0;
+    ff_stepper S;
+    S.begin(A.ta, A.tb, valid);
+    int s = -2, nev = 0;
+    double h0v = 0.0, d1v = 0.0;
+
+    auto group_sum = [&](double part) -> double {
+      if (ingrp) s_err[g][idx] = part;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < L; j++) t += s_err[gg][j];
+      __syncthreads();
+      return t;
+    };
+    // slots 0 and MH+1 exist on owner lanes only
+    auto wgt = [&](int v) -> double { return ((v == 0 || v == MH + 1) && !owner) ? 0.0 : 1.0; };
+
+#pragma unroll 1
+    for (;;) {
+      const double hs = S.h;
+      double gy = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      switch (s) {
+        case -1: g0 = h0v * S.dir; break;
+        case 1: g0 = hs * FF_A10; break;
+        case 2: g0 = hs * FF_A20; g1 = hs * FF_A21; break;
+        case 3: g0 = hs * FF_A30; g1 = hs * FF_A31; g2 = hs * FF_A32; break;
+        case 4: gy = 0.0; g0 = 1.0; break;
+        case 5: gy = 0.0; g1 = 1.0; break;
+        case 6: gy = 0.0; g2 = 1.0; break;
+        default: break;
+      }
+      double in[NV], out[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) in[v] = fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v])));
+      // ------------------------------------------------------------------ publish z, kbar (owners) and the u halves
+      __syncthreads();
+      if (ingrp) {
+        if (owner) { s_z[g][i] = in[0]; s_kb[g][i] = in[MH + 1]; }
+#pragma unroll
+        for (int k = 0; k < MH; k++) s_u[g][i][h * MH + k] = in[1 + k];
+      }
+      __syncthreads();
+      // ------------------------------------------------------------------ radius phase (lane <-> radius)
+      for (int q = lane; q < G * nrad; q += FF_WAVE) {
+        const int qg = q / nrad, p = q - qg * nrad;
+        const int a = s_pa[p], bb = s_pb[p];
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          double t = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
+          r2 = fma(t, t, r2);
+        }
+        const double r = sqrt(r2);
+        double hd[4];
+        if (!(use_tab && ff_heads_table<4>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd)))
+          ff_heads<4, true>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
+        s_rr[qg][p][0] = r;
+        s_rr[qg][p][1] = ff_rcp(r);
+#pragma unroll
+        for (int m = 0; m < 4; m++) s_hd[qg][p][m] = hd[m];
+      }
+      __syncthreads();
+      nev++;
+      // ------------------------------------------------------------------ jet sweep over this half's particles
+      double du[MH], qv[MH];
+#pragma unroll
+      for (int k = 0; k < MH; k++) { du[k] = 0.0; qv[k] = 0.0; }
+      double ddiv = 0.0, qdiv = 0.0, divv = 0.0, vi = 0.0, dvk = 0.0, gdi = 0.0;
+      const double* u = &in[1];
+      const double* zm = s_z[gg] + h * MH;          // my half's coordinates / kbar
+      const double* km = s_kb[gg] + h * MH;
+      const double* zo = s_z[gg] + (1 - h) * MH;    // the other half's
+      const double* ko = s_kb[gg] + (1 - h) * MH;
+      const double* uo = s_u[gg][i] + (1 - h) * MH;  // partner lane's half of u_i
+      const int pbase = h * NP, obase = (1 - h) * NP;
+      // one radius term; TWO: both particles are mine (accumulate both sides); wsc: weight of the scalar sources
+      auto term = [&](const double* rho, const double* dl, const double* dk, int p, int m1, int m2, bool two, double cf, double wsc,
+                      double sgn) {
+        double rd = 0.0, dd = 0.0, rdk = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) { rd = fma(rho[c], dl[c], rd); dd = fma(dl[c], dl[c], dd); rdk = fma(rho[c], dk[c], rdk); }
+        const double r = s_rr[gg][p][0], ri = s_rr[gg][p][1];
+        const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2], f3 = s_hd[gg][p][3];
+        const double r1 = rd * ri, r1s = r1 * r1, r2q = (dd - r1s) * ri;
+        const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          const double a1 = fma(F1, rho[c], f0 * dl[c]), a2 = fma(F2, rho[c], 2.0 * F1 * dl[c]);
+          du[m1 * D + c] += a1; qv[m1 * D + c] += a2;
+          if (two) { du[m2 * D + c] -= a1; qv[m2 * D + c] -= a2; }
+        }
+        const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
+        ddiv = fma(wsc * cf * sp, r1, ddiv);
+        qdiv += wsc * cf * fma(spp, r1s, sp * r2q);
+        divv += wsc * cf * fma(f1, r, D * f0);
+        double rc = rho[0], dkc = dk[0];
+#pragma unroll
+        for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
+        const double F1k = f1 * (rdk * ri);
+        vi = fma(sgn * f0, rc, vi);
+        dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
+        gdi = fma(sgn * cf * sp * ri, rc, gdi);
+      };
+      // pairs inside my half
+#pragma unroll
+      for (int m1 = 0; m1 < NP; m1++) {
+#pragma unroll
+        for (int m2 = m1 + 1; m2 < NP; m2++) {
+          double rho[D], dl[D], dk[D];
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            rho[c] = zm[m1 * D + c] - zm[m2 * D + c];
+            dl[c] = u[m1 * D + c] - u[m2 * D + c];
+            dk[c] = km[m1 * D + c] - km[m2 * D + c];
+          }
+          const int p = ff_pair_index(N, pbase + m1, pbase + m2);
+          term(rho, dl, dk, p, m1, m2, true, 2.0, 1.0, la == m1 ? 1.0 : (la == m2 ? -1.0 : 0.0));
+        }
+        if ((m1 & 1) == 1) FF_SCHED_FENCE();
+      }
+      // pairs across the halves: my particle m, the other half's particle o (one-sided; scalar sources count half)
+#pragma unroll
+      for (int m = 0; m < NP; m++) {
+#pragma unroll
+        for (int o = 0; o < NP; o++) {
+          double rho[D], dl[D], dk[D];
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            rho[c] = zm[m * D + c] - zo[o * D + c];
+            dl[c] = u[m * D + c] - uo[o * D + c];
+            dk[c] = km[m * D + c] - ko[o * D + c];
+          }
+          const int pm = pbase + m, po = obase + o;
+          const int p = ff_pair_index(N, pm < po ? pm : po, pm < po ? po : pm);
+          term(rho, dl, dk, p, m, 0, false, 2.0, 0.5, la == m ? 1.0 : 0.0);
+        }
+        FF_SCHED_FENCE();
+      }
+      if (has_mu) {
+#pragma unroll
+        for (int m = 0; m < NP; m++) {
+          double rho[D], dl[D], dk[D];
+#pragma unroll
+          for (int c = 0; c < D; c++) { rho[c] = zm[m * D + c]; dl[c] = u[m * D + c]; dk[c] = km[m * D + c]; }
+          term(rho, dl, dk, P + pbase + m, m, 0, false, 1.0, 1.0, la == m ? 1.0 : 0.0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < MH; k++) out[1 + k] = du[k];
+      // transpose-reduce the quadratic sources: the owner of coordinate c needs sum_i qv_(i, half(c))[c]
+      if (ingrp) {
+#pragma unroll
+        for (int k = 0; k < MH; k++) s_q[g][i][h][k] = qv[k];
+      }
+      __syncthreads();
+      double sumq = 0.0;
+      if (owner) {
+        const int lc = i - h * MH;
+        for (int j = 0; j < M; j++) sumq += s_q[gg][j][h][lc];
+      }
+      out[0] = owner ? vi : 0.0;
+      out[MH + 1] = owner ? sumq + dvk : 0.0;
+      out[MH + 2] = -ddiv;
+      out[MH + 3] = -divv;
+      out[MH + 4] = -(qdiv + (owner ? gdi * in[MH + 1] : 0.0));
+      // ------------------------------------------------------------------ consume
+      if (s == -2) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) c0[v] = out[v];
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double isc = wgt(v) * ff_rcp(fma(fabs(y[v]), rtol, atol));
+          p0 = fma(y[v] * isc, y[v] * isc, p0);
+          p1 = fma(c0[v] * isc, c0[v] * isc, p1);
+        }
+        const double d0 = sqrt(group_sum(p0) * (1.0 / NT));
+        d1v = sqrt(group_sum(p1) * (1.0 / NT));
+        h0v = S.h0(d0, d1v);
+        s = -1;
+      } else if (s == -1) {
+        double p2 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double t = (out[v] - c0[v]) * wgt(v) * ff_rcp(fma(fabs(y[v]), rtol, atol));
+          p2 = fma(t, t, p2);
+        }
+        const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
+        S.init_habs(h0v, d1v, d2);
+        S.plan();
+        s = 1;
+      } else if (s == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) c0[v] = out[v];
+        s = 1;
+      } else if (s == 1) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) c1[v] = out[v];
+        s = 2;
+      } else if (s == 2) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) c2[v] = out[v];
+        s = 3;
+      } else if (s == 3) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v], yv = y[v];
+          c0[v] = fma(hs, FF_A40 * k0v + FF_A41 * k1v + FF_A42 * k2v + FF_A43 * k3v, yv);
+          c1[v] = fma(hs, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
+          c2[v] = fma(hs, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
+          c3[v] = hs * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+        }
+        s = 4;
+      } else if (s == 4) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          c1[v] = fma(hs * FF_A54, out[v], c1[v]);
+          c2[v] = fma(hs * FF_B4, out[v], c2[v]);
+          c3[v] = fma(hs * FF_E4, out[v], c3[v]);
+        }
+        s = 5;
+      } else if (s == 5) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          c2[v] = fma(hs * FF_B5, out[v], c2[v]);
+          c3[v] = fma(hs * FF_E5, out[v], c3[v]);
+        }
+        s = 6;
+      } else {
+        double pe = 0.0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double e = fma(hs * FF_E6, out[v], c3[v]);
+          const double t = e * wgt(v) * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
+          pe = fma(t, t, pe);
+        }
+        const double err = sqrt(group_sum(pe) * (1.0 / NT));
+        const bool was_active = !S.done;
+        const bool acc = S.decide(err, A.max_steps);
+        if (acc) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) { y[v] = in[v]; c0[v] = out[v]; }
+        }
+        S.plan();
+        if (lane == 0) s_any = 0;
+        __syncthreads();
+        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
+        __syncthreads();
+        const int any = s_any;
+        if (!any) break;
+        s = (any & 2) ? 0 : 1;
+      }
+    }
+    // ---------------------------------------------------------------------- results: combine the per-lane partials
+    const double dpart = y[MH + 2], delpart = y[MH + 3], lpart = y[MH + 4];
+    const double delta = group_sum(delpart) * (1.0 / M);    // every direction's two lanes cover all pairs once
+    if (ingrp) s_err[g][idx] = dpart;
+    __syncthreads();
+    const double dD_i = s_err[gg][i] + s_err[gg][M + i];
+    __syncthreads();
+    if (ingrp) s_err[g][idx] = lpart;
+    __syncthreads();
+    const double L_i = s_err[gg][i] + s_err[gg][M + i];
+    __syncthreads();
+    if (valid) {
+      if (owner) { A.y_out[b * M + i] = y[0]; A.kbar[b * M + i] = y[MH + 1]; }
+#pragma unroll
+      for (int k = 0; k < MH; k++) A.Jt[(b * M + i) * M + h * MH + k] = y[1 + k];
+      if (h == 0) { A.dD[b * M + i] = dD_i; A.Lpart[b * M + i] = L_i; }
+      if (idx == 0) {
+        A.dl_out[b] = delta;
+        ev_sum += nev;
+        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
+        rej_sum += S.nrej;
+        fail_any |= S.fail;
+      }
+    }
+    __syncthreads();
+  }
+  if (A.stats && (ev_sum || fail_any)) {
+    atomicAdd(&A.stats[0], (int)ev_sum);
+    atomicMax(&A.stats[1], acc_max);
+    atomicAdd(&A.stats[2], rej_sum);
+    if (fail_any) atomicMax(&A.stats[3], 1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Local-energy finish (one lane per walker): Slater gradient/Hessian at z(t0) contracted with the
 // sensitivities from the MODE-2 pass.  With g0 = grad_z logp0, H0 = Hess_z logp0:
@@ -552,8 +908,23 @@ static void launch_fwd(void* stream, const ff_fwd_args& a) {
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE>), grid, FF_WAVE, stream, a);
 }
 
+// n >= 8 uses the two-lanes-per-direction local-energy kernel (measured, 32768 walkers: n = 8 6.5 -> 4.5 ms,
+// n = 10 48 -> 9.3 ms, n = 12 95 -> 14.7 ms); FF_NO_SPLIT=1 forces the one-lane-per-direction kernel (A/B testing)
+template <int N, int D>
+static void launch_split(void* stream, const ff_fwd_args& a) {
+  constexpr int G = FF_WAVE / (2 * N * D);
+  int64_t ngroups = (a.B + G - 1) / G;
+  const int64_t cap = ff_persist_blocks(1 << 20);
+  FF_LAUNCH((ff_eloc_split_kernel<N, D>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, stream, a);
+}
+
 template <int MODE>
 static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a) {
+  if (MODE == 2 && d == 2 && !getenv("FF_NO_SPLIT")) {
+#define FF_SP(N_) if (n == N_) { launch_split<N_, 2>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+    FF_SP(8) FF_SP(10) FF_SP(12)
+#undef FF_SP
+  }
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
   FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
 #undef FF_ND

@@ -340,6 +340,7 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
   if (B == 0) return FF_OK;
 #define FF_MC(NU_, ND_) if (nup == NU_ && ndn == ND_) { launch_mcmc<NU_, ND_>(noise, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count); FF_LAUNCH_CHECK(); return FF_OK; }
   FF_MC(3, 3) FF_MC(3, 0) FF_MC(6, 0) FF_MC(6, 6) FF_MC(1, 0) FF_MC(2, 0) FF_MC(4, 0)
+  FF_MC(1, 1) FF_MC(2, 2) FF_MC(4, 4) FF_MC(5, 5) FF_MC(5, 0) FF_MC(10, 0)
 #undef FF_MC
   launch_mcmc<-1, -1>(noise, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count);
   FF_LAUNCH_CHECK();

@@ -155,3 +155,21 @@ def test_radii_beyond_the_table_fall_back_to_direct_evaluation(golden):
     gx_t, gp_t, _ = S.cnf_adjoint(z, cz, cd, tab, rtol=1e-9, atol=1e-11)
     np.testing.assert_array_equal(gp_t, gp_e)        # same kernel served both calls
     np.testing.assert_array_equal(gx_t, gx_e)
+
+
+@pytest.mark.parametrize("nup,ndn,B", [(4, 4, 5), (6, 6, 3)])
+def test_split_column_eloc_kernel(nup, ndn, B):
+    """ff_eloc_split_kernel (n >= 8: two lanes per direction, half columns exchanged through LDS) against the oracle,
+    with direct and tabulated radial functions; B is chosen ragged (G = 2 walkers per wave for n = 8, 1 for n = 12)."""
+    rng = np.random.default_rng(5 + nup)
+    He, Hm = 16, 12
+    eta = [rng.normal(size=He) * 0.5, rng.normal(size=He) * 0.3, rng.normal(size=He) * 0.05]
+    mu = [rng.normal(size=Hm) * 0.5, rng.normal(size=Hm) * 0.3, rng.normal(size=Hm) * 0.05]
+    x = rng.normal(size=(B, nup + ndn, 2)) * 1.2
+    ref = O.eloc(x, nup, ndn, O.Net(eta, mu), 2.0, rtol=1e-11, atol=1e-13)
+    for table in (False, True):
+        r = S.eloc(x, nup, ndn, S.Net(eta, mu, table=table), 2.0, rtol=1e-9, atol=1e-11)
+        assert r["stats"][3] == 0
+        np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-8)
+        np.testing.assert_allclose(r["grad"], ref["grad"], atol=1e-8)
+        np.testing.assert_allclose(r["lap"], ref["lap"], rtol=1e-7)
