@@ -100,14 +100,20 @@ class GSVMC(torch.nn.Module):
             mark("t0")
             z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
             mark("mcmc")
-            x = self.cnf.generate(z)
+            # Walker schedule (include/fermiflow.h, ff_ode.walker_cost/_order): the flow pass reports a cost class per
+            # walker (how close its trajectory comes to a vanishing radius); the local-energy pass, whose step count
+            # depends on exactly that, takes the expensive walkers first.
+            t0, t1 = self.cnf.t_span
+            net = self.cnf.v_wrapper.v.net()
+            steps = torch.empty(nloc, dtype=torch.int32, device=z.device)
+            x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=steps)
+            order = native.walker_order(steps)
             mark("generate")
             p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
             tu, td = self._tables(x.device)
-            t0, t1 = self.cnf.t_span
-            r = native.eloc(tu, td, self.nup, self.ndown, self.cnf.v_wrapper.v.net(), x, t0, t1, self.cnf.rtol,
+            r = native.eloc(tu, td, self.nup, self.ndown, net, x, t0, t1, self.cnf.rtol,
                             self.cnf.atol, getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None,
-                            want_stats=prof is not None, pass1_events=p1)
+                            want_stats=prof is not None, pass1_events=p1, walker_order=order)
             mark("eloc")
             Eloc = r["eloc"]
             s0 = native.reduce_moments(Eloc, 0.0)
@@ -117,7 +123,7 @@ class GSVMC(torch.nn.Module):
             v, params = _flow_params(self.cnf)
             mark("estimator")
             _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
-                                       self.cnf.rtol, self.cnf.atol, need_gx=False)
+                                       self.cnf.rtol, self.cnf.atol, need_gx=False)   # (uniform cost: no schedule)
             buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
             D.all_reduce_sum_(buf)
             mark("adjoint")

@@ -16,7 +16,7 @@ SYMBOLS = [
     "ff_version", "ff_last_error", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
     "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
     "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint",
-    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments",
+    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_walker_order_workspace_bytes", "ff_walker_order",
 ]
 
 
@@ -28,7 +28,7 @@ class FFNet(C.Structure):
 
 class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
-                ("max_steps", C.c_int32)]
+                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p)]
 
 
 def lib():
@@ -44,6 +44,7 @@ def lib():
         _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
         _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
         _LIB.ff_radial_table_bytes.restype = C.c_size_t
+        _LIB.ff_walker_order_workspace_bytes.restype = C.c_size_t
     return _LIB
 
 
@@ -119,5 +120,11 @@ class Net:
         return C.byref(self.c)
 
 
-def ode(t0, t1, rtol, atol, max_steps=0):
-    return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps))
+def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None):
+    """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids)."""
+    for name, tns in (("walker_cost", walker_cost), ("walker_order", walker_order)):
+        if tns is not None and not (tns.dtype == torch.int32 and tns.is_contiguous() and tns.is_cuda):
+            raise ValueError(f"{name} must be a contiguous int32 device tensor")
+    return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps),
+                 walker_cost.data_ptr() if walker_cost is not None else None,
+                 walker_order.data_ptr() if walker_order is not None else None)

@@ -30,6 +30,8 @@ struct ff_adj_args {
   double* trows;        // (gridDim.x, 2, FF_DEP_NLDS, FF_DEP_ROW) private coefficient tables, then Wtot (tabulated kernel)
   double* off_table;    // one double, zeroed per call: set to 1 when a radius falls off the deposit table
   int32_t* stats;
+  int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
+  const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
 };
 
 // MAXU: hidden units owned per lane and net (ceil(H/M) for the widths at hand; <= ceil(FF_HMAX/M))
@@ -86,8 +88,9 @@ ff_ode_adj_kernel(ff_adj_args A) {
   };
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t b = grp * G + g;
-    const bool valid = ingrp && b < A.B;
+    const int64_t bq = grp * G + g;
+    const bool valid = ingrp && bq < A.B;
+    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
     double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
     y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
     y[1] = valid ? A.az_in[b * M + i] : 0.0;
@@ -375,6 +378,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     if (valid) {
       if (A.gx_out) A.gx_out[b * M + i] = y[1];
       if (i == 0) {
+        if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
         rej_sum += S.nrej;
@@ -481,8 +485,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t b = grp * G + g;
-    const bool valid = ingrp && b < A.B;
+    const int64_t bq = grp * G + g;
+    const bool valid = ingrp && bq < A.B;
+    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
     double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
     y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
     y[1] = valid ? A.az_in[b * M + i] : 0.0;
@@ -733,6 +738,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     if (valid) {
       if (A.gx_out) A.gx_out[b * M + i] = y[1];
       if (i == 0) {
+        if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
         rej_sum += S.nrej;
@@ -875,6 +881,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   ff_adj_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);

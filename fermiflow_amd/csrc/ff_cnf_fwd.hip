@@ -15,6 +15,7 @@
 //      2nd-order Taylor jet (first-order part -> dJ/dt column, quadratic part -> source of kbar and lap Delta);
 //   4. "component phase": lane (g,i) assembles v_i, (Dv[kbar])_i, (grad div)_i from the heads of the pairs
 //      its particle takes part in.
+#include <atomic>
 #include "ff_common.h"
 #include "ff_ode.h"
 #include "ff_slater.h"
@@ -47,12 +48,22 @@ struct ff_fwd_args {
   double* dD;           // (B, M)   d Delta / d x_i
   double* Lpart;        // (B, M)   per-direction parts of lap_x Delta
   int32_t* stats;
+  int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
+  const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place
+  // Off-table protocol (TAB kernels): a kernel that meets a radius beyond the table, or an unusable table, stores
+  // evt_id into *evt (a slot of the table header); the direct-evaluation kernel launched right behind it with the
+  // same id returns at once unless it finds its id there.  ids are unique per process, so slots need no reset.
+  double* evt;
+  double evt_id;
 };
 
+#ifndef FF_SWEEP_CH
+#define FF_SWEEP_CH 3   // records per look-ahead chunk of the jet sweep (4 spills to scratch at n = 6)
+#endif
 #ifndef FF_FWD_WAVES_PER_SIMD
 #define FF_FWD_WAVES_PER_SIMD 1
 #endif
-template <int N, int D, int MODE>
+template <int N, int D, int MODE, bool TAB>
 __global__ void __launch_bounds__(FF_WAVE, FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
   using Gm = ff_geom<N, D>;
@@ -63,13 +74,31 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   // [M+2] dDelta/dx_i, [M+3] Delta, [M+4] L_i
   constexpr int IDL = MODE == 1 ? 1 : M + 3;  // slot of the replicated Delta
 
-  __shared__ ff_wtab s_w[2][FF_HPAD];
+  // TAB: radial functions from the per-launch table only (no weights, no exp table in LDS); !TAB: direct evaluation
+  __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
+  __shared__ double s_e2[TAB ? 1 : 64];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M];
-  __shared__ __attribute__((aligned(16))) double s_rr[G][R][2];   // radius and its reciprocal
-  __shared__ __attribute__((aligned(16))) double s_hd[G][R][NH];
-  __shared__ double s_q[MODE == 2 ? G : 1][MODE == 2 ? M : 1][MODE == 2 ? M + 1 : 1];
+  constexpr bool JET = (MODE == 2);
+  __shared__ __attribute__((aligned(16))) double s_rr[JET ? 1 : G][JET ? 1 : R][2];   // radius and its reciprocal
+  __shared__ __attribute__((aligned(16))) double s_hd[JET ? 1 : G][JET ? 1 : R][NH];
+  // MODE 2: one record per radius with everything about it that does not depend on the direction:
+  //   rho (D), 1/r, eta, eta', eta'', A = c (eta'' r + (1+D) eta'), B = c (eta''' r + (2+D) eta''), c (eta' r + D eta)
+  //   (c = 2 for pairs, 1 for one-body radii)
+  constexpr int RECW = (D + 7 + 1) & ~1;   // + the radius' share of div v
+  // walker stride padded so that the G records a wave reads together (one address per walker, broadcast to its M lanes)
+  // fall into different LDS banks: stride mod 32 dwords is an odd multiple of 4
+  constexpr int RECS0 = R * RECW, RECS = RECS0 + ((RECS0 % 4 == 2) ? 0 : ((RECS0 % 4 == 0) ? 2 : 1));
+  static_assert(!JET || ((2 * RECS) % 32) % 8 == 4, "record stride");
+  __shared__ __attribute__((aligned(16))) double s_rec[JET ? G * RECS : 1];
+  // s_qt is used twice per evaluation: first as T[g][a][j][3][D], the contributions of partner j (j = a: one-body term)
+  // to particle a's own rows (v, Dv[kbar], grad div), written in the radius phase and gathered before the sweep; then
+  // as the (M x (M+1)) transposition buffer of the quadratic sources
+  constexpr int QTW = ((3 * N > M) ? 3 * N + 1 : M + 1) | 1;   // odd row length: conflict-free transposition
+  constexpr int TROW = N * 3 * D + 1;                              // T row of one particle (padded likewise)
+  static_assert(N * TROW <= M * QTW, "T must fit the transposition buffer");
+  __shared__ __attribute__((aligned(16))) double s_qt[JET ? G * M * QTW : 1];
   __shared__ int s_pa[R], s_pb[R], s_any;
-  __shared__ double s_e2[64];
+  __shared__ double s_rmin[G][R];   // smallest value each radius took during the walker's integration (walker_cost)
   // lane-private LDS columns for y and the error accumulator: only while 4 workgroups still fit a CU's LDS
   constexpr bool LDS_STATE = (MODE == 2 && M <= 12);
   __shared__ double s_yv[LDS_STATE ? NV : 1][FF_WAVE], s_cv[LDS_STATE ? NV : 1][FF_WAVE];
@@ -78,10 +107,19 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const int g = lane / M, i = lane % M;
   const bool ingrp = g < G;
   const int gg = ingrp ? g : 0;  // safe LDS row for the idle tail lanes
-  ff_fill_exp2_table(s_e2, lane);
   const int ai = i / D, ci = i % D;
-
-  ff_load_weights(s_w, A.net, lane);
+  const double* __restrict__ rtab = A.net.radial_table;
+  if constexpr (TAB) {
+    if (rtab[3] != 0.0) {   // table unusable for these weights: leave the call to the direct kernel
+      if (lane == 0 && blockIdx.x == 0) *A.evt = A.evt_id;
+      return;
+    }
+  } else {
+    if (A.evt && *A.evt != A.evt_id) return;   // fallback launch that is not needed
+    ff_fill_exp2_table(s_e2, lane);
+    ff_load_weights(s_w, A.net, lane);
+  }
+  bool off_table = false;
   if (lane == 0) {
     int p = 0;
     for (int a = 0; a < N; a++)
@@ -92,9 +130,19 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? (P + N) : P;
-  const double* __restrict__ rtab = A.net.radial_table;
-  const bool use_tab = rtab != nullptr && rtab[3] == 0.0;
-  const double tab_inv_h = use_tab ? rtab[0] : 0.0, tab_h = use_tab ? rtab[1] : 0.0;
+  const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
+  // NH derivative heads of eta (t = 0) / mu (t = 1) at radius r
+  auto heads = [&](int t, double r, double* hd) {
+    if constexpr (TAB) {
+      if (!ff_heads_table<NH>(rtab, tab_inv_h, tab_h, t, r, hd)) {
+        off_table = true;
+#pragma unroll
+        for (int m = 0; m < NH; m++) hd[m] = 0.0;
+      }
+    } else {
+      ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[t], s_e2, t ? Hm : He, r, hd);
+    }
+  };
   const double rtol = A.rtol, atol = A.atol;
   constexpr double NT = MODE == 0 ? M : (MODE == 1 ? M + 1 : M * (M + 4) + 1);
   const int64_t ngroups = (A.B + G - 1) / G;
@@ -102,11 +150,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   int acc_max = 0, rej_sum = 0, fail_any = 0;
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_readcyclecounter() * 0 + wall_clock64();
 #endif
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t b = grp * G + g;
-    const bool valid = ingrp && b < A.B;
+    const int64_t bq = grp * G + g;
+    const bool valid = ingrp && bq < A.B;
+    const int64_t b = (valid && A.order) ? A.order[bq] : bq;   // the walker this lane group integrates
     // Stage storage, 5 vectors instead of the textbook 7 (y, k0..k5): c0..c2 hold k0..k2 up to stage 3; once k3 is
     // known the remaining stage inputs and the error accumulator are formed and overwrite them:
     //   c0 = input of stage 4, c1 = partial input of stage 5, c2 = partial y_new, c3 = partial error.
@@ -127,6 +177,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     S.begin(A.ta, A.tb, valid);
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
+    double rmin_q[(G * R + FF_WAVE - 1) / FF_WAVE];   // this lane's radii keep their slots from evaluation to evaluation
+#pragma unroll
+    for (int k = 0; k < (G * R + FF_WAVE - 1) / FF_WAVE; k++) rmin_q[k] = 1e300;
 
     // group-wide sum of a per-lane partial (all lanes of a walker get the identical result)
     auto group_sum = [&](double part) -> double {
@@ -178,23 +231,54 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       __syncthreads();
       FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase
-      for (int q = lane; q < G * nrad; q += FF_WAVE) {
+#pragma unroll
+      for (int qk = 0; qk < (G * R + FF_WAVE - 1) / FF_WAVE; qk++) {
+        const int q = lane + qk * FF_WAVE;
+        if (q >= G * nrad) break;
         const int qg = q / nrad, p = q - qg * nrad;
         const int a = s_pa[p], bb = s_pb[p];
-        double r2 = 0.0;
+        const bool pair = bb >= 0;
+        double rho[D], r2 = 0.0;
 #pragma unroll
         for (int c = 0; c < D; c++) {
-          double t = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
-          r2 = fma(t, t, r2);
+          rho[c] = s_z[qg][a * D + c] - (pair ? s_z[qg][bb * D + c] : 0.0);
+          r2 = fma(rho[c], rho[c], r2);
         }
         const double r = sqrt(r2);
+        rmin_q[qk] = fmin(rmin_q[qk], r);
         double hd[NH];
-        if (!(use_tab && ff_heads_table<NH>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd)))
-          ff_heads<NH, FF_TAB_MODE(MODE)>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
-        s_rr[qg][p][0] = r;
-        s_rr[qg][p][1] = ff_rcp(r);
+        heads(pair ? 0 : 1, r, hd);
+        if constexpr (!JET) {
+          s_rr[qg][p][0] = r;
+          s_rr[qg][p][1] = ff_rcp(r);
 #pragma unroll
-        for (int m = 0; m < NH; m++) s_hd[qg][p][m] = hd[m];
+          for (int m = 0; m < NH; m++) s_hd[qg][p][m] = hd[m];
+        } else {
+          const double ri = ff_rcp(r), cf = pair ? 2.0 : 1.0;
+          const double f0 = hd[0], f1 = hd[1], f2 = hd[NH > 2 ? 2 : 0], f3 = hd[NH > 3 ? 3 : 0];
+          const double Ac = cf * fma(f2, r, (1.0 + D) * f1), Bc = cf * fma(f3, r, (2.0 + D) * f2);
+          double* rec = &s_rec[qg * RECS + p * RECW];
+#pragma unroll
+          for (int c = 0; c < D; c++) rec[c] = rho[c];
+          rec[D] = ri; rec[D + 1] = f0; rec[D + 2] = f1; rec[D + 3] = f2; rec[D + 4] = Ac; rec[D + 5] = Bc;
+          rec[D + 6] = cf * fma(f1, r, D * f0);                 // this radius' share of div v
+          // own-row contributions of this radius: +x to particle a from partner bb, -x to particle bb from partner a
+          double dk[D], rdk = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            dk[c] = s_kb[qg][a * D + c] - (pair ? s_kb[qg][bb * D + c] : 0.0);
+            rdk = fma(rho[c], dk[c], rdk);
+          }
+          const double F1k = f1 * (rdk * ri), gq = Ac * ri;
+          double* Ta = &s_qt[qg * M * QTW + a * TROW + (pair ? bb : a) * 3 * D];
+          double* Tb = &s_qt[qg * M * QTW + (pair ? bb : a) * TROW + a * 3 * D];
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            const double pv = f0 * rho[c], pw = fma(F1k, rho[c], f0 * dk[c]), pg = gq * rho[c];
+            Ta[c] = pv; Ta[D + c] = pw; Ta[2 * D + c] = pg;
+            if (pair) { Tb[c] = -pv; Tb[D + c] = -pw; Tb[2 * D + c] = -pg; }
+          }
+        }
       }
       __syncthreads();
       nev++;
@@ -214,34 +298,34 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         //    latency-bound pass over LDS is needed.
         // Scheduling fences every few radii keep hipcc from hoisting all LDS reads of the sweep at once
         // (that would need > 400 VGPRs and spill to scratch).
+        // own rows first (the buffer they sit in is reused by the transposition below)
+        {
+          const double* T = &s_qt[gg * M * QTW + ai * TROW + ci];
+#pragma unroll
+          for (int j = 0; j < N; j++) {
+            const bool use = has_mu || j != ai;
+            const double tv = T[j * 3 * D], tw = T[j * 3 * D + D], tg = T[j * 3 * D + 2 * D];
+            vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
+          }
+        }
+        __syncthreads();
         double du[M], qv[M];
 #pragma unroll
         for (int k = 0; k < M; k++) { du[k] = 0.0; qv[k] = 0.0; }
         const double* u = &in[1];
-        // coordinates and kbar of the walker in registers; (r, 1/r, eta..eta''') of the radii stream through a
-        // two-deep register buffer: the LDS reads of chunk c+1 are issued before chunk c is computed, so the single
-        // resident wave does not sit out an LDS round trip per radius
-        // (for M > 12 the coordinates stay in LDS: 2*M more live doubles would push the kernel into scratch)
-        constexpr bool ZK_REG = (M <= 12);
-        double zr_[ZK_REG ? M : 1], kr_[ZK_REG ? M : 1];
-        if constexpr (ZK_REG) {
-#pragma unroll
-          for (int k = 0; k < M; k++) { zr_[k] = sz[k]; kr_[k] = s_kb[gg][k]; }
-        }
-        const double* zr = ZK_REG ? zr_ : sz;
-        const double* kr = ZK_REG ? kr_ : s_kb[gg];
+        // the records stream through a two-deep register buffer: the LDS reads of chunk c+1 are issued before chunk c
+        // is computed, so the single resident wave does not sit out an LDS round trip per radius
         constexpr bool PREF = (M <= 12);   // look-ahead only where the registers are there for it
-        constexpr int CH = PREF ? 4 : 2, RT = P + N, NCH = (RT + CH - 1) / CH;
+        constexpr int CH = PREF ? FF_SWEEP_CH : 2, RT = P + N, NCH = (RT + CH - 1) / CH;
         constexpr ff_pair_table<N> PT{};
-        double hb[2][CH][6];
-        auto load_chunk = [&](int c, double (*buf)[6]) {
+        double hb[2][CH][RECW];
+        auto load_chunk = [&](int c, double (*buf)[RECW]) {
 #pragma unroll
           for (int q = 0; q < CH; q++) {
             const int p = c * CH + q;
             if (p < RT) {
-              buf[q][0] = s_rr[gg][p][0]; buf[q][1] = s_rr[gg][p][1];
 #pragma unroll
-              for (int m = 0; m < 4; m++) buf[q][2 + m] = s_hd[gg][p][m];
+              for (int m = 0; m < D + 7; m++) buf[q][m] = s_rec[gg * RECS + p * RECW + m];
             }
           }
         };
@@ -256,43 +340,30 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
             if (p < RT && (p < P || has_mu)) {
               const bool pair = p < P;
               const int a = pair ? PT.a[p < P ? p : 0] : p - P, bq = pair ? PT.b[p < P ? p : 0] : 0;
-              const double cf = pair ? 2.0 : 1.0;
-              double rho[D], dl[D], dk[D], rd = 0.0, dd = 0.0, rdk = 0.0;
+              const double* hq = hb[PREF ? (c & 1) : 0][q];
+              const double* rho = hq;
+              const double ri = hq[D], f0 = hq[D + 1], f1 = hq[D + 2], f2 = hq[D + 3], Ac = hq[D + 4], Bc = hq[D + 5];
+              double dl[D], rd = 0.0, dd = 0.0;
 #pragma unroll
               for (int cc = 0; cc < D; cc++) {
-                rho[cc] = pair ? zr[a * D + cc] - zr[bq * D + cc] : zr[a * D + cc];
                 dl[cc] = pair ? u[a * D + cc] - u[bq * D + cc] : u[a * D + cc];
-                dk[cc] = pair ? kr[a * D + cc] - kr[bq * D + cc] : kr[a * D + cc];
                 rd = fma(rho[cc], dl[cc], rd);
                 dd = fma(dl[cc], dl[cc], dd);
-                rdk = fma(rho[cc], dk[cc], rdk);
               }
-              const double* hq = hb[PREF ? (c & 1) : 0][q];
-              const double r = hq[0], ri = hq[1], f0 = hq[2], f1 = hq[3], f2 = hq[4], f3 = hq[5];
               const double r1 = rd * ri, r1s = r1 * r1;
               const double r2q = (dd - r1s) * ri;
-              const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+              const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q), F1x2 = F1 + F1;
 #pragma unroll
               for (int cc = 0; cc < D; cc++) {
                 const double g1 = fma(F1, rho[cc], f0 * dl[cc]);
-                const double g2 = fma(F2, rho[cc], 2.0 * F1 * dl[cc]);
+                const double g2 = fma(F2, rho[cc], F1x2 * dl[cc]);
                 du[a * D + cc] += g1;
                 qv[a * D + cc] += g2;
                 if (pair) { du[bq * D + cc] -= g1; qv[bq * D + cc] -= g2; }
               }
-              const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
-              ddiv = fma(cf * sp, r1, ddiv);
-              qdiv += cf * fma(spp, r1s, sp * r2q);
-              divv += cf * fma(f1, r, D * f0);
-              // own coordinate (ai, ci): +term if this lane's particle is a, -term if it is the partner
-              const double sgn = (ai == a) ? 1.0 : ((pair && ai == bq) ? -1.0 : 0.0);
-              double rc = rho[0], dkc = dk[0];
-#pragma unroll
-              for (int cc = 1; cc < D; cc++) { rc = (ci == cc) ? rho[cc] : rc; dkc = (ci == cc) ? dk[cc] : dkc; }
-              const double F1k = f1 * (rdk * ri);
-              vi = fma(sgn * f0, rc, vi);
-              dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
-              gdi = fma(sgn * cf * sp * ri, rc, gdi);
+              ddiv = fma(Ac, r1, ddiv);
+              qdiv = fma(Bc, r1s, fma(Ac, r2q, qdiv));
+              divv += hq[D + 6];
             }
           }
           FF_SCHED_FENCE();
@@ -303,11 +374,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         // transpose-reduce the quadratic sources: lane c needs sum_j qv_j[c]
         if (ingrp) {
 #pragma unroll
-          for (int k = 0; k < M; k++) s_q[g][i][k] = qv[k];
+          for (int k = 0; k < M; k++) s_qt[(g * M + i) * QTW + k] = qv[k];
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < M; j++) sumq += s_q[gg][j][i];
+        for (int j = 0; j < M; j++) sumq += s_qt[(gg * M + j) * QTW + i];
         FF_STAMP(3);
       } else {
         if constexpr (MODE == 1) {
@@ -427,6 +498,14 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       FF_STAMP(5);
     }
     // ---------------------------------------------------------------------- results
+    if (A.wcost) {   // wave-uniform
+#pragma unroll
+      for (int qk = 0; qk < (G * R + FF_WAVE - 1) / FF_WAVE; qk++) {
+        const int q = lane + qk * FF_WAVE;
+        if (q < G * nrad) s_rmin[q / nrad][q % nrad] = rmin_q[qk];
+      }
+      __syncthreads();
+    }
     if (valid) {
       A.y_out[b * M + i] = y[0];
       if constexpr (MODE >= 1) { if (i == 0) A.dl_out[b] = y[IDL]; }
@@ -438,6 +517,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         A.Lpart[b * M + i] = y[M + 4];
       }
       if (i == 0) {
+        if (A.wcost) {
+          double rm = 1e300;
+          for (int p = 0; p < nrad; p++) rm = fmin(rm, s_rmin[g][p]);
+          A.wcost[b] = ff_cost_class(S.nacc + S.nrej, rm);
+        }
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
         rej_sum += S.nrej;
@@ -449,7 +533,21 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #ifdef FF_STAMPS
   if (A.stats && lane == 0)
     for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+  if (A.stats && lane == 0 && blockIdx.x == 0) {   // core ticks and 100 MHz ticks over this wave's life: the core clock
+    A.stats[26] = (int)(__builtin_amdgcn_s_memtime() - stamp_t0);
+    A.stats[27] = (int)(wall_clock64() - stamp_r0);
+  }
+#ifdef FF_STAMPS_TRACE   // per-workgroup (start, end, core ticks, hw id) behind the 32 stats words: tools/kbench.py --trace
+  if (A.stats && lane == 0 && blockIdx.x < 16384) {
+    int* t = A.stats + 32 + 4 * blockIdx.x;
+    t[0] = (int)(stamp_r0 & 0x7fffffff);
+    t[1] = (int)(wall_clock64() & 0x7fffffff);
+    t[2] = (int)(__builtin_amdgcn_s_memtime() - stamp_t0);
+    t[3] = (int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffff) | ((int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf) << 16);
+  }
 #endif
+#endif
+  if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);
     atomicMax(&A.stats[1], acc_max);
@@ -518,8 +616,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   int acc_max = 0, rej_sum = 0, fail_any = 0;
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t b = grp * G + g;
-    const bool valid = ingrp && b < A.B;
+    const int64_t bq = grp * G + g;
+    const bool valid = ingrp && bq < A.B;
+    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
     ff_lane_vec<NV, true> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
     double c0[NV], c1[NV], c2[NV];
 #pragma unroll
@@ -798,6 +897,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       if (h == 0) { A.dD[b * M + i] = dD_i; A.Lpart[b * M + i] = L_i; }
       if (idx == 0) {
         A.dl_out[b] = delta;
+        if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
         rej_sum += S.nrej;
@@ -899,13 +999,16 @@ extern void ff_set_error(const char* msg);
 // persistent single-wave workgroups; FF_PERSIST_BLOCKS env overrides (tuning experiments)
 static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
+// With a radial table: the table kernel, then the direct-evaluation kernel as its (normally idle) fallback -- it returns
+// in its first instructions unless the table kernel left this launch's id in the event slot.  Without: direct only.
 template <int N, int D, int MODE>
 static void launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
   const int64_t cap = ff_persist_blocks(1 << 20);   // measured: one workgroup per walker group balances best
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
-  FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE>), grid, FF_WAVE, stream, a);
+  if (a.evt) FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
 }
 
 // n >= 8 uses the two-lanes-per-direction local-energy kernel (measured, 32768 walkers: n = 8 6.5 -> 4.5 ms,
@@ -918,8 +1021,18 @@ static void launch_split(void* stream, const ff_fwd_args& a) {
   FF_LAUNCH((ff_eloc_split_kernel<N, D>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, stream, a);
 }
 
+static std::atomic<uint64_t> g_evt_counter{1};
+
 template <int MODE>
-static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a) {
+static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
+  ff_fwd_args a = a_in;
+  a.evt = nullptr;
+  a.evt_id = 0.0;
+  if (a.net.radial_table) {
+    const uint64_t id = g_evt_counter.fetch_add(1);
+    a.evt = const_cast<double*>(a.net.radial_table) + FF_TAB_EVT0 + (id % FF_TAB_NEVT);
+    a.evt_id = (double)(id & ((1ull << 52) - 1)) + 1.0;
+  }
   if (MODE == 2 && d == 2 && !getenv("FF_NO_SPLIT")) {
 #define FF_SP(N_) if (n == N_) { launch_split<N_, 2>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_SP(8) FF_SP(10) FF_SP(12)
@@ -965,6 +1078,7 @@ int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, co
   ff_fwd_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.y_in = z; a.y_out = x_out; a.stats = stats;
   return dispatch_fwd<0>(stream, n, d, a);
 }
@@ -978,6 +1092,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   ff_fwd_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
   return dispatch_fwd<1>(stream, n, d, a);
 }
@@ -1011,6 +1126,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   ff_fwd_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
+  a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
   return dispatch_fwd<2>(stream, n, d, a);
 }

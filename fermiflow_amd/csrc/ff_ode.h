@@ -53,6 +53,16 @@ struct ff_pair_table {
 };
 
 // per-hidden-unit weight record staged in LDS (48 B, 16-B aligned -> three ds_read_b128)
+// ff_ode.walker_cost (include/fermiflow.h): attempted steps + max(0, -log2(r_min^2) - 1), clamped to [0, 32)
+FF_D int ff_cost_class(int steps, double rmin) {
+  int e = 0;
+  const double r2 = rmin * rmin;
+  if (r2 > 0.0 && r2 < 1e300) (void)frexp(r2, &e); else e = r2 > 0.0 ? 2 : -64;
+  const int rc = -e - 1 > 0 ? -e - 1 : 0;
+  const int c = steps + rc;
+  return c < 0 ? 0 : (c > 31 ? 31 : c);
+}
+
 struct __attribute__((aligned(16))) ff_wtab { double w1, b1, w2, w2w1, w2w1_2, w2w1_3; };
 
 FF_D void ff_load_weights(ff_wtab (*s_w)[FF_HPAD], const ff_net& net, int lane) {

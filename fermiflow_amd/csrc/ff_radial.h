@@ -16,8 +16,12 @@
 #define FF_TAB_ROW 10                       // doubles per node (9 used; 80-byte rows keep 16-byte alignment)
 #define FF_TAB_MAXLOG 9                     // finest grid: h = 2^-9
 #define FF_TAB_NMAX (32 * (1 << FF_TAB_MAXLOG) + 1)
-#define FF_TAB_HDR 8                        // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used,
-                                            // [4] 1.0 if the adjoint's deposit grid must not be used
+#define FF_TAB_HDR 16                       // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used,
+                                            // [4] 1.0 if the adjoint's deposit grid must not be used,
+                                            // [8..15] event slots written by the kernels that read the table: a launch
+                                            // that met a radius beyond the table leaves its id in slot (id mod 8)
+#define FF_TAB_EVT0 8
+#define FF_TAB_NEVT 8
 #define FF_TAB_DOUBLES (FF_TAB_HDR + 2 * FF_TAB_NMAX * FF_TAB_ROW)
 
 // sigma^(n)(a) as a polynomial in s = sigma(a): P_0 = s, P_{n+1} = P_n'(s) s (1 - s)
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(64) ff_table_header_kernel(ff_net net, double*
     tab[2] = (double)(32 * (1 << lg) + 1);
     tab[3] = bad ? 1.0 : 0.0;
     tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.6) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
+    for (int q = 5; q < FF_TAB_HDR; q++) tab[q] = 0.0;
   }
 }
 

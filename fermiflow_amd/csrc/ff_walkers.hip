@@ -347,6 +347,82 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
   return FF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Walker schedule: indices by descending cost class (two-pass counting sort, deterministic).
+// Every walker of the fused ODE kernels adapts its own step size; walkers that pass close to a point where a radius
+// vanishes need several times the usual number of steps.  Taking the expensive walkers first (and putting walkers of
+// equal cost into the same waves) keeps them out of the tail of a launch.  cost is clamped to [0, FF_ORD_BINS); ties
+// keep a fixed order (segment, thread, index).  Workspace: FF_ORD_BINS counters per FF_ORD_SEG walkers.
+#define FF_ORD_BINS 32
+#define FF_ORD_THREADS 256
+#define FF_ORD_SEG 2048
+FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
+
+// pass 1: per-segment histogram
+__global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t B, const int32_t* __restrict__ cost,
+                                                                        unsigned* __restrict__ hist) {
+  __shared__ unsigned h[FF_ORD_BINS];
+  const int t = threadIdx.x;
+  if (t < FF_ORD_BINS) h[t] = 0;
+  __syncthreads();
+  const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) atomicAdd(&h[ff_ord_row(cost[j0 + k])], 1u);
+  __syncthreads();
+  if (t < FF_ORD_BINS) hist[(int64_t)blockIdx.x * FF_ORD_BINS + t] = h[t];
+}
+
+// pass 2: position = (walkers in more expensive rows) + (same row, earlier segments) + (same row and segment, earlier
+// (thread, index)); the last term from per-thread counters, so no atomics decide an order
+__global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t B, const int32_t* __restrict__ cost,
+                                                                        const unsigned* __restrict__ hist, int nseg,
+                                                                        int32_t* __restrict__ order) {
+  __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
+  __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
+  __shared__ unsigned base[FF_ORD_BINS];
+  const int t = threadIdx.x, seg = blockIdx.x;
+  // row totals over all segments and over the earlier segments (thread t: row t % BINS, every (THREADS/BINS)-th segment)
+  {
+    constexpr int SL = FF_ORD_THREADS / FF_ORD_BINS;
+    const int row = t % FF_ORD_BINS, sl = t / FF_ORD_BINS;
+    unsigned a = 0, b = 0;
+    for (int k = sl; k < nseg; k += SL) {
+      const unsigned v = hist[(int64_t)k * FF_ORD_BINS + row];
+      a += v;
+      b += k < seg ? v : 0u;
+    }
+    tot[sl][row] = a;
+    before[sl][row] = b;
+  }
+  for (int k = 0; k < FF_ORD_BINS; k++) cnt[k][t] = 0;
+  const int64_t j0 = (int64_t)seg * FF_ORD_SEG;
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) cnt[ff_ord_row(cost[j0 + k])][t]++;
+  __syncthreads();
+  if (t == 0) {
+    unsigned run = 0;
+    for (int r = 0; r < FF_ORD_BINS; r++) {
+      unsigned a = 0, b = 0;
+      for (int sl = 0; sl < FF_ORD_THREADS / FF_ORD_BINS; sl++) { a += tot[sl][r]; b += before[sl][r]; }
+      base[r] = run + b;
+      run += a;
+    }
+  }
+  // exclusive scan of each row's per-thread counters: one wave-sized group of threads per row, serial over 4 chunks
+  {
+    const int row = t / (FF_ORD_THREADS / FF_ORD_BINS), part = t % (FF_ORD_THREADS / FF_ORD_BINS);
+    constexpr int PER = FF_ORD_BINS;   // THREADS / (THREADS / BINS) counters per thread
+    unsigned sum = 0;
+    for (int k = 0; k < PER; k++) sum += cnt[row][part * PER + k];
+    __syncthreads();
+    tot[part][row] = sum;              // tot is free again (base is final only after the barrier below)
+    __syncthreads();
+    unsigned off = base[row];
+    for (int q = 0; q < part; q++) off += tot[q][row];
+    for (int k = 0; k < PER; k++) { const unsigned c = cnt[row][part * PER + k]; cnt[row][part * PER + k] = off; off += c; }
+  }
+  __syncthreads();
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) order[cnt[ff_ord_row(cost[j0 + k])][t]++] = (int32_t)(j0 + k);
+}
+
 extern "C" {
 
 int ff_mcmc_sample_noise(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
@@ -426,6 +502,22 @@ int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, co
   FF_CHECK(n <= FF_MAX_N && d <= 3, FF_EUNSUPPORTED, "ff_potential: n > 24 or d > 3");
   if (B == 0) return FF_OK;
   FF_LAUNCH(ff_potential_kernel, ff_grid(B, 128), 128, stream, B, n, d, Z, use_ho, x, V);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+size_t ff_walker_order_workspace_bytes(int64_t B) {
+  return sizeof(unsigned) * FF_ORD_BINS * (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
+}
+
+int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {
+  FF_CHECK(B >= 0 && (B == 0 || (cost && order && workspace)), FF_EINVAL, "ff_walker_order: bad argument");
+  FF_CHECK(B < ((int64_t)1 << 31), FF_EUNSUPPORTED, "ff_walker_order: B >= 2^31");
+  if (B == 0) return FF_OK;
+  const int nseg = (int)((B + FF_ORD_SEG - 1) / FF_ORD_SEG);
+  FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace);
+  FF_LAUNCH_CHECK();
+  FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -38,9 +38,23 @@ typedef struct ff_ode {
   double t0, t1;      /* CNF t_span (src/flow.py:7-40) */
   double rtol, atol;
   int32_t max_steps;  /* safety bound on accepted+rejected steps per walker (0 -> 10000) */
+  /* Scheduling aids, both optional (NULL).  Every walker adapts its own step size, so a few walkers (a radius close to
+   * zero) need several times the usual number of steps; taking those first keeps them out of the tail of the launch.
+   * walker_cost (out, B): a cost class in [0, 32) for integrating along this walker's trajectory again:
+   *   min(31, steps attempted in this call + max(0, -log2(r_min^2) - 1)),  r_min = the smallest pair or one-body radius
+   *   any stage of the call saw (the backflow field is only C^1 where a radius vanishes, so its second-order
+   *   sensitivities -- the local-energy pass -- need many small steps near such points even when this call did not;
+   *   ff_cnf_adjoint reports the attempted steps only).
+   * walker_order (in, B): a permutation of 0..B-1 (ff_walker_order); workgroups take walkers in this order.
+   * Results are written to each walker's own slot, so the order changes timing only. */
+  int32_t* walker_cost;
+  const int32_t* walker_order;
 } ff_ode;
 
 int ff_version(void);
+/* order (B) = walker indices sorted by descending cost (ties in a fixed order; classes above 31 count as 31); cost (B) >= 0, e.g. ff_ode.walker_cost. */
+size_t ff_walker_order_workspace_bytes(int64_t B);
+int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);
 const char* ff_last_error(void);
 
 /* ---- Slater determinants / base distribution ------------------------------------------------ */

@@ -40,6 +40,7 @@ template <class T> inline T ff_sim_atomic_add(T* p, T v) {
 }
 inline double atomicAdd(double* p, double v) { return ff_sim_atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return ff_sim_atomic_add(p, v); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return ff_sim_atomic_add(p, v); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return ff_sim_atomic_add(p, v); }
 inline int atomicOr(int* p, int v) { std::atomic_ref<int> a(*p); return a.fetch_or(v); }
 inline int atomicMax(int* p, int v) {

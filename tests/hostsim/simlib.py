@@ -19,7 +19,7 @@ class FFNet(C.Structure):
 
 class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
-                ("max_steps", C.c_int32)]
+                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p)]
 
 
 def build():
@@ -145,39 +145,49 @@ def mlp(r, w1, b1, w2):
     return v, dv
 
 
-def _ode(t0, t1, rtol, atol):
-    return FFOde(t0, t1, rtol, atol, 0)
+def _ode(t0, t1, rtol, atol, steps=None, order=None):
+    return FFOde(t0, t1, rtol, atol, 0, steps.ctypes.data if steps is not None else None,
+                 order.ctypes.data if order is not None else None)
 
 
-def cnf_generate(z, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+def walker_order(cost):
+    cost = _i(cost); order = np.empty_like(cost)
+    lib().ff_walker_order_workspace_bytes.restype = C.c_size_t
+    ws = np.zeros(lib().ff_walker_order_workspace_bytes(C.c_int64(len(cost))) // 4, dtype=np.int32)
+    _ck(lib().ff_walker_order(None, C.c_int64(len(cost)), _p(cost), _p(order), _p(ws)))
+    return order
+
+
+def cnf_generate(z, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=None, order=None):
     z = _d(z); B, n, d = z.shape
-    x = np.empty_like(z); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    x = np.empty_like(z); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol, steps, order)
     _ck(lib().ff_cnf_generate(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z), _p(x), _p(stats)))
     return x, stats
 
 
-def cnf_delta_logp(x, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+def cnf_delta_logp(x, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=None, order=None):
     x = _d(x); B, n, d = x.shape
-    z = np.empty_like(x); dl = np.empty(B); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    z = np.empty_like(x); dl = np.empty(B); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol, steps, order)
     _ck(lib().ff_cnf_delta_logp(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(x), _p(z), _p(dl), _p(stats)))
     return z, dl, stats
 
 
-def cnf_adjoint(z0, a_z, a_d, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+def cnf_adjoint(z0, a_z, a_d, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=None, order=None):
     z0, a_z, a_d = _d(z0), _d(a_z), _d(a_d); B, n, d = z0.shape
-    gx = np.empty_like(z0); gp = np.empty(net.nparams); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    gx = np.empty_like(z0); gp = np.empty(net.nparams); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol, steps, order)
     ws = np.zeros(max(1, lib().ff_cnf_adjoint_workspace_bytes(C.c_int64(B), n, d, net.c.He, net.c.Hm) // 8))
     _ck(lib().ff_cnf_adjoint(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z0), _p(a_z), _p(a_d),
                              _p(gx), _p(gp), _p(ws), _p(stats)))
     return gx, gp, stats
 
 
-def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None):
+def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None,
+         steps=None, order=None):
     x = _d(x); B = x.shape[0]; n = nup + ndn
     tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
     o = dict(logp=np.empty(B), grad=np.empty_like(x), lap=np.empty(B), V=np.empty(B), eloc=np.empty(B),
              z=np.empty_like(x), dlogp=np.empty(B), glogp0=np.empty_like(x))
-    stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol, steps, order)
     wk = np.zeros(lib().ff_eloc_workspace_bytes(C.c_int64(B), n, 2) // 8)
     _ck(lib().ff_eloc(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), C.byref(net.c), C.byref(ode), C.c_double(Z),
                       int(use_ho), _p(x), _p(o["logp"]), _p(o["grad"]), _p(o["lap"]), _p(o["V"]), _p(o["eloc"]),

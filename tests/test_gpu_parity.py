@@ -380,3 +380,42 @@ def test_other_particle_numbers_vs_oracle(golden, dev, nup, ndn):
     _, g0o, _ = O.logprob(zo, nup, ndn)
     _, gpo, _ = O.cnf_adjoint(zo, dlo, N(w)[:, None, None] * g0o, -N(w), net, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
+
+
+# ------------------------------------------------------------------------------------------------ walker schedule
+def test_walker_schedule_is_invisible_in_the_results(dev):
+    """ff_ode.walker_cost / walker_order, ff_walker_order: the cost classes the flow pass reports put the walkers in
+    descending order of cost; running the local-energy pass and the adjoint in that order leaves every per-walker
+    result bit-identical (order changes timing only) and the parameter gradient equal to rounding."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    B = 20000
+    torch.manual_seed(5)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    cost = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost)
+    assert torch.equal(x, native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8))
+    assert int(cost.min()) >= 1 and int(cost.max()) <= 31
+    order = native.walker_order(cost)
+    assert torch.equal(order.long().sort().values, torch.arange(B, device=dev))
+    c = cost[order.long()]
+    assert bool((c[:-1] >= c[1:]).all())
+    assert torch.equal(order, native.walker_order(cost))
+    steps0, steps1 = torch.empty_like(cost), torch.empty_like(cost)
+    r0 = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, walker_cost=steps0)
+    r1 = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, walker_cost=steps1, walker_order=order)
+    for k in ("logp", "grad", "lap", "V", "eloc", "z", "dlogp", "glogp0"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.equal(steps0, steps1)
+    # the predictor does its job: the walkers the flow pass marks expensive are the ones the sensitivity pass works on longest
+    top = order[: B // 100].long()
+    assert steps0[top].double().mean() > 1.5 * steps0.double().mean()
+    w = (r0["eloc"] - r0["eloc"].mean()) / B
+    gx0, gp0 = native.cnf_adjoint(net, r0["z"], w[:, None, None] * r0["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8)
+    gx1, gp1 = native.cnf_adjoint(net, r0["z"], w[:, None, None] * r0["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
+                                  walker_order=native.walker_order(steps0))
+    assert torch.equal(gx0, gx1)
+    assert (gp0 - gp1).abs().max().item() <= 1e-12 * gp0.abs().max().item()

@@ -173,3 +173,40 @@ def test_split_column_eloc_kernel(nup, ndn, B):
         np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-8)
         np.testing.assert_allclose(r["grad"], ref["grad"], atol=1e-8)
         np.testing.assert_allclose(r["lap"], ref["lap"], rtol=1e-7)
+
+
+def test_walker_schedule_changes_nothing_but_the_order_of_work(golden):
+    """ff_ode.walker_cost / walker_order + ff_walker_order: a permutation by descending cost; every walker's results
+    are bit-identical whatever the processing order (each walker adapts its own steps, so its arithmetic does not
+    depend on its wave-mates), only the parameter gradient (a sum over walkers) moves by rounding."""
+    G = golden["g5_gsvmc"]
+    name = "z2_nt"
+    eta, mu = net_arrays(G, name + "_")
+    x = G[name + "_x"][:13]
+    B = len(x)
+    cost = np.array([3, 7, 7, 0, 40, 5, 31, 5, 2, 99, 7, 1, 5], dtype=np.int32)
+    order = S.walker_order(cost)
+    assert sorted(order.tolist()) == list(range(B))
+    c = np.clip(cost[order], 0, 31)
+    assert np.all(c[:-1] >= c[1:])
+    big = np.random.default_rng(3).integers(-2, 40, size=7001).astype(np.int32)      # several segments, ragged tail
+    ob = S.walker_order(big)
+    cb = np.clip(big[ob], 0, 31)
+    assert sorted(ob.tolist()) == list(range(len(big))) and np.all(cb[:-1] >= cb[1:])
+    assert np.array_equal(ob, S.walker_order(big))                                   # deterministic
+    for table in (False, True):
+        net = S.Net(eta, mu, table=table)
+        st0, st1 = np.full(B, -1, np.int32), np.full(B, -1, np.int32)
+        x0, _ = S.cnf_generate(x, net, steps=st0)
+        x1, _ = S.cnf_generate(x, net, steps=st1, order=order)
+        assert np.array_equal(x0, x1) and np.array_equal(st0, st1) and st0.min() >= 1
+        r0 = S.eloc(x, 3, 3, net, 2.0, steps=st0)
+        r1 = S.eloc(x, 3, 3, net, 2.0, steps=st1, order=S.walker_order(st0))
+        for k in ("eloc", "grad", "lap", "z", "dlogp", "glogp0"):
+            assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(st0, st1)
+        w = (r0["eloc"] - r0["eloc"].mean()) / B
+        gx0, gp0, _ = S.cnf_adjoint(r0["z"], w[:, None, None] * r0["glogp0"], -w, net, steps=st0)
+        gx1, gp1, _ = S.cnf_adjoint(r0["z"], w[:, None, None] * r0["glogp0"], -w, net, steps=st1, order=S.walker_order(st0))
+        assert np.array_equal(gx0, gx1) and np.array_equal(st0, st1)
+        np.testing.assert_allclose(gp1, gp0, rtol=1e-10, atol=1e-14)
