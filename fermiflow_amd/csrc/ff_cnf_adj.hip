@@ -370,7 +370,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
         __syncthreads();
         if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
-        const int any = s_any;
+        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
         if (!any) break;
         s = (any & 2) ? 0 : 1;   // somebody rejected: the whole wave passes through stage 0
       }
@@ -730,7 +730,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         __syncthreads();
         if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
-        const int any = s_any;
+        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }

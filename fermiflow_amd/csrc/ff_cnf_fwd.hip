@@ -148,6 +148,17 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const int64_t ngroups = (A.B + G - 1) / G;
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
+  // the radii this lane evaluates in the radius phase (slot qk: radius lane + 64 qk of the wave's G*nrad), fixed for the
+  // whole launch: walker slot, particles, radius index packed into one register each
+  constexpr int NQ = (G * R + FF_WAVE - 1) / FF_WAVE;
+  int rq_id[NQ];
+#pragma unroll
+  for (int qk = 0; qk < NQ; qk++) {
+    const int q = lane + qk * FF_WAVE;
+    const bool act = q < G * nrad;
+    const int qg = act ? q / nrad : 0, p = act ? q - qg * nrad : 0;
+    rq_id[qk] = act ? (qg | (s_pa[p] << 4) | ((s_pb[p] < 0 ? 15 : s_pb[p]) << 8) | (p << 12)) : -1;   // N <= 12, G <= 16
+  }
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
   const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_readcyclecounter() * 0 + wall_clock64();
@@ -177,9 +188,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     S.begin(A.ta, A.tb, valid);
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
-    double rmin_q[(G * R + FF_WAVE - 1) / FF_WAVE];   // this lane's radii keep their slots from evaluation to evaluation
+    double rmin_q[NQ];   // this lane's radii keep their slots from evaluation to evaluation
 #pragma unroll
-    for (int k = 0; k < (G * R + FF_WAVE - 1) / FF_WAVE; k++) rmin_q[k] = 1e300;
+    for (int k = 0; k < NQ; k++) rmin_q[k] = 1e300;
 
     // group-wide sum of a per-lane partial (all lanes of a walker get the identical result)
     auto group_sum = [&](double part) -> double {
@@ -231,30 +242,59 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       __syncthreads();
       FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase
+      // (two halves: every radius of the wave is formed and -- table kernels -- its table row requested before the
+      //  first one is evaluated, so the passes over the G*R radii share one memory round trip)
+      double rq_rho[NQ][D], rq_dk[JET ? NQ : 1][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
+      bool rq_ok[NQ];
 #pragma unroll
-      for (int qk = 0; qk < (G * R + FF_WAVE - 1) / FF_WAVE; qk++) {
-        const int q = lane + qk * FF_WAVE;
-        if (q >= G * nrad) break;
-        const int qg = q / nrad, p = q - qg * nrad;
-        const int a = s_pa[p], bb = s_pb[p];
-        const bool pair = bb >= 0;
-        double rho[D], r2 = 0.0;
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        const bool act = id >= 0;
+        const int qg = act ? (id & 15) : 0, a = act ? ((id >> 4) & 15) : 0, bq = act ? ((id >> 8) & 15) : 15;
+        const bool pair = bq != 15;
+        const int bb = pair ? bq : a;
+        double r2 = 0.0;
 #pragma unroll
         for (int c = 0; c < D; c++) {
-          rho[c] = s_z[qg][a * D + c] - (pair ? s_z[qg][bb * D + c] : 0.0);
-          r2 = fma(rho[c], rho[c], r2);
+          rq_rho[qk][c] = s_z[qg][a * D + c] - (pair ? s_z[qg][bb * D + c] : 0.0);
+          if constexpr (JET) rq_dk[qk][c] = s_kb[qg][a * D + c] - (pair ? s_kb[qg][bb * D + c] : 0.0);
+          r2 = fma(rq_rho[qk][c], rq_rho[qk][c], r2);
         }
-        const double r = sqrt(r2);
-        rmin_q[qk] = fmin(rmin_q[qk], r);
+        ff_sqrt_rcp(r2, rq_r[qk], rq_ri[qk]);
+        if (act) rmin_q[qk] = fmin(rmin_q[qk], rq_r[qk]);
+        rq_dr[qk] = 0.0;
+        rq_ok[qk] = true;
+        if constexpr (TAB) {
+          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[qk], rq_T[qk], rq_dr[qk]);
+          if (act && !rq_ok[qk]) off_table = true;
+        }
+      }
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int qg = id & 15, a = (id >> 4) & 15, bq = (id >> 8) & 15, p = id >> 12;
+        const bool pair = bq != 15;
+        const int bb = pair ? bq : a;
+        const double* rho = rq_rho[qk];
+        const double r = rq_r[qk], ri = rq_ri[qk];
         double hd[NH];
-        heads(pair ? 0 : 1, r, hd);
+        if constexpr (TAB) {
+          if (rq_ok[qk]) ff_table_eval<NH>(rq_T[qk], rq_dr[qk], hd);
+          else {
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          heads(pair ? 0 : 1, r, hd);
+        }
         if constexpr (!JET) {
           s_rr[qg][p][0] = r;
-          s_rr[qg][p][1] = ff_rcp(r);
+          s_rr[qg][p][1] = ri;
 #pragma unroll
           for (int m = 0; m < NH; m++) s_hd[qg][p][m] = hd[m];
         } else {
-          const double ri = ff_rcp(r), cf = pair ? 2.0 : 1.0;
+          const double cf = pair ? 2.0 : 1.0;
           const double f0 = hd[0], f1 = hd[1], f2 = hd[NH > 2 ? 2 : 0], f3 = hd[NH > 3 ? 3 : 0];
           const double Ac = cf * fma(f2, r, (1.0 + D) * f1), Bc = cf * fma(f3, r, (2.0 + D) * f2);
           double* rec = &s_rec[qg * RECS + p * RECW];
@@ -263,15 +303,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           rec[D] = ri; rec[D + 1] = f0; rec[D + 2] = f1; rec[D + 3] = f2; rec[D + 4] = Ac; rec[D + 5] = Bc;
           rec[D + 6] = cf * fma(f1, r, D * f0);                 // this radius' share of div v
           // own-row contributions of this radius: +x to particle a from partner bb, -x to particle bb from partner a
-          double dk[D], rdk = 0.0;
+          const double* dk = rq_dk[qk];
+          double rdk = 0.0;
 #pragma unroll
-          for (int c = 0; c < D; c++) {
-            dk[c] = s_kb[qg][a * D + c] - (pair ? s_kb[qg][bb * D + c] : 0.0);
-            rdk = fma(rho[c], dk[c], rdk);
-          }
+          for (int c = 0; c < D; c++) rdk = fma(rho[c], dk[c], rdk);
           const double F1k = f1 * (rdk * ri), gq = Ac * ri;
-          double* Ta = &s_qt[qg * M * QTW + a * TROW + (pair ? bb : a) * 3 * D];
-          double* Tb = &s_qt[qg * M * QTW + (pair ? bb : a) * TROW + a * 3 * D];
+          double* Ta = &s_qt[qg * M * QTW + a * TROW + bb * 3 * D];
+          double* Tb = &s_qt[qg * M * QTW + bb * TROW + a * 3 * D];
 #pragma unroll
           for (int c = 0; c < D; c++) {
             const double pv = f0 * rho[c], pw = fma(F1k, rho[c], f0 * dk[c]), pg = gq * rho[c];
@@ -491,7 +529,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         __syncthreads();
         if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
-        const int any = s_any;
+        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
@@ -500,9 +538,8 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     // ---------------------------------------------------------------------- results
     if (A.wcost) {   // wave-uniform
 #pragma unroll
-      for (int qk = 0; qk < (G * R + FF_WAVE - 1) / FF_WAVE; qk++) {
-        const int q = lane + qk * FF_WAVE;
-        if (q < G * nrad) s_rmin[q / nrad][q % nrad] = rmin_q[qk];
+      for (int qk = 0; qk < NQ; qk++) {
+        if (rq_id[qk] >= 0) s_rmin[rq_id[qk] & 15][rq_id[qk] >> 12] = rmin_q[qk];
       }
       __syncthreads();
     }
@@ -874,7 +911,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         __syncthreads();
         if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
         __syncthreads();
-        const int any = s_any;
+        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }

@@ -62,6 +62,21 @@ FF_D double ff_rcp(double x) {
 #endif
 }
 
+// r = sqrt(r2) and 1/r from one v_rsq_f64 + two Newton steps (r within ~1 ulp; r2 = 0 gives r = 0, 1/r = inf)
+FF_D void ff_sqrt_rcp(double r2, double& r, double& ri) {
+#ifdef FF_HOSTSIM
+  r = sqrt(r2);
+  ri = 1.0 / r;
+#else
+  double y = __builtin_amdgcn_rsq(r2);
+  const double hx = 0.5 * r2;
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  ri = y;
+  r = r2 > 0.0 ? r2 * y : 0.0;
+#endif
+}
+
 // --- exp for |x| <= 708.  Rounding and scaling use the integer pipe instead of the quarter-rate
 //     v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64: adding 1.5*2^52 leaves round(x*log2e) in the low mantissa word, and
 //     2^k is applied by adding k to the exponent field (the polynomial value is in [0.7,1.42], |k| <= 1010: always normal).

@@ -117,16 +117,21 @@ __global__ void __launch_bounds__(128) ff_table_build_kernel(ff_net net, double*
 
 #endif  // FF_RADIAL_BUILD_KERNELS
 
-// NH derivative heads of net t (0 eta, 1 mu) at radius r from the table; returns false if r is off the table
+// NH derivative heads of net t (0 eta, 1 mu) at radius r from the table, in two halves so that a caller can put other
+// work (or a second fetch) between the loads and their use.  fetch returns false if r is off the table.
 template <int NH>
-FF_D bool ff_heads_table(const double* __restrict__ tab, double inv_h, double h, int t, double r, double* hd) {
+FF_D bool ff_table_fetch(const double* __restrict__ tab, double inv_h, double h, int t, double r, double* T, double& dr) {
   if (!(r < FF_TAB_RMAX)) return false;
   const double jf = rint(r * inv_h);
-  const double dr = fma(-jf, h, r);
+  dr = fma(-jf, h, r);
   const double* __restrict__ row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + (int)jf) * FF_TAB_ROW;
-  double T[NH + 5];
 #pragma unroll
   for (int e = 0; e < NH + 5; e++) T[e] = row[e];
+  return true;
+}
+
+template <int NH>
+FF_D void ff_table_eval(const double* T, double dr, double* hd) {
   const double d2 = dr * 0.5, d3 = dr * (1.0 / 3.0), d4 = dr * 0.25, d5 = dr * 0.2;
 #pragma unroll
   for (int m = 0; m < NH; m++) {
@@ -136,5 +141,12 @@ FF_D bool ff_heads_table(const double* __restrict__ tab, double inv_h, double h,
     v = fma(v, d2, T[m + 1]);
     hd[m] = fma(v, dr, T[m]);
   }
+}
+
+template <int NH>
+FF_D bool ff_heads_table(const double* __restrict__ tab, double inv_h, double h, int t, double r, double* hd) {
+  double T[NH + 5], dr;
+  if (!ff_table_fetch<NH>(tab, inv_h, h, t, r, T, dr)) return false;
+  ff_table_eval<NH>(T, dr, hd);
   return true;
 }
