@@ -366,11 +366,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
               tent[t][j][c] = acc ? FF_B0 * cur[t][j][c] : 0.0;   // FSAL: k6_theta opens the next step
             }
         S.plan();
-        if (lane == 0) s_any = 0;
-        __syncthreads();
-        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
-        __syncthreads();
-        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
+        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;   // somebody rejected: the whole wave passes through stage 0
       }
@@ -726,11 +722,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           }
         }
         S.plan();
-        if (lane == 0) s_any = 0;
-        __syncthreads();
-        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
-        __syncthreads();
-        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
+        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }

@@ -161,6 +161,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   }
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long stage_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stage_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_readcyclecounter() * 0 + wall_clock64();
 #endif
 
@@ -446,6 +447,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       }
       FF_STAMP(4);
       // ------------------------------------------------------------------ consume
+#if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
+      const int s_prev = s;
+#endif
       if (s == -2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
@@ -525,14 +529,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         }
         S.plan();
         // wave-wide: anybody still integrating?  anybody rejected (then everyone passes through stage 0)?
-        if (lane == 0) s_any = 0;
-        __syncthreads();
-        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
-        __syncthreads();
-        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
+        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
+#if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
+      { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stage_acc[s_prev + 2] += t_ - stamp_prev; stage_cnt[s_prev + 2]++; }
+#endif
       FF_STAMP(5);
     }
     // ---------------------------------------------------------------------- results
@@ -574,6 +577,13 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     A.stats[26] = (int)(__builtin_amdgcn_s_memtime() - stamp_t0);
     A.stats[27] = (int)(wall_clock64() - stamp_r0);
   }
+#ifdef FF_STAMPS_TRACE
+  if (A.stats && lane == 0)   // consume-phase ticks and counts by stage, behind the per-workgroup trace
+    for (int q = 0; q < 9; q++) {
+      atomicAdd((unsigned long long*)(A.stats + 65600) + q, stage_acc[q]);
+      atomicAdd((unsigned long long*)(A.stats + 65600) + 9 + q, stage_cnt[q]);
+    }
+#endif
 #ifdef FF_STAMPS_TRACE   // per-workgroup (start, end, core ticks, hw id) behind the 32 stats words: tools/kbench.py --trace
   if (A.stats && lane == 0 && blockIdx.x < 16384) {
     int* t = A.stats + 32 + 4 * blockIdx.x;
@@ -907,11 +917,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
           for (int v = 0; v < NV; v++) { y[v] = in[v]; c0[v] = out[v]; }
         }
         S.plan();
-        if (lane == 0) s_any = 0;
-        __syncthreads();
-        if (!S.done) atomicOr(&s_any, (was_active && !acc) ? 3 : 1);
-        __syncthreads();
-        const int any = FF_UNIFORM(s_any);   // wave-uniform by construction: keeps the stage index in a scalar register
+        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }

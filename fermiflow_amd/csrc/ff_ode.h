@@ -156,6 +156,24 @@ FF_D double ff_pow02(double x, float e) {
 #endif
 }
 
+// Wave-wide OR of per-lane flag words (bit 0: still integrating, bit 1: just rejected a step); wave-uniform result.
+// On the GPU two ballots -- no LDS traffic, no barrier (64 lanes OR-ing into one LDS word serialise: that cost ~10 % of
+// the local-energy kernel).  The host simulator (one thread per lane) goes through the shared word.
+FF_D int ff_wave_or(int* s_any, int lane, int flags) {
+#ifdef FF_HOSTSIM
+  if (lane == 0) *s_any = 0;
+  __syncthreads();
+  if (flags) atomicOr(s_any, flags);
+  __syncthreads();
+  const int any = *s_any;
+  __syncthreads();
+  return any;
+#else
+  const unsigned long long b1 = __ballot((flags & 1) != 0), b2 = __ballot((flags & 2) != 0);
+  return (b1 ? 1 : 0) | (b2 ? 2 : 0);
+#endif
+}
+
 // per-walker step-size bookkeeping (identical on all lanes of a walker's group)
 struct ff_stepper {
   double t, tb, dir, interval, habs, h, tnew;

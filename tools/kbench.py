@@ -85,6 +85,9 @@ if r["stats"].numel() > 32:   # per-workgroup trace of the local-energy kernel (
     res["trace"]["per_xcc_blocks"] = np.bincount(xcc, minlength=8).tolist()
     res["trace"]["per_xcc_mean_dur"] = [round(float(dur[xcc == k].mean()), 1) if (xcc == k).any() else 0 for k in range(8)]
     np.save(os.path.join(ROOT, "gpurun_out", "trace.npy"), t)
+    if r["stats"].numel() >= 65600 + 36:
+        sa = r["stats"][65600:65636].view(torch.int64).double()
+        res["consume_ticks_by_stage(-2..6)"] = [round(float(a / max(1.0, float(c)))) for a, c in zip(sa[:9], sa[9:])]
 res["E"] = r["eloc"].mean().item()
 res["gp_norm"] = gp.norm().item()
 print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))
