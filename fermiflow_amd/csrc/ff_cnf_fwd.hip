@@ -614,7 +614,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 // pairs half each.  z_i, kbar_i and the own-coordinate picks live on the lane whose half contains particle(i).
 // Delta, grad Delta and lap Delta are kept as per-lane partial sums (their equations are linear) and combined at the
 // end.  L = 2M lanes per walker, G = 64 / L walkers per wave.
-template <int N, int D>
+template <int N, int D, bool TAB>
 __global__ void __launch_bounds__(FF_WAVE)
 ff_eloc_split_kernel(ff_fwd_args A) {
   static_assert(N % 2 == 0, "split kernel needs an even particle number");
@@ -623,13 +623,20 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   constexpr int NV = MH + 5;   // [0] z_i (owner lanes), [1..MH] u half, [MH+1] kbar_i (owner), [MH+2] dDelta part, [MH+3] Delta part, [MH+4] lap part
   static_assert(G >= 1, "walker does not fit a wave");
 
-  __shared__ ff_wtab s_w[2][FF_HPAD];
-  __shared__ double s_e2[64];
+  constexpr int NH = 4;
+  __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
+  __shared__ double s_e2[TAB ? 1 : 64];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][L];
   __shared__ double s_u[G][M][M + 1];
-  __shared__ __attribute__((aligned(16))) double s_rr[G][R][2];
-  __shared__ __attribute__((aligned(16))) double s_hd[G][R][4];
-  __shared__ double s_q[G][M][2][MH + 1];
+  // one record per radius, as in ff_ode_fwd_kernel: rho (D), 1/r, eta, eta', eta'', A, B, share of div v
+  constexpr int RECW = (D + 7 + 1) & ~1;
+  constexpr int RECS0 = R * RECW, RECS = RECS0 + ((RECS0 % 4 == 2) ? 0 : ((RECS0 % 4 == 0) ? 2 : 1));
+  __shared__ __attribute__((aligned(16))) double s_rec[G * RECS];
+  // s_qt: first T[g][a][j][3][D] (own-row contributions of partner j to particle a, j = a: one-body), gathered before the
+  // sweep; then the transposition buffer [g][i][h][MH+1] of the quadratic sources
+  constexpr int TROW = N * 3 * D + 1;
+  constexpr int QTS = (N * TROW > M * 2 * (MH + 1)) ? N * TROW : M * 2 * (MH + 1);
+  __shared__ double s_qt[G * QTS];
   __shared__ double s_yv[NV][FF_WAVE], s_cv[NV][FF_WAVE];
   __shared__ int s_pa[R], s_pb[R], s_any;
 
@@ -641,8 +648,18 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   const int ai = i / D, ci = i % D;              // particle / component of direction i
   const bool owner = (ai / NP) == h;             // this lane carries z_i, kbar_i and the own-coordinate picks
   const int la = owner ? ai - h * NP : -1;       // local index of particle(i) inside this half
-  ff_load_weights(s_w, A.net, lane);
-  ff_fill_exp2_table(s_e2, lane);
+  const double* __restrict__ rtab = A.net.radial_table;
+  if constexpr (TAB) {
+    if (rtab[3] != 0.0) {
+      if (lane == 0 && blockIdx.x == 0) *A.evt = A.evt_id;
+      return;
+    }
+  } else {
+    if (A.evt && *A.evt != A.evt_id) return;
+    ff_load_weights(s_w, A.net, lane);
+    ff_fill_exp2_table(s_e2, lane);
+  }
+  bool off_table = false;
   if (lane == 0) {
     int p = 0;
     for (int a = 0; a < N; a++)
@@ -653,10 +670,17 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? R : P;
-  const double* __restrict__ rtab = A.net.radial_table;
-  const bool use_tab = rtab != nullptr && rtab[3] == 0.0;
-  const double tab_inv_h = use_tab ? rtab[0] : 0.0, tab_h = use_tab ? rtab[1] : 0.0;
+  const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
   const double rtol = A.rtol, atol = A.atol;
+  constexpr int NQ = (G * R + FF_WAVE - 1) / FF_WAVE;
+  int rq_id[NQ];   // the radii this lane evaluates: walker slot | particle a << 4 | particle b (15: none) << 8 | radius << 12
+#pragma unroll
+  for (int qk = 0; qk < NQ; qk++) {
+    const int q = lane + qk * FF_WAVE;
+    const bool act = q < G * nrad;
+    const int qg = act ? q / nrad : 0, p = act ? q - qg * nrad : 0;
+    rq_id[qk] = act ? (qg | (s_pa[p] << 4) | ((s_pb[p] < 0 ? 15 : s_pb[p]) << 8) | (p << 12)) : -1;
+  }
   constexpr double NT = 2.0 * M + (double)M * M + 3.0 * L;   // z, kbar (owners), u, and three partial scalars per lane
   const int64_t ngroups = (A.B + G - 1) / G;
   long long ev_sum = 0;
@@ -716,80 +740,121 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       }
       __syncthreads();
       // ------------------------------------------------------------------ radius phase (lane <-> radius)
-      for (int q = lane; q < G * nrad; q += FF_WAVE) {
-        const int qg = q / nrad, p = q - qg * nrad;
-        const int a = s_pa[p], bb = s_pb[p];
+      double rq_rho[NQ][D], rq_dk[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
+      bool rq_ok[NQ];
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        const bool act = id >= 0;
+        const int qg = act ? (id & 15) : 0, a = act ? ((id >> 4) & 15) : 0, bq = act ? ((id >> 8) & 15) : 15;
+        const bool pair = bq != 15;
+        const int bb = pair ? bq : a;
         double r2 = 0.0;
 #pragma unroll
         for (int c = 0; c < D; c++) {
-          double t = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
-          r2 = fma(t, t, r2);
+          rq_rho[qk][c] = s_z[qg][a * D + c] - (pair ? s_z[qg][bb * D + c] : 0.0);
+          rq_dk[qk][c] = s_kb[qg][a * D + c] - (pair ? s_kb[qg][bb * D + c] : 0.0);
+          r2 = fma(rq_rho[qk][c], rq_rho[qk][c], r2);
         }
-        const double r = sqrt(r2);
-        double hd[4];
-        if (!(use_tab && ff_heads_table<4>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd)))
-          ff_heads<4, true>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
-        s_rr[qg][p][0] = r;
-        s_rr[qg][p][1] = ff_rcp(r);
+        ff_sqrt_rcp(r2, rq_r[qk], rq_ri[qk]);
+        rq_dr[qk] = 0.0;
+        rq_ok[qk] = true;
+        if constexpr (TAB) {
+          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[qk], rq_T[qk], rq_dr[qk]);
+          if (act && !rq_ok[qk]) off_table = true;
+        }
+      }
 #pragma unroll
-        for (int m = 0; m < 4; m++) s_hd[qg][p][m] = hd[m];
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int qg = id & 15, a = (id >> 4) & 15, bq = (id >> 8) & 15, p = id >> 12;
+        const bool pair = bq != 15;
+        const int bb = pair ? bq : a;
+        const double* rho = rq_rho[qk];
+        const double* dk = rq_dk[qk];
+        const double r = rq_r[qk], ri = rq_ri[qk];
+        double hd[NH];
+        if constexpr (TAB) {
+          if (rq_ok[qk]) ff_table_eval<NH>(rq_T[qk], rq_dr[qk], hd);
+          else {
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, r, hd);
+        }
+        const double cf = pair ? 2.0 : 1.0;
+        const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
+        const double Ac = cf * fma(f2, r, (1.0 + D) * f1), Bc = cf * fma(f3, r, (2.0 + D) * f2);
+        double* rec = &s_rec[qg * RECS + p * RECW];
+#pragma unroll
+        for (int c = 0; c < D; c++) rec[c] = rho[c];
+        rec[D] = ri; rec[D + 1] = f0; rec[D + 2] = f1; rec[D + 3] = f2; rec[D + 4] = Ac; rec[D + 5] = Bc;
+        rec[D + 6] = cf * fma(f1, r, D * f0);
+        double rdk = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) rdk = fma(rho[c], dk[c], rdk);
+        const double F1k = f1 * (rdk * ri), gq = Ac * ri;
+        double* Ta = &s_qt[qg * QTS + a * TROW + bb * 3 * D];
+        double* Tb = &s_qt[qg * QTS + bb * TROW + a * 3 * D];
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          const double pv = f0 * rho[c], pw = fma(F1k, rho[c], f0 * dk[c]), pg = gq * rho[c];
+          Ta[c] = pv; Ta[D + c] = pw; Ta[2 * D + c] = pg;
+          if (pair) { Tb[c] = -pv; Tb[D + c] = -pw; Tb[2 * D + c] = -pg; }
+        }
       }
       __syncthreads();
       nev++;
-      // ------------------------------------------------------------------ jet sweep over this half's particles
+      // ------------------------------------------------------------------ own rows (owner lanes), then the jet sweep
+      double ddiv = 0.0, qdiv = 0.0, divv = 0.0, vi = 0.0, dvk = 0.0, gdi = 0.0;
+      {
+        const double* T = &s_qt[gg * QTS + ai * TROW + ci];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+          const bool use = owner && (has_mu || j != ai);
+          const double tv = T[j * 3 * D], tw = T[j * 3 * D + D], tg = T[j * 3 * D + 2 * D];
+          vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
+        }
+      }
+      __syncthreads();   // s_qt is reused by the transposition below
       double du[MH], qv[MH];
 #pragma unroll
       for (int k = 0; k < MH; k++) { du[k] = 0.0; qv[k] = 0.0; }
-      double ddiv = 0.0, qdiv = 0.0, divv = 0.0, vi = 0.0, dvk = 0.0, gdi = 0.0;
       const double* u = &in[1];
-      const double* zm = s_z[gg] + h * MH;          // my half's coordinates / kbar
-      const double* km = s_kb[gg] + h * MH;
-      const double* zo = s_z[gg] + (1 - h) * MH;    // the other half's
-      const double* ko = s_kb[gg] + (1 - h) * MH;
       const double* uo = s_u[gg][i] + (1 - h) * MH;  // partner lane's half of u_i
       const int pbase = h * NP, obase = (1 - h) * NP;
-      // one radius term; TWO: both particles are mine (accumulate both sides); wsc: weight of the scalar sources
-      auto term = [&](const double* rho, const double* dl, const double* dk, int p, int m1, int m2, bool two, double cf, double wsc,
-                      double sgn) {
-        double rd = 0.0, dd = 0.0, rdk = 0.0;
+      const double sg = h ? -1.0 : 1.0;              // records hold rho = z_a - z_b with a < b; half 1's particles are the b's
+      // one radius term; two: both particles are mine (accumulate both sides); wsc: weight of the scalar sources
+      auto term = [&](const double* rho, const double* dl, const double* rec, int m1, int m2, bool two, bool halfw) {
+        double rd = 0.0, dd = 0.0;
 #pragma unroll
-        for (int c = 0; c < D; c++) { rd = fma(rho[c], dl[c], rd); dd = fma(dl[c], dl[c], dd); rdk = fma(rho[c], dk[c], rdk); }
-        const double r = s_rr[gg][p][0], ri = s_rr[gg][p][1];
-        const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2], f3 = s_hd[gg][p][3];
+        for (int c = 0; c < D; c++) { rd = fma(rho[c], dl[c], rd); dd = fma(dl[c], dl[c], dd); }
+        const double ri = rec[D], f0 = rec[D + 1], f1 = rec[D + 2], f2 = rec[D + 3];
+        const double Ac = halfw ? 0.5 * rec[D + 4] : rec[D + 4], Bc = halfw ? 0.5 * rec[D + 5] : rec[D + 5];
         const double r1 = rd * ri, r1s = r1 * r1, r2q = (dd - r1s) * ri;
-        const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q);
+        const double F1 = f1 * r1, F2 = fma(f2, r1s, f1 * r2q), F1x2 = F1 + F1;
 #pragma unroll
         for (int c = 0; c < D; c++) {
-          const double a1 = fma(F1, rho[c], f0 * dl[c]), a2 = fma(F2, rho[c], 2.0 * F1 * dl[c]);
+          const double a1 = fma(F1, rho[c], f0 * dl[c]), a2 = fma(F2, rho[c], F1x2 * dl[c]);
           du[m1 * D + c] += a1; qv[m1 * D + c] += a2;
           if (two) { du[m2 * D + c] -= a1; qv[m2 * D + c] -= a2; }
         }
-        const double sp = fma(f2, r, (1.0 + D) * f1), spp = fma(f3, r, (2.0 + D) * f2);
-        ddiv = fma(wsc * cf * sp, r1, ddiv);
-        qdiv += wsc * cf * fma(spp, r1s, sp * r2q);
-        divv += wsc * cf * fma(f1, r, D * f0);
-        double rc = rho[0], dkc = dk[0];
-#pragma unroll
-        for (int c = 1; c < D; c++) { rc = (ci == c) ? rho[c] : rc; dkc = (ci == c) ? dk[c] : dkc; }
-        const double F1k = f1 * (rdk * ri);
-        vi = fma(sgn * f0, rc, vi);
-        dvk = fma(sgn, fma(F1k, rc, f0 * dkc), dvk);
-        gdi = fma(sgn * cf * sp * ri, rc, gdi);
+        ddiv = fma(Ac, r1, ddiv);
+        qdiv = fma(Bc, r1s, fma(Ac, r2q, qdiv));
+        divv = halfw ? fma(0.5, rec[D + 6], divv) : divv + rec[D + 6];
       };
       // pairs inside my half
 #pragma unroll
       for (int m1 = 0; m1 < NP; m1++) {
 #pragma unroll
         for (int m2 = m1 + 1; m2 < NP; m2++) {
-          double rho[D], dl[D], dk[D];
+          const double* rec = &s_rec[gg * RECS + ff_pair_index(N, pbase + m1, pbase + m2) * RECW];
+          double dl[D];
 #pragma unroll
-          for (int c = 0; c < D; c++) {
-            rho[c] = zm[m1 * D + c] - zm[m2 * D + c];
-            dl[c] = u[m1 * D + c] - u[m2 * D + c];
-            dk[c] = km[m1 * D + c] - km[m2 * D + c];
-          }
-          const int p = ff_pair_index(N, pbase + m1, pbase + m2);
-          term(rho, dl, dk, p, m1, m2, true, 2.0, 1.0, la == m1 ? 1.0 : (la == m2 ? -1.0 : 0.0));
+          for (int c = 0; c < D; c++) dl[c] = u[m1 * D + c] - u[m2 * D + c];
+          term(rec, dl, rec, m1, m2, true, false);
         }
         if ((m1 & 1) == 1) FF_SCHED_FENCE();
       }
@@ -798,26 +863,20 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       for (int m = 0; m < NP; m++) {
 #pragma unroll
         for (int o = 0; o < NP; o++) {
-          double rho[D], dl[D], dk[D];
-#pragma unroll
-          for (int c = 0; c < D; c++) {
-            rho[c] = zm[m * D + c] - zo[o * D + c];
-            dl[c] = u[m * D + c] - uo[o * D + c];
-            dk[c] = km[m * D + c] - ko[o * D + c];
-          }
           const int pm = pbase + m, po = obase + o;
-          const int p = ff_pair_index(N, pm < po ? pm : po, pm < po ? po : pm);
-          term(rho, dl, dk, p, m, 0, false, 2.0, 0.5, la == m ? 1.0 : 0.0);
+          const double* rec = &s_rec[gg * RECS + ff_pair_index(N, pm < po ? pm : po, pm < po ? po : pm) * RECW];
+          double rho[D], dl[D];
+#pragma unroll
+          for (int c = 0; c < D; c++) { rho[c] = sg * rec[c]; dl[c] = u[m * D + c] - uo[o * D + c]; }
+          term(rho, dl, rec, m, 0, false, true);
         }
         FF_SCHED_FENCE();
       }
       if (has_mu) {
 #pragma unroll
         for (int m = 0; m < NP; m++) {
-          double rho[D], dl[D], dk[D];
-#pragma unroll
-          for (int c = 0; c < D; c++) { rho[c] = zm[m * D + c]; dl[c] = u[m * D + c]; dk[c] = km[m * D + c]; }
-          term(rho, dl, dk, P + pbase + m, m, 0, false, 1.0, 1.0, la == m ? 1.0 : 0.0);
+          const double* rec = &s_rec[gg * RECS + (P + pbase + m) * RECW];
+          term(rec, &u[m * D], rec, m, 0, false, false);
         }
       }
 #pragma unroll
@@ -825,13 +884,13 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       // transpose-reduce the quadratic sources: the owner of coordinate c needs sum_i qv_(i, half(c))[c]
       if (ingrp) {
 #pragma unroll
-        for (int k = 0; k < MH; k++) s_q[g][i][h][k] = qv[k];
+        for (int k = 0; k < MH; k++) s_qt[g * QTS + (i * 2 + h) * (MH + 1) + k] = qv[k];
       }
       __syncthreads();
       double sumq = 0.0;
       if (owner) {
         const int lc = i - h * MH;
-        for (int j = 0; j < M; j++) sumq += s_q[gg][j][h][lc];
+        for (int j = 0; j < M; j++) sumq += s_qt[gg * QTS + (j * 2 + h) * (MH + 1) + lc];
       }
       out[0] = owner ? vi : 0.0;
       out[MH + 1] = owner ? sumq + dvk : 0.0;
@@ -949,6 +1008,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     }
     __syncthreads();
   }
+  if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);
     atomicMax(&A.stats[1], acc_max);
@@ -1061,7 +1121,9 @@ static void launch_split(void* stream, const ff_fwd_args& a) {
   constexpr int G = FF_WAVE / (2 * N * D);
   int64_t ngroups = (a.B + G - 1) / G;
   const int64_t cap = ff_persist_blocks(1 << 20);
-  FF_LAUNCH((ff_eloc_split_kernel<N, D>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, stream, a);
+  const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
+  if (a.evt) FF_LAUNCH((ff_eloc_split_kernel<N, D, true>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_eloc_split_kernel<N, D, false>), grid, FF_WAVE, stream, a);
 }
 
 static std::atomic<uint64_t> g_evt_counter{1};
