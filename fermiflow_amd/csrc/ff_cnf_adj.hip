@@ -17,6 +17,13 @@
 #include "ff_ode.h"
 #include "ff_radial.h"
 
+// FF_STAMPS: diagnostic build only (tools/kbench.py): per-phase s_memtime shares of the tabulated adjoint's RHS loop
+#ifdef FF_STAMPS
+#define FF_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_prev; stamp_prev = t_; } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
+
 struct ff_adj_args {
   int64_t B;
   ff_net net;
@@ -424,18 +431,72 @@ ff_rows_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrow
 // 3(He+Hm) parameter gradients.  Per RHS evaluation this costs ~50 instructions per radius instead of ~50 sigmoid
 // chains per radius.
 struct ff_rec { double dr, ca, cb; int j; };
+// LDS rows of the deposit table are padded to an odd number of doubles: lanes deposit into rows of different nodes at the
+// same column, and a 12-double row stride maps all of them onto four bank groups
+#define FF_DEP_LROW (FF_DEP_ROW + 1)
 
-FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_ROW], double* __restrict__ ovf, int t, const ff_rec& rc, double w) {
+// add one coefficient row to node j of net t: LDS table for the near nodes, global overflow table beyond
+// (one branch and one address computation per row, not per coefficient)
+FF_D void ff_row_add(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, int j, const double* c) {
+  if (j < FF_DEP_NLDS) {
+    double* row = &sW[t][j][0];
+#pragma unroll
+    for (int k = 0; k < FF_DEP_ROW; k++) atomicAdd(row + k, c[k]);
+  } else {
+    double* row = ovf + ((size_t)t * FF_DEP_NTOT + j) * FF_DEP_ROW;
+#pragma unroll
+    for (int k = 0; k < FF_DEP_ROW; k++) atomicAdd(row + k, c[k]);
+  }
+}
+
+FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& rc, double w) {
   if (w == 0.0) return;
-  double pk = 1.0, pm = 0.0;   // dr^k/k!, dr^(k-1)/(k-1)!
+  double pk = 1.0, pm = 0.0, c[FF_DEP_ROW];   // dr^k/k!, dr^(k-1)/(k-1)!
 #pragma unroll
   for (int k = 0; k < FF_DEP_ROW; k++) {
-    const double c = w * fma(rc.ca, pk, rc.cb * pm);
-    if (rc.j < FF_DEP_NLDS) atomicAdd(&sW[t][rc.j][k], c);
-    else atomicAdd(&ovf[((size_t)t * FF_DEP_NTOT + rc.j) * FF_DEP_ROW + k], c);
+    c[k] = w * fma(rc.ca, pk, rc.cb * pm);
     pm = pk;
     pk = pk * rc.dr * (1.0 / (k + 1));
   }
+  ff_row_add(sW, ovf, t, rc.j, c);
+}
+
+// The five records of one accepted step (stages 0, 2, 3, 4, 5 with the b-weights of the tableau).  Within a step the
+// radius moves a little and in one direction, so the records fall on one node or on two neighbours: they are summed
+// in two register accumulators and deposited once each (24 LDS atomics instead of 60); a record on a third node (rare;
+// the branch is skipped when no lane of the wave needs it) goes separately.
+FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& q0, const ff_rec& q2,
+                      const ff_rec& q3, const ff_rec& q4, const ff_rec& q5, double hw) {
+  if (hw == 0.0) return;
+  const ff_rec* rc[5] = {&q0, &q2, &q3, &q4, &q5};
+  const double bw[5] = {hw * FF_B0, hw * FF_B2, hw * FF_B3, hw * FF_B4, hw * FF_B5};
+  const int jA = q0.j;
+  int jB = jA;
+#pragma unroll
+  for (int e = 4; e >= 1; e--) jB = (rc[e]->j != jA) ? rc[e]->j : jB;   // the first node other than jA (jA if there is none)
+  double accA[FF_DEP_ROW], accB[FF_DEP_ROW];
+#pragma unroll
+  for (int k = 0; k < FF_DEP_ROW; k++) { accA[k] = 0.0; accB[k] = 0.0; }
+#pragma unroll
+  for (int e = 0; e < 5; e++) {
+    const int j = rc[e]->j;
+    if (j == jA || j == jB) {
+      const double wA = (j == jA) ? bw[e] : 0.0, wB = (j == jA) ? 0.0 : bw[e];
+      double pk = 1.0, pm = 0.0;
+#pragma unroll
+      for (int k = 0; k < FF_DEP_ROW; k++) {
+        const double c = fma(rc[e]->ca, pk, rc[e]->cb * pm);
+        accA[k] = fma(wA, c, accA[k]);
+        accB[k] = fma(wB, c, accB[k]);
+        pm = pk;
+        pk = pk * rc[e]->dr * (1.0 / (k + 1));
+      }
+    } else {
+      ff_deposit(sW, ovf, t, *rc[e], bw[e]);
+    }
+  }
+  ff_row_add(sW, ovf, t, jA, accA);
+  if (jB != jA) ff_row_add(sW, ovf, t, jB, accB);
 }
 
 template <int N, int D>
@@ -447,11 +508,12 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
 
-  __shared__ ff_wtab s_w[2][FF_HPAD];
-  __shared__ double s_e2[64];
   __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G], s_hw[G];
-  __shared__ double s_rad[G][R], s_rinv[G][R], s_hd[G][R][3];
-  __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_ROW];
+  // T[g][a][j][3][D]: what partner j (j = a: the one-body term) contributes to particle a's rows of v, Dv^T[lambda] and
+  // grad div -- written by the radius lanes, summed by the component lanes (row padded against bank conflicts)
+  constexpr int TROW = N * 3 * D + 1;
+  __shared__ double s_T[G][N][TROW];
+  __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
   __shared__ int s_pa[R], s_pb[R], s_any;
 
   const int lane = threadIdx.x;
@@ -459,9 +521,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const bool ingrp = g < G;
   const int gg = ingrp ? g : 0;
   const int ai = i / D, ci = i % D;
-  ff_load_weights(s_w, A.net, lane);
-  ff_fill_exp2_table(s_e2, lane);
-  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) (&s_W[0][0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += FF_WAVE) (&s_W[0][0][0])[e] = 0.0;
   if (lane == 0) {
     int p = 0;
     for (int a = 0; a < N; a++)
@@ -474,17 +534,31 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const int nrad = has_mu ? (P + N) : P;
   const double tab_inv_h = rtab[0], tab_h = rtab[1];
   const double rtol = A.rtol, atol = A.atol;
+  // the radii this lane evaluates (slot sl: radius lane + 64 sl of the wave's G*nrad), fixed for the whole launch:
+  // walker slot | particle a << 4 | particle b (15: none) << 8 | radius index << 12
+  int rq_id[NSLOT];
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; sl++) {
+    const int q = lane + sl * FF_WAVE;
+    const bool act = q < G * nrad;
+    const int qg = act ? q / nrad : 0, p = act ? q - qg * nrad : 0;
+    rq_id[sl] = act ? (qg | (s_pa[p] << 4) | ((s_pb[p] < 0 ? 15 : s_pb[p]) << 8) | (p << 12)) : -1;
+  }
+  bool off_any = false;
   constexpr double NT = 2 * M;
   const int64_t ngroups = (A.B + G - 1) / G;
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
   double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
+#ifdef FF_STAMPS
+  unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
     const int64_t b = (valid && A.order) ? A.order[bq] : bq;
-    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
+    double y[NV], k0[NV] = {0.0, 0.0}, k1[NV] = {0.0, 0.0}, k2[NV] = {0.0, 0.0}, k3[NV] = {0.0, 0.0}, k4[NV] = {0.0, 0.0}, k5[NV] = {0.0, 0.0};
     y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
     y[1] = valid ? A.az_in[b * M + i] : 0.0;
     if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
@@ -509,121 +583,99 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     for (;;) {
       double in[NV];
       const double h = S.h;
-      switch (s) {
-        case -2: case 0:
+      {
+        // y + hsel * sum_k a_k k_k with the stage's tableau row (wave-uniform row: scalar loads, no literals)
+        const double hsel = (s == -1) ? h0v * S.dir : h;
+        const double* __restrict__ arow = FF_ATAB[s + 2];
+        const double a0 = hsel * arow[0], a1 = hsel * arow[1], a2 = hsel * arow[2], a3 = hsel * arow[3], a4 = hsel * arow[4],
+                     a5 = hsel * arow[5];
 #pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = y[v];
-          break;
-        case -1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h0v * S.dir, k0[v], y[v]);
-          break;
-        case 1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h * FF_A10, k0[v], y[v]);
-          break;
-        case 2:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
-          break;
-        case 3:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
-          break;
-        case 4:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
-          break;
-        case 5:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
-          break;
-        default:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
-          break;
+        for (int v = 0; v < NV; v++)
+          in[v] = fma(a5, k5[v], fma(a4, k4[v], fma(a3, k3[v], fma(a2, k2[v], fma(a1, k1[v], fma(a0, k0[v], y[v]))))));
       }
+      FF_STAMP(0);
       __syncthreads();
       if (ingrp) { s_z[g][i] = in[0]; s_kb[g][i] = in[1]; }
       __syncthreads();
+      FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase (lane <-> radius)
       ff_rec cur[NSLOT];
+      double rq_rho[NSLOT][D], rq_dl[NSLOT][D], rq_r[NSLOT], rq_ri[NSLOT], rq_T[NSLOT][3 + 5], rq_dr[NSLOT];
+      bool rq_ok[NSLOT];
 #pragma unroll
-      for (int sl = 0; sl < NSLOT; sl++) {
-        const int q = lane + sl * FF_WAVE;
+      for (int sl = 0; sl < NSLOT; sl++) {   // all radii first, table rows requested ...
+        const int id = rq_id[sl];
+        const bool act = id >= 0;
+        const int qg = act ? (id & 15) : 0, a = act ? ((id >> 4) & 15) : 0, bq = act ? ((id >> 8) & 15) : 15;
+        const bool pair = bq != 15;
+        const int bb = pair ? bq : a;
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          rq_rho[sl][c] = s_z[qg][a * D + c] - (pair ? s_z[qg][bb * D + c] : 0.0);
+          rq_dl[sl][c] = s_kb[qg][a * D + c] - (pair ? s_kb[qg][bb * D + c] : 0.0);
+          r2 = fma(rq_rho[sl][c], rq_rho[sl][c], r2);
+        }
+        ff_sqrt_rcp(r2, rq_r[sl], rq_ri[sl]);
+        rq_dr[sl] = 0.0;
+        rq_ok[sl] = ff_table_fetch<3>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[sl], rq_T[sl], rq_dr[sl]);
+      }
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; sl++) {   // ... then evaluated
+        const int id = rq_id[sl];
         cur[sl].j = 0; cur[sl].dr = 0.0; cur[sl].ca = 0.0; cur[sl].cb = 0.0;
-        if (q < G * nrad) {
-          const int qg = q / nrad, p = q - qg * nrad;
-          const int a = s_pa[p], bb = s_pb[p];
-          double r2 = 0.0, al = 0.0;
+        if (id >= 0) {
+          const int qg = id & 15, a = (id >> 4) & 15, bq = (id >> 8) & 15;
+          const bool pair = bq != 15;
+          const int bb = pair ? bq : a;
+          const double* rho = rq_rho[sl];
+          const double* dl = rq_dl[sl];
+          const double r = rq_r[sl], ri = rq_ri[sl], ad = s_ad[qg];
+          double hd[3] = {0.0, 0.0, 0.0}, al = 0.0;
+          if (rq_ok[sl]) ff_table_eval<3>(rq_T[sl], rq_dr[sl], hd);
 #pragma unroll
-          for (int c = 0; c < D; c++) {
-            const double rho = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
-            const double dl = s_kb[qg][a * D + c] - (bb >= 0 ? s_kb[qg][bb * D + c] : 0.0);
-            r2 = fma(rho, rho, r2);
-            al = fma(dl, rho, al);
-          }
-          const double r = sqrt(r2), ad = s_ad[qg];
-          double hd[3];
-          if (!ff_heads_table<3>(rtab, tab_inv_h, tab_h, bb >= 0 ? 0 : 1, r, hd))
-            ff_heads<3, true>(s_w[bb >= 0 ? 0 : 1], s_e2, bb >= 0 ? He : Hm, r, hd);
-          s_rad[qg][p] = r;
-          s_rinv[qg][p] = ff_rcp(r);
-          s_hd[qg][p][0] = hd[0]; s_hd[qg][p][1] = hd[1]; s_hd[qg][p][2] = hd[2];
+          for (int c = 0; c < D; c++) al = fma(dl[c], rho[c], al);
           // parameter integrand  ca * df(r)/dtheta + cb * df'(r)/dtheta, deposited about node jd of the coarse grid
           double jf = rint(r * FF_DEP_INVH);
-          if (!(jf <= (double)(FF_DEP_NTOT - 1)) && (grp * G + qg) < A.B) *A.off_table = 1.0;   // beyond the table (or NaN): direct kernel redoes the call
+          // beyond either table (or NaN): the direct kernel redoes the call
+          if ((!rq_ok[sl] || !(jf <= (double)(FF_DEP_NTOT - 1))) && (grp * G + qg) < A.B) off_any = true;
           jf = fmin(jf, (double)(FF_DEP_NTOT - 1));
           cur[sl].j = (r == r) ? (int)jf : 0;
           cur[sl].dr = fma(-jf, 1.0 / FF_DEP_INVH, r);
-          cur[sl].ca = bb >= 0 ? -(al - 2.0 * D * ad) : -(al - D * ad);
-          cur[sl].cb = bb >= 0 ? 2.0 * ad * r : ad * r;
+          cur[sl].ca = pair ? -(al - 2.0 * D * ad) : -(al - D * ad);
+          cur[sl].cb = pair ? 2.0 * ad * r : ad * r;
+          // own rows: +x to particle a from partner bb, -x to particle bb from partner a
+          const double f0 = hd[0], f1 = hd[1], f2 = hd[2];
+          const double F1 = f1 * (al * ri), gq = (pair ? 2.0 : 1.0) * fma(f2, r, (1.0 + D) * f1) * ri;
+          double* Ta = &s_T[qg][a][bb * 3 * D];
+          double* Tb = &s_T[qg][bb][a * 3 * D];
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            const double pv = f0 * rho[c], pw = fma(F1, rho[c], f0 * dl[c]), pg = gq * rho[c];
+            Ta[c] = pv; Ta[D + c] = pw; Ta[2 * D + c] = pg;
+            if (pair) { Tb[c] = -pv; Tb[D + c] = -pw; Tb[2 * D + c] = -pg; }
+          }
         }
       }
       __syncthreads();
       nev++;
-      // ------------------------------------------------------------------ component phase
+      FF_STAMP(2);
+      // ------------------------------------------------------------------ component phase: sum the own rows
       double out[NV];
       {
-        const double* sz = s_z[gg];
-        const double* sl = s_kb[gg];
         double vi = 0.0, dvk = 0.0, gdi = 0.0;
-        const double zc = sz[ai * D + ci], lc = sl[ai * D + ci];
+        const double* T = &s_T[gg][ai][ci];
 #pragma unroll
-        for (int bq = 0; bq < N; bq++) {
-          const bool self = (bq == ai);
-          const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
-          const int p = self ? 0 : ff_pair_index(N, lo, hi);
-          const double m = self ? 0.0 : 1.0;
-          const double rc = zc - sz[bq * D + ci];
-          const double f0 = m * s_hd[gg][p][0], f1 = m * s_hd[gg][p][1], f2 = m * s_hd[gg][p][2];
-          double rdk = 0.0;
-#pragma unroll
-          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c] - sz[bq * D + c], sl[ai * D + c] - sl[bq * D + c], rdk);
-          const double ri = s_rinv[gg][p], r1 = rdk * ri;
-          vi = fma(f0, rc, vi);
-          dvk += fma(f1 * r1, rc, f0 * (lc - sl[bq * D + ci]));
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(2.0 * sp * ri, rc, gdi);
-        }
-        if (has_mu) {
-          const int p = P + ai;
-          const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2];
-          double rdk = 0.0;
-#pragma unroll
-          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c], sl[ai * D + c], rdk);
-          const double ri = s_rinv[gg][p], r1 = rdk * ri;
-          vi = fma(f0, zc, vi);
-          dvk += fma(f1 * r1, zc, f0 * lc);
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(sp * ri, zc, gdi);
+        for (int j = 0; j < N; j++) {
+          const bool use = has_mu || j != ai;
+          const double tv = T[j * 3 * D], tw = T[j * 3 * D + D], tg = T[j * 3 * D + 2 * D];
+          vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
         }
         out[0] = vi;
         out[1] = fma(s_ad[gg], gdi, -dvk);
       }
+      FF_STAMP(3);
+      const int s_before = s;
       // ------------------------------------------------------------------ consume
       if (s == -2) {
 #pragma unroll
@@ -692,7 +744,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         double pe = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
+          const double e = h * (FF_ATAB[9][0] * k0[v] + FF_ATAB[9][2] * k2[v] + FF_ATAB[9][3] * k3[v] + FF_ATAB[9][4] * k4[v] + FF_ATAB[9][5] * k5[v] + FF_E6 * out[v]);
           const double t = e * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
           pe = fma(t, t, pe);
         }
@@ -708,16 +760,11 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) {
-          const int q = lane + sl * FF_WAVE;
-          if (q < G * nrad) {
-            const int qg = q / nrad, p = q - qg * nrad;
-            const int t = p < P ? 0 : 1;
+          if (rq_id[sl] >= 0) {
+            const int qg = rq_id[sl] & 15;
+            const int t = ((rq_id[sl] >> 8) & 15) != 15 ? 0 : 1;
             const double hw = s_hw[qg];
-            ff_deposit(s_W, ovf, t, r0[sl], hw * FF_B0);
-            ff_deposit(s_W, ovf, t, r2[sl], hw * FF_B2);
-            ff_deposit(s_W, ovf, t, r3[sl], hw * FF_B3);
-            ff_deposit(s_W, ovf, t, r4[sl], hw * FF_B4);
-            ff_deposit(s_W, ovf, t, r5[sl], hw * FF_B5);
+            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }
         }
@@ -726,6 +773,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
+      if (s_before == 6) FF_STAMP(5); else FF_STAMP(4);
     }
     if (valid) {
       if (A.gx_out) A.gx_out[b * M + i] = y[1];
@@ -739,10 +787,15 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     }
     __syncthreads();
   }
+#ifdef FF_STAMPS
+  if (A.stats && lane == 0)
+    for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+#endif
+  if (off_any) *A.off_table = 1.0;
   // flush the workgroup-private coefficient table
   {
     double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[e];
+    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
   }
   if (A.stats && (ev_sum || fail_any)) {
     atomicAdd(&A.stats[0], (int)ev_sum);

@@ -61,6 +61,9 @@ w = (r["eloc"] - r["eloc"].mean()) / a.B
 res["adjoint_ms"], (_, gp, st) = timeit(lambda: native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
                                                                    need_gx=False, want_stats=True, walker_order=order2))
 res["adjoint_evals"] = st[0].item() / a.B
+sa = st[8:26].view(torch.int64)[:9].double()
+if sa.sum() > 0:   # 0 stage input, 1 publish, 2 radius, 3 component, 4 consume, 5 consume of stage 6 (deposit), per wave-eval
+    res["adjoint_stamps_ticks"] = [round(v) for v in (sa / (st[0].item() / 5.0)).tolist()]
 st8 = r["stats"][8:26].view(torch.int64)[:9].double()
 if st8.sum() > 0:
     res["stamps_pct"] = [round(v, 1) for v in (100 * st8 / st8.sum()).tolist()]
