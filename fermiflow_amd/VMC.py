@@ -55,6 +55,15 @@ class GSVMC(torch.nn.Module):
         self.sp_potential = sp_potential
         self.profile = None
 
+    # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
+    @property
+    def E(self):
+        return self._E_dev.item()
+
+    @property
+    def E_std(self):
+        return self._E_std_dev.item()
+
     # -- pieces with the reference's names ---------------------------------------------------------
     def sample(self, sample_shape):
         z = self.basedist.sample(self.orbitals_up, self.orbitals_down, sample_shape)
@@ -116,10 +125,12 @@ class GSVMC(torch.nn.Module):
                             want_stats=prof is not None, pass1_events=p1, walker_order=order)
             mark("eloc")
             Eloc = r["eloc"]
+            # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the
+            # sweep, so kernel launches keep running ahead of the GPU
             s0 = native.reduce_moments(Eloc, 0.0)
-            self.E, self.E_std, nglob = D.global_mean_std(
-                s0[0], nloc, lambda m: native.reduce_moments(Eloc, m)[1])
-            w = (Eloc - self.E) / nglob
+            self._E_dev, self._E_std_dev = D.global_mean_std_dev(
+                s0[0], batch, lambda tot, scale: native.reduce_moments(Eloc, shift_dev=tot, shift_dev_scale=scale)[1])
+            w = (Eloc - self._E_dev) / batch
             v, params = _flow_params(self.cnf)
             mark("estimator")
             _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,

@@ -877,9 +877,23 @@ extern void ff_set_error(const char* msg);
 static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
 static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? FF_WAVE / M : 0; }
+// Persistent grid: one wave per SIMD.  Every walker takes the same few steps here, so a static split is balanced, and
+// each workgroup flushes a private deposit table (25 KB) at its end -- the fewer workgroups the less HBM traffic
+// (measured, 65536 walkers: 4096 workgroups 1.09 ms, 1024 workgroups 0.92 ms).
+static int64_t adj_default_blocks() {
+  static int64_t n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = 4 * (int64_t)cus;
+  }
+  return n;
+}
+
 static unsigned adj_grid(int64_t B, int G) {
   int64_t ngroups = (B + G - 1) / G;
-  const int64_t cap = ff_persist_blocks(4096);
+  const int64_t cap = ff_persist_blocks(adj_default_blocks());
   return (unsigned)(ngroups < cap ? ngroups : cap);
 }
 

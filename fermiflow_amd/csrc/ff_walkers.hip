@@ -295,19 +295,31 @@ ff_backflow_kernel(int64_t B, int n, int d, ff_net net, const double* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// out[0] = sum (e - shift), out[1] = sum (e - shift)^2; one workgroup, fixed summation tree (deterministic)
-__global__ void __launch_bounds__(256)
-ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift, double* __restrict__ out) {
-  __shared__ double s1[256], s2[256];
-  double a = 0.0, q = 0.0;
-  for (int64_t i = threadIdx.x; i < B; i += 256) { double t = e[i] - shift; a += t; q = fma(t, t, q); }
-  s1[threadIdx.x] = a; s2[threadIdx.x] = q;
+// out[0] = sum (e - shift), out[1] = sum (e - shift)^2; one workgroup, fixed summation tree (deterministic for a given
+// block size); four independent accumulator pairs per thread keep several loads in flight
+__global__ void __launch_bounds__(1024)
+ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, const double* __restrict__ shift_dev,
+                  double shift_dev_scale, double* __restrict__ out) {
+  __shared__ double s1[1024], s2[1024];
+  const double shift = shift_dev ? shift_dev[0] * shift_dev_scale : shift_host;
+  const int nt = blockDim.x, t = threadIdx.x;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+  int64_t i = t;
+  for (; i + 3 * (int64_t)nt < B; i += 4 * (int64_t)nt) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const double v = e[i + k * (int64_t)nt] - shift; a[k] += v; q[k] = fma(v, v, q[k]); }
+  }
+  for (int k = 0; i < B; i += nt, k++) { const double v = e[i] - shift; a[k] += v; q[k] = fma(v, v, q[k]); }
+  s1[t] = (a[0] + a[1]) + (a[2] + a[3]);
+  s2[t] = (q[0] + q[1]) + (q[2] + q[3]);
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { s1[threadIdx.x] += s1[threadIdx.x + w]; s2[threadIdx.x] += s2[threadIdx.x + w]; }
+  int w = 1;
+  while (w * 2 < nt) w *= 2;   // largest power of two below the block size
+  for (; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) { s1[t] += s1[t + w]; s2[t] += s2[t + w]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+  if (t == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
 // =================================================================================================
@@ -522,9 +534,10 @@ int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order
   return FF_OK;
 }
 
-int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, double* out2) {
+int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev, double shift_dev_scale,
+                      double* out2) {
   FF_CHECK(B > 0 && e && out2, FF_EINVAL, "ff_reduce_moments: bad argument");
-  FF_LAUNCH(ff_moments_kernel, 1, 256, stream, B, e, shift, out2);
+  FF_LAUNCH(ff_moments_kernel, 1, FF_RBLOCK(1024), stream, B, e, shift, shift_dev, shift_dev_scale, out2);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

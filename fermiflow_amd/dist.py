@@ -38,6 +38,20 @@ def shard(batch, rank=None, world_size=None):
     return offset, count
 
 
+def global_mean_std_dev(sum_e, n_global, centered_sumsq_fn):
+    """Mean and unbiased std over all ranks as 0-dim DEVICE tensors, without a host synchronisation.
+    sum_e: 0-dim tensor, the local sum; n_global: the global number of samples (known on the host: the shards are a
+    fixed split of the batch); centered_sumsq_fn(sum_tensor, scale) -> 0-dim tensor with the local
+    sum of (e - sum_tensor*scale)^2."""
+    buf = sum_e.reshape(1).clone()
+    all_reduce_sum_(buf)
+    mean = buf[0] / n_global
+    ss = centered_sumsq_fn(buf, 1.0 / n_global).reshape(1).clone()
+    all_reduce_sum_(ss)
+    std = (ss[0] / (n_global - 1)).sqrt() if n_global > 1 else torch.full_like(mean, float("nan"))
+    return mean, std
+
+
 def global_mean_std(sum_e, count, centered_sumsq_fn):
     """Two-phase mean / unbiased std over all ranks.
     sum_e: 0-dim tensor with the local sum; count: local number of walkers;

@@ -192,9 +192,13 @@ def walker_order(cost):
     return order
 
 
-def reduce_moments(e, shift=0.0):
-    """tensor [sum(e - shift), sum((e - shift)^2)] on the device."""
+def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0):
+    """tensor [sum(e - shift), sum((e - shift)^2)] on the device; shift_dev: optional 1-element device tensor, then
+    shift = shift_dev[0] * shift_dev_scale (no host round trip for the mean)."""
     e = L.dev(e, name="e")
     out = torch.empty(2, dtype=torch.float64, device=e.device)
-    L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(out)), "ff_reduce_moments")
+    if shift_dev is not None:
+        shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
+    L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(shift_dev),
+                                      L.f64(shift_dev_scale), L.ptr(out)), "ff_reduce_moments")
     return out

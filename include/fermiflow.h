@@ -146,8 +146,11 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
 
 /* ---- estimator reductions (src/VMC.py:57-58) ------------------------------------------------ */
 /* out2[0] = sum_b (e[b] - shift), out2[1] = sum_b (e[b] - shift)^2; one workgroup, fixed summation tree
- * (deterministic).  Called with shift = 0 for the mean, then with shift = mean for the unbiased std. */
-int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, double* out2);
+ * (deterministic).  Called with shift = 0 for the mean, then with shift = mean for the unbiased std.
+ * shift_dev (device pointer, may be NULL): if given, shift = shift_dev[0] * shift_dev_scale and `shift` is ignored --
+ * the mean of the first call (a sum on the device, all-reduced there) feeds the second without a host round trip. */
+int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev,
+                      double shift_dev_scale, double* out2);
 
 #ifdef __cplusplus
 }

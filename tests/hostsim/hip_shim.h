@@ -31,6 +31,9 @@ typedef int hipError_t;
 inline int hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(int) { return "hostsim"; }
 inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return 0; }
+#define hipDeviceAttributeMultiprocessorCount 0
+inline int hipGetDevice(int* d) { *d = 0; return 0; }
+inline int hipDeviceGetAttribute(int* v, int, int) { *v = 2; return 0; }   // the simulator pretends to have two CUs
 
 template <class T> inline T ff_sim_atomic_add(T* p, T v) {
   std::atomic_ref<T> a(*p);

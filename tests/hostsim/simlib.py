@@ -198,5 +198,5 @@ def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8,
 
 def moments(e, shift=0.0):
     e = _d(e); out = np.empty(2)
-    _ck(lib().ff_reduce_moments(None, C.c_int64(len(e)), _p(e), C.c_double(shift), _p(out)))
+    _ck(lib().ff_reduce_moments(None, C.c_int64(len(e)), _p(e), C.c_double(shift), None, C.c_double(1.0), _p(out)))
     return out
