@@ -1018,79 +1018,127 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Local-energy finish (one lane per walker): Slater gradient/Hessian at z(t0) contracted with the
-// sensitivities from the MODE-2 pass.  With g0 = grad_z logp0, H0 = Hess_z logp0:
+// Local-energy finish: Slater gradient/Hessian at z(t0) contracted with the sensitivities from the MODE-2 pass.
+// With g0 = grad_z logp0, H0 = Hess_z logp0:
 //   grad_i = g0 . u_i - dDelta_i
 //   lap    = sum_i u_i^T H0 u_i + g0 . kbar - sum_i L_i
 //   E_loc  = -lap/4 - |grad|^2/8 + V(x)            (src/VMC.py:49-55)
+// Two launches.  (1) ff_eloc_slater_kernel, one lane per walker: the Slater quantities of z(t0) (runtime determinant
+// sizes, private arrays -- serial per walker, so 64 walkers per wave) into a slot-major table Q[slot][walker]
+// (coalesced).  (2) ff_eloc_contract_kernel, M = 2n lanes per walker as in the sensitivity kernels: the wave's G*M*M
+// block of J^T is ONE contiguous read (the one-lane-per-walker version of this contraction fetched every cache line
+// ~8 times: 730 MB per launch against 100 MB of sensitivities), each lane contracts its own direction, three LDS sums
+// finish the walker.
+// slots of Q: [0,M) g0 | [M, M+3n) S (particle-major) | then T_up (2 nup^2), T_dn (2 ndn^2) | last: logp0
 __global__ void __launch_bounds__(128)
-ff_eloc_finish_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
-                      const int* __restrict__ wstate, double Zc, int use_ho, const double* __restrict__ x,
-                      const double* __restrict__ z0, const double* __restrict__ Jt, const double* __restrict__ kbar,
-                      const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
-                      double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
-                      double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                      const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
-  double zl[2 * FF_MAX_NS], T[2][2 * FF_MAX_NS * FF_MAX_NS], S[2][3 * FF_MAX_NS], g0[4 * FF_MAX_NS];
+  double zl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS], S[3 * FF_MAX_NS];
   double lp0 = 0.0;
+  int tq = M + 3 * n;
   for (int sp = 0; sp < 2; sp++) {
     const int ns = sp ? ndn : nup, off = sp ? nup : 0;
     if (!ns) continue;
     for (int k = 0; k < 2 * ns; k++) zl[k] = z0[b * M + 2 * off + k];
-    lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T[sp], S[sp]);
+    lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T, S);
     for (int a = 0; a < ns; a++) {
-      g0[2 * (off + a)] = 2.0 * T[sp][a * ns + a];
-      g0[2 * (off + a) + 1] = 2.0 * T[sp][ns * ns + a * ns + a];
+      Q[(int64_t)(2 * (off + a)) * B + b] = 2.0 * T[a * ns + a];
+      Q[(int64_t)(2 * (off + a) + 1) * B + b] = 2.0 * T[ns * ns + a * ns + a];
+      for (int k = 0; k < 3; k++) Q[(int64_t)(M + 3 * (off + a) + k) * B + b] = S[3 * a + k];
     }
+    for (int k = 0; k < 2 * ns * ns; k++) Q[(int64_t)(tq + k) * B + b] = T[k];
+    tq += 2 * ns * ns;
   }
-  lp0 *= 2.0;
-  double lapv = 0.0, g2 = 0.0;
-  for (int i = 0; i < M; i++) {
-    const double* u = Jt + (b * M + i) * M;
-    double gi = 0.0;
-    for (int k = 0; k < M; k++) gi = fma(g0[k], u[k], gi);
-    gi -= dD[b * M + i];
-    if (grad) grad[b * M + i] = gi;
-    g2 = fma(gi, gi, g2);
-    double hq = 0.0;
-    for (int sp = 0; sp < 2; sp++) {
-      const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-      if (!ns) continue;
-      const double* Tx = T[sp];
-      const double* Ty = T[sp] + ns * ns;
-      double q = 0.0;
-      for (int a = 0; a < ns; a++) {
-        const double ux = u[2 * (off + a)], uy = u[2 * (off + a) + 1];
-        q += ux * ux * S[sp][3 * a] + 2.0 * ux * uy * S[sp][3 * a + 1] + uy * uy * S[sp][3 * a + 2];
-        for (int c = 0; c < ns; c++) {
-          const double vx = u[2 * (off + c)], vy = u[2 * (off + c) + 1];
-          const double Wac = ux * Tx[a * ns + c] + uy * Ty[a * ns + c];
-          const double Wca = vx * Tx[c * ns + a] + vy * Ty[c * ns + a];
-          q -= Wac * Wca;
+  Q[(int64_t)tq * B + b] = 2.0 * lp0;
+}
+
+// dynamic LDS: [G*M*M J^T block | G*nq Slater slots | 64 x | 3*64 partial sums]  (10 KB at n = 6: many waves per CU)
+static size_t ff_contract_lds_bytes(int nup, int ndn) {
+  const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M, nq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 1;
+  return sizeof(double) * ((size_t)G * M * M + (size_t)G * nq + 4 * FF_WAVE);
+}
+__global__ void __launch_bounds__(FF_WAVE)
+ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, const double* __restrict__ x,
+                        const double* __restrict__ Q, const double* __restrict__ Jt, const double* __restrict__ kbar,
+                        const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
+                        double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
+                        double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
+  FF_DYN_LDS(ff_fin_lds);
+  const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M;
+  const int lane = threadIdx.x, g = lane / M, i = lane - g * M;
+  const bool ingrp = g < G;
+  const int tsz = 2 * (nup * nup + ndn * ndn), nq = M + 3 * n + tsz + 1;
+  double* const s_u = ff_fin_lds;                            // [g][i][k] = dz_k/dx_i
+  double* const s_q = s_u + G * M * M;                       // [g][slot]
+  double* const s_x = s_q + G * nq;
+  double (*const s_red)[FF_WAVE] = (double (*)[FF_WAVE])(s_x + FF_WAVE);
+  const int64_t ngroups = (B + G - 1) / G;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t b0 = grp * G, b = b0 + g;
+    const bool valid = ingrp && b < B;
+    const int nw = (int)((B - b0) < G ? (B - b0) : G);       // walkers of this wave
+    __syncthreads();
+    for (int e = lane; e < nw * M * M; e += FF_WAVE) s_u[e] = Jt[b0 * M * M + e];
+    for (int e = lane; e < nw * nq; e += FF_WAVE) { const int q = e / nw, w = e - q * nw; s_q[w * nq + q] = Q[(int64_t)q * B + b0 + w]; }
+    if (valid) s_x[lane] = x[b * M + i];
+    __syncthreads();
+    double gi = 0.0, lap_i = 0.0, v_i = 0.0;
+    if (valid) {
+      const double* u = s_u + (g * M + i) * M;
+      const double* qw = s_q + g * nq;
+      const double* g0 = qw;
+      for (int k = 0; k < M; k++) gi = fma(g0[k], u[k], gi);
+      gi -= dD[b * M + i];
+      double hq = 0.0;
+      for (int sp = 0; sp < 2; sp++) {
+        const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+        if (!ns) continue;
+        const double* Tx = qw + M + 3 * n + (sp ? 2 * nup * nup : 0);
+        const double* Ty = Tx + ns * ns;
+        double q = 0.0;
+        for (int a = 0; a < ns; a++) {
+          const double ux = u[2 * (off + a)], uy = u[2 * (off + a) + 1];
+          const double* Sa = qw + M + 3 * (off + a);
+          q += ux * ux * Sa[0] + 2.0 * ux * uy * Sa[1] + uy * uy * Sa[2];
+          for (int c = 0; c < ns; c++) {
+            const double vx = u[2 * (off + c)], vy = u[2 * (off + c) + 1];
+            const double Wac = ux * Tx[a * ns + c] + uy * Ty[a * ns + c];
+            const double Wca = vx * Tx[c * ns + a] + vy * Ty[c * ns + a];
+            q -= Wac * Wca;
+          }
         }
+        hq += 2.0 * q;
       }
-      hq += 2.0 * q;
+      lap_i = hq - Lpart[b * M + i] + g0[i] * kbar[b * M + i];
+      // potential: the lane of particle a's x-coordinate takes a's trap term and its pairs with the later particles
+      if ((i & 1) == 0) {
+        const int a = i >> 1;
+        const double* xs = s_x + g * M;
+        const double xa = xs[2 * a], ya = xs[2 * a + 1];
+        double pair = 0.0;
+        for (int c = a + 1; c < n; c++) {
+          const double dx = xa - xs[2 * c], dy = ya - xs[2 * c + 1];
+          pair += Zc / sqrt(dx * dx + dy * dy);
+        }
+        v_i = pair + (use_ho ? 0.5 * (xa * xa + ya * ya) : 0.0);
+      }
+      if (grad) grad[b * M + i] = gi;
+      if (glogp0) glogp0[b * M + i] = g0[i];
     }
-    lapv += hq - Lpart[b * M + i];
-  }
-  for (int k = 0; k < M; k++) lapv = fma(g0[k], kbar[b * M + k], lapv);
-  double pair = 0.0, ho = 0.0;
-  for (int a = 0; a < n; a++) {
-    const double xa = x[b * M + 2 * a], ya = x[b * M + 2 * a + 1];
-    ho += xa * xa + ya * ya;
-    for (int c = a + 1; c < n; c++) {
-      const double dx = xa - x[b * M + 2 * c], dy = ya - x[b * M + 2 * c + 1];
-      pair += Zc / sqrt(dx * dx + dy * dy);
+    s_red[0][lane] = gi * gi; s_red[1][lane] = lap_i; s_red[2][lane] = v_i;
+    __syncthreads();
+    if (valid && i == 0) {
+      double g2 = 0.0, lapv = 0.0, Vv = 0.0;
+      for (int k = 0; k < M; k++) { g2 += s_red[0][g * M + k]; lapv += s_red[1][g * M + k]; Vv += s_red[2][g * M + k]; }
+      if (logp) logp[b] = s_q[g * nq + nq - 1] - delta[b];
+      if (lap) lap[b] = lapv;
+      if (V) V[b] = Vv;
+      if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv;
     }
   }
-  const double Vv = pair + (use_ho ? 0.5 * ho : 0.0);
-  if (logp) logp[b] = lp0 - delta[b];
-  if (lap) lap[b] = lapv;
-  if (V) V[b] = Vv;
-  if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv;
-  if (glogp0) for (int k = 0; k < M; k++) glogp0[b * M + k] = g0[k];
 }
 
 // =================================================================================================
@@ -1202,12 +1250,13 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   return dispatch_fwd<1>(stream, n, d, a);
 }
 
+// sensitivities (z0, Jt, kbar, dD, Lpart, Delta) + the Slater table of the finish (g0, S, T <= 2 n^2, logp0)
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
   size_t M = (size_t)n * d;
-  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1);
+  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 1);
 }
 
-struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl; };
+struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl, *Q; };
 static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
   double* w = (double*)workspace;
   ff_eloc_ws o;
@@ -1216,7 +1265,8 @@ static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
   o.kbar = w; w += (size_t)B * M;
   o.dD = w;   w += (size_t)B * M;
   o.Lp = w;   w += (size_t)B * M;
-  o.dl = w;
+  o.dl = w;   w += (size_t)B;
+  o.Q = w;
   return o;
 }
 
@@ -1248,9 +1298,17 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
   if (B == 0) return FF_OK;
   const size_t M = (size_t)n * 2;
   ff_eloc_ws w = eloc_carve((void*)workspace, B, M);
-  FF_LAUNCH(ff_eloc_finish_kernel, (unsigned)((B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho,
-            x, (const double*)w.z0, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
-            (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+  FF_CHECK(2 * n <= FF_WAVE, FF_EUNSUPPORTED, "ff_eloc_finish: n*d > 64");
+  FF_LAUNCH(ff_eloc_slater_kernel, (unsigned)((B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state,
+            (const double*)w.z0, w.Q);
+  FF_LAUNCH_CHECK();
+  {
+    const int Gf = FF_WAVE / (2 * n);
+    const int64_t ng = (B + Gf - 1) / Gf;
+    FF_LAUNCH_LDS(ff_eloc_contract_kernel, (unsigned)(ng < 32768 ? ng : 32768), FF_WAVE, ff_contract_lds_bytes(nup, ndn), stream, B, nup, ndn, Z, use_ho, x,
+              (const double*)w.Q, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
+              (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+  }
   FF_LAUNCH_CHECK();
 #ifdef FF_HOSTSIM
   if (z_out) memcpy(z_out, w.z0, sizeof(double) * (size_t)B * M);

@@ -25,6 +25,9 @@
 #include <hip/hip_runtime.h>
 #define FF_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define FF_LAUNCH_LDS(kernel, grid, block, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
+#define FF_DYN_LDS(name) extern __shared__ double name[]
 #endif
 
 // a value the program knows to be wave-uniform -> scalar register (lets loops on it be scalar loops)

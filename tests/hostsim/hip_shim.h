@@ -78,3 +78,8 @@ inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   ff_sim_bar = nullptr;
 }
 #define FF_LAUNCH(kernel, grid, block, stream, ...) ff_sim_launch(kernel, (unsigned)(grid), (unsigned)(block), __VA_ARGS__)
+// dynamic LDS: one static buffer (workgroups run one after the other)
+static double ff_sim_dyn_lds[20480];
+#define FF_LAUNCH_LDS(kernel, grid, block, lds_bytes, stream, ...) \
+  do { if ((size_t)(lds_bytes) > sizeof(ff_sim_dyn_lds)) abort(); ff_sim_launch(kernel, (unsigned)(grid), (unsigned)(block), __VA_ARGS__); } while (0)
+#define FF_DYN_LDS(name) double* const name = ff_sim_dyn_lds
