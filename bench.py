@@ -28,7 +28,10 @@ sys.path.insert(0, ROOT)
 # algorithmic work per RHS evaluation of one walker in the local-energy kernel ("Kernels"):
 FLOP_PER_SIGMOID_UNIT = 30      # 1 exp + 1 rcp + ~8 FMA-class ops      (FERMIFLOW_RADIAL=exact)
 FLOP_PER_TABLE_RADIUS = 60      # 4 heads x 5 Horner FMAs + index/offset arithmetic     (FERMIFLOW_RADIAL=table, default)
-FLOP_PER_JET_TERM = 55          # counted from the jet-phase source: one (direction, radius) term
+FLOP_PER_RADIUS_RECORD = 55     # r, 1/r, the direction-independent record and the own-row contributions of one radius
+FLOP_PER_PAIR_TERM = 44         # counted from the jet sweep: one (direction, pair) term (FMA = 2); was 55 before the
+FLOP_PER_ONEBODY_TERM = 40      # radius records took the direction-independent part out of the sweep (profiles r01_a..g)
+FLOP_PER_LANE_GATHER = 30       # own rows (18 adds) + transposition sum (12 adds)
 PEAK_FP64_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (vendor)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -110,9 +113,11 @@ def main():
     M, R, H = 2 * n, n * (n - 1) // 2 + n, 50
     from fermiflow_amd import _lib as L
     radial = L.RADIAL_MODE
-    flop_per_eval = (R * H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else R * FLOP_PER_TABLE_RADIUS) + M * R * FLOP_PER_JET_TERM
+    P = n * (n - 1) // 2
+    flop_per_eval = (R * ((H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else FLOP_PER_TABLE_RADIUS) + FLOP_PER_RADIUS_RECORD)
+                     + M * (P * FLOP_PER_PAIR_TERM + n * FLOP_PER_ONEBODY_TERM) + M * FLOP_PER_LANE_GATHER)
     achieved = evals * flop_per_eval / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": f"ff_ode_fwd_kernel<{n},2,2> (local-energy sensitivities)", "bound": "mfma",
+    roofline = {"kernel": "ff_ode_fwd_kernel<%d,2,2,%s> (local-energy sensitivities)" % (n, "true" if radial == "table" else "false"), "bound": "mfma",
                 "note": "fp64 VALU-bound; on MI355X the fp64 vector and fp64 MFMA peaks coincide (78.6 TFLOP/s); "
                         "MFMA is not used: the MLP is 1->50->1 (no dense GEMM)",
                 "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
@@ -120,13 +125,13 @@ def main():
                 "flop_per_walker_eval": flop_per_eval, "radial_functions": radial}
 
     # HBM bytes of the dominant kernel: not measurable live; taken from the committed rocprofv3 PMC pass
-    # (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01_g_hbm_traffic.json
+    # (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01_i_hbm_traffic.json
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")))
-        key = [k for k in tj if "ff_ode_fwd_kernel<%d, 2, 2>" % n in k]
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")))
+        key = [k for k in tj if "ff_ode_fwd_kernel<%d, 2, 2, true>" % n in k]
         if key and radial == "table" and args.walkers_per_gpu == 65536:
             roofline["traffic"] = tj[key[0]]["hbm_bytes_fetchx2_plus_write"]
-            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_g_hbm_traffic.json), bytes per launch"
+            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_i_hbm_traffic.json), bytes per launch"
             roofline["algorithmic_bytes"] = args.walkers_per_gpu * 8 * (M + M * M + 4 * M + 1)
     except Exception:
         pass
