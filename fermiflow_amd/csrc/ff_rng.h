@@ -1,7 +1,7 @@
 // ff_rng.h -- counter-based Philox4x32-10 + Box-Muller for the throughput-mode MCMC.
 // (The reference draws from torch's global generator, src/base_dist.py:62,65,68; bit-parity with it is
 // only possible by feeding its noise explicitly -- ff_mcmc_sample_noise.  This generator gives every
-// (walker, step, particle) its own counter, so results do not depend on how walkers are sharded.)
+// (walker, step, particle pair) its own counter, so results do not depend on how walkers are sharded.)
 #pragma once
 #include "ff_common.h"
 
@@ -34,6 +34,22 @@ FF_D void ff_normal_pair(uint64_t key, uint64_t walker, uint32_t step, uint32_t 
   ff_sincospi(2.0 * u2, &s, &c);
   z0 = rad * c;
   z1 = rad * s;
+}
+
+// four independent N(0,1) from one Philox block: Box-Muller on two pairs of 32-bit uniforms (u1 in (0,1] and u2 in
+// [0,1) on a 2^-32 grid: the normal's tail ends at 6.7 sigma and the angle grid maps onto itself under z -> -z, so the
+// Metropolis proposal stays exactly symmetric).  Slot `quad` of a (walker, step) serves particles 2*quad and 2*quad+1.
+FF_D void ff_normal_quad(uint64_t key, uint64_t walker, uint32_t step, uint32_t quad, double* z) {
+  ff_u4 r = ff_philox(key, walker, step, quad);
+  const double s32 = 2.3283064365386963e-10;   // 2^-32
+  const double ua = ((double)r.x + 1.0) * s32, ub = (double)r.y * s32;
+  const double uc = ((double)r.z + 1.0) * s32, ud = (double)r.w * s32;
+  const double ra = sqrt(-2.0 * ff_log(ua)), rc = sqrt(-2.0 * ff_log(uc));
+  double sn, cs;
+  ff_sincospi(2.0 * ub, &sn, &cs);
+  z[0] = ra * cs; z[1] = ra * sn;
+  ff_sincospi(2.0 * ud, &sn, &cs);
+  z[2] = rc * cs; z[3] = rc * sn;
 }
 
 // uniform in [0,1) (torch.rand_like semantics)

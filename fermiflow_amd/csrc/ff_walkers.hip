@@ -90,7 +90,13 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
     for (int i = 0; i < MAXM; i++) if (i < M) x[i] = g0[b * M + i];
   } else {
 #pragma unroll
-    for (int j = 0; j < MAXM / 2; j++) if (j < n) ff_normal_pair(seed, wid, 0u, (uint32_t)j, x[2 * j], x[2 * j + 1]);
+    for (int q = 0; q < (MAXM + 3) / 4; q++)
+      if (2 * q < n) {
+        double z4[4];
+        ff_normal_quad(seed, wid, 0u, (uint32_t)q, z4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (4 * q + k < MAXM && 4 * q + k < M) x[4 * q + k] = z4[k];
+      }
   }
   double logp = ff_logprob_value<NU, ND>(nup, ndn, ou, od, x, md);
   int nacc = 0;
@@ -116,12 +122,13 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < MAXM / 2; j++)
-        if (j < n) {
-          double z0, z1;
-          ff_normal_pair(seed, wid, (uint32_t)(s + 1), (uint32_t)j, z0, z1);
-          nx[2 * j] = ff_add_rn(x[2 * j], ff_mul_rn(tau, z0));
-          nx[2 * j + 1] = ff_add_rn(x[2 * j + 1], ff_mul_rn(tau, z1));
+      for (int q = 0; q < (MAXM + 3) / 4; q++)
+        if (2 * q < n) {
+          double z4[4];
+          ff_normal_quad(seed, wid, (uint32_t)(s + 1), (uint32_t)q, z4);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (4 * q + k < MAXM && 4 * q + k < M) nx[4 * q + k] = ff_add_rn(x[4 * q + k], ff_mul_rn(tau, z4[k]));
         }
     }
     double nl = ff_logprob_value<NU, ND>(nup, ndn, ou, od, nx, md);
@@ -155,10 +162,18 @@ ff_rng_fill_kernel(int64_t B, int n, int steps, uint64_t seed, int64_t woff, dou
   if (b >= B) return;
   const int M = 2 * n;
   const uint64_t wid = (uint64_t)(woff + b);
-  for (int j = 0; j < n; j++) ff_normal_pair(seed, wid, 0u, (uint32_t)j, g0[b * M + 2 * j], g0[b * M + 2 * j + 1]);
+  for (int q = 0; 2 * q < n; q++) {
+    double z4[4];
+    ff_normal_quad(seed, wid, 0u, (uint32_t)q, z4);
+    for (int k = 0; k < 4; k++) if (4 * q + k < M) g0[b * M + 4 * q + k] = z4[k];
+  }
   for (int s = 0; s < steps; s++) {
     double* gs = g + ((int64_t)s * B + b) * M;
-    for (int j = 0; j < n; j++) ff_normal_pair(seed, wid, (uint32_t)(s + 1), (uint32_t)j, gs[2 * j], gs[2 * j + 1]);
+    for (int q = 0; 2 * q < n; q++) {
+      double z4[4];
+      ff_normal_quad(seed, wid, (uint32_t)(s + 1), (uint32_t)q, z4);
+      for (int k = 0; k < 4; k++) if (4 * q + k < M) gs[4 * q + k] = z4[k];
+    }
     u[(int64_t)s * B + b] = ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
   }
 }
