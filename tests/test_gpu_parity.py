@@ -419,3 +419,38 @@ def test_walker_schedule_is_invisible_in_the_results(dev):
                                   walker_order=native.walker_order(steps0))
     assert torch.equal(gx0, gx1)
     assert (gp0 - gp1).abs().max().item() <= 1e-12 * gp0.abs().max().item()
+
+
+def test_off_table_radii_are_served_by_the_direct_kernels(golden, dev):
+    """Off-table protocol of the forward kernels: with the particles in two clusters 34 apart some pair
+    distance exceeds the table's 32, the table kernel leaves its launch id in the table header and the direct kernel queued
+    behind it redoes the call -- so the table net and the exact net return bit-identical results (same kernel), for
+    the flow, the local energy (one lane and two lanes per direction) and the adjoint.  Walkers inside the table are
+    NOT bit-identical between the two nets (different arithmetic), which shows the fallback did run above."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    for nup, ndn in ((3, 3), (4, 4)):
+        n = nup + ndn
+        model = Gm._model(dev, nup, ndn, 2.0)
+        v = model.cnf.v_wrapper.v
+        tu, td = model._tables(dev)
+        tab, exact = v.net(radial="table"), v.net(radial="exact")
+        g = torch.Generator().manual_seed(3)
+        near = torch.randn(40, n, 2, generator=g, dtype=torch.float64).to(dev)
+        far = near.clone()
+        far[:, ::2, 0] += 17.0
+        far[:, 1::2, 0] -= 17.0
+        assert torch.cdist(far, far).max() > 33
+        for z, same in ((far, True), (near, False)):
+            xt = native.cnf_generate(tab, z, 0.0, 1.0, 1e-6, 1e-8)
+            xe = native.cnf_generate(exact, z, 0.0, 1.0, 1e-6, 1e-8)
+            rt = native.eloc(tu, td, nup, ndn, tab, z, 0.0, 1.0, 1e-6, 1e-8, 2.0, True)
+            re = native.eloc(tu, td, nup, ndn, exact, z, 0.0, 1.0, 1e-6, 1e-8, 2.0, True)
+            if same:
+                assert torch.equal(xt, xe)
+                assert torch.isfinite(rt["z"]).all() and torch.isfinite(rt["dlogp"]).all()
+                for k in ("z", "dlogp", "grad", "lap"):      # (the flow carries some walkers to |r| ~ 38, where exp(-r^2/2)
+                    assert torch.allclose(rt[k], re[k], rtol=0.0, atol=0.0, equal_nan=True), k   # underflows: NaN on both sides)
+            else:
+                assert not torch.equal(xt, xe) and (xt - xe).abs().max() < 1e-10
+                assert not torch.equal(rt["lap"], re["lap"])
