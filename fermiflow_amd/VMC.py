@@ -8,6 +8,7 @@ reference training loop (`gradE = model(batch); gradE.backward(); optimizer.step
 src/FermionHO2D.py:66-72) runs unchanged.  With torch.distributed initialised, `batch` is the GLOBAL
 number of walkers; each rank handles its contiguous shard and the estimator sums are all-reduced (dist.py).
 """
+import os
 import time
 from collections import Counter
 
@@ -54,6 +55,9 @@ class GSVMC(torch.nn.Module):
         self.pair_potential = pair_potential
         self.sp_potential = sp_potential
         self.profile = None
+        # ODE step-size warm start inside forward(); FERMIFLOW_WARM_START=0 restores the cold start
+        self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
+        self._h_flow = None
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
     @property
@@ -115,14 +119,26 @@ class GSVMC(torch.nn.Module):
             t0, t1 = self.cnf.t_span
             net = self.cnf.v_wrapper.v.net()
             steps = torch.empty(nloc, dtype=torch.int32, device=z.device)
-            x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=steps)
+            # Step-size warm start (ff_ode.walker_h_*): the three integrations of a sweep follow the same trajectories, so
+            # each one opens with the step size the previous one settled on (scaled: the sensitivity system wants ~0.6 of
+            # the flow's step, the adjoint ~1.25 of the sensitivities') instead of the ~20x too small Hairer start; the
+            # flow pass itself starts from the step sizes of the previous sweep.  Error control per step is unchanged.
+            warm = self.warm_start
+            hg = torch.empty(nloc, dtype=torch.float64, device=z.device) if warm else None
+            hprev = self._h_flow if (warm and self._h_flow is not None and self._h_flow.shape[0] == nloc
+                                     and self._h_flow.device == z.device) else None
+            x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=steps,
+                                    walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg)
+            self._h_flow = hg
+            he = torch.empty_like(hg) if warm else None
             order = native.walker_order(steps)
             mark("generate")
             p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
             tu, td = self._tables(x.device)
             r = native.eloc(tu, td, self.nup, self.ndown, net, x, t0, t1, self.cnf.rtol,
                             self.cnf.atol, getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None,
-                            want_stats=prof is not None, pass1_events=p1, walker_order=order)
+                            want_stats=prof is not None, pass1_events=p1, walker_order=order,
+                            walker_h_init=hg, walker_h_scale=0.6, walker_h_out=he)
             mark("eloc")
             Eloc = r["eloc"]
             # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the
@@ -134,7 +150,8 @@ class GSVMC(torch.nn.Module):
             v, params = _flow_params(self.cnf)
             mark("estimator")
             _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
-                                       self.cnf.rtol, self.cnf.atol, need_gx=False)   # (uniform cost: no schedule)
+                                       self.cnf.rtol, self.cnf.atol, need_gx=False,   # (uniform cost: no schedule)
+                                       walker_h_init=he, walker_h_scale=1.25)
             buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
             D.all_reduce_sum_(buf)
             mark("adjoint")

@@ -28,7 +28,8 @@ class FFNet(C.Structure):
 
 class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
-                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p)]
+                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
+                ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p)]
 
 
 def lib():
@@ -120,11 +121,14 @@ class Net:
         return C.byref(self.c)
 
 
-def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None):
-    """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids)."""
-    for name, tns in (("walker_cost", walker_cost), ("walker_order", walker_order)):
-        if tns is not None and not (tns.dtype == torch.int32 and tns.is_contiguous() and tns.is_cuda):
-            raise ValueError(f"{name} must be a contiguous int32 device tensor")
-    return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps),
-                 walker_cost.data_ptr() if walker_cost is not None else None,
-                 walker_order.data_ptr() if walker_order is not None else None)
+def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, walker_h_init=None, walker_h_scale=1.0,
+        walker_h_out=None):
+    """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
+    walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start)."""
+    for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),
+                          ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64)):
+        if tns is not None and not (tns.dtype == dt and tns.is_contiguous() and tns.is_cuda):
+            raise ValueError(f"{name} must be a contiguous {dt} device tensor")
+    p = lambda t: t.data_ptr() if t is not None else None
+    return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps), p(walker_cost), p(walker_order),
+                 p(walker_h_init), float(walker_h_scale), p(walker_h_out))

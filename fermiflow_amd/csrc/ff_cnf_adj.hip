@@ -37,6 +37,9 @@ struct ff_adj_args {
   double* trows;        // (gridDim.x, 2, FF_DEP_NLDS, FF_DEP_ROW) private coefficient tables, then Wtot (tabulated kernel)
   double* off_table;    // one double, zeroed per call: set to 1 when a radius falls off the deposit table
   int32_t* stats;
+  const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
+  double h_scale;
+  double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
 };
@@ -112,6 +115,10 @@ ff_ode_adj_kernel(ff_adj_args A) {
         for (int c = 0; c < 3; c++) tent[t][j][c] = 0.0;
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
+    // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
+    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const bool warm = hwarm > 0.0;
+    double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
 
@@ -302,6 +309,12 @@ ff_ode_adj_kernel(ff_adj_args A) {
         d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
+        // every walker of the wave brings its own first step: no probe evaluation
+        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
+          S.habs = fmin(hwarm, S.interval);
+          S.plan();
+          s = 1;
+        }
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
@@ -311,6 +324,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
         }
         const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
+        if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
       } else if (s == 0) {   // re-evaluated f(y) after a rejection (k0 and its parameter integrand)
@@ -359,6 +373,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
         const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
+        if (acc) hmax_acc = fmax(hmax_acc, fabs(h));
         if (acc) {
 #pragma unroll
           for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
@@ -381,6 +396,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     if (valid) {
       if (A.gx_out) A.gx_out[b * M + i] = y[1];
       if (i == 0) {
+        if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
@@ -566,6 +582,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     ff_rec r0[NSLOT], r2[NSLOT], r3[NSLOT], r4[NSLOT], r5[NSLOT], r6[NSLOT];
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
+    // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
+    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const bool warm = hwarm > 0.0;
+    double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
 
@@ -693,6 +713,12 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
+        // every walker of the wave brings its own first step: no probe evaluation
+        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
+          S.habs = fmin(hwarm, S.interval);
+          S.plan();
+          s = 1;
+        }
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
@@ -702,6 +728,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
         const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
+        if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
       } else if (s == 0) {
@@ -751,6 +778,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
+        if (acc) hmax_acc = fmax(hmax_acc, fabs(h));
         if (acc) {
 #pragma unroll
           for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
@@ -778,6 +806,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     if (valid) {
       if (A.gx_out) A.gx_out[b * M + i] = y[1];
       if (i == 0) {
+        if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
@@ -941,6 +970,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);

@@ -48,6 +48,9 @@ struct ff_fwd_args {
   double* dD;           // (B, M)   d Delta / d x_i
   double* Lpart;        // (B, M)   per-direction parts of lap_x Delta
   int32_t* stats;
+  const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
+  double h_scale;
+  double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place
   // Off-table protocol (TAB kernels): a kernel that meets a radius beyond the table, or an unusable table, stores
@@ -187,6 +190,10 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     }
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
+    // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
+    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const bool warm = hwarm > 0.0;
+    double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
     double rmin_q[NQ];   // this lane's radii keep their slots from evaluation to evaluation
@@ -464,6 +471,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
+        // every walker of the wave brings its own first step: no probe evaluation
+        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
+          S.habs = fmin(hwarm, S.interval);
+          S.plan();
+          s = 1;
+        }
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
@@ -473,6 +486,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         }
         const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
+        if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
       } else if (s == 0) {
@@ -523,6 +537,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
+        if (acc) hmax_acc = fmax(hmax_acc, fabs(h));
         if (acc) {
 #pragma unroll
           for (int v = 0; v < NV; v++) { y[v] = in[v]; c0[v] = out[v]; }
@@ -557,6 +572,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         A.Lpart[b * M + i] = y[M + 4];
       }
       if (i == 0) {
+        if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) {
           double rm = 1e300;
           for (int p = 0; p < nrad; p++) rm = fmin(rm, s_rmin[g][p]);
@@ -699,6 +715,10 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     for (int k = 0; k < MH; k++) y[1 + k] = (h * MH + k == i) ? 1.0 : 0.0;
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
+    // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
+    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const bool warm = hwarm > 0.0;
+    double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
 
@@ -912,6 +932,12 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         d1v = sqrt(group_sum(p1) * (1.0 / NT));
         h0v = S.h0(d0, d1v);
         s = -1;
+        // every walker of the wave brings its own first step: no probe evaluation
+        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
+          S.habs = fmin(hwarm, S.interval);
+          S.plan();
+          s = 1;
+        }
       } else if (s == -1) {
         double p2 = 0.0;
 #pragma unroll
@@ -921,6 +947,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         }
         const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
         S.init_habs(h0v, d1v, d2);
+        if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
       } else if (s == 0) {
@@ -971,6 +998,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         const double err = sqrt(group_sum(pe) * (1.0 / NT));
         const bool was_active = !S.done;
         const bool acc = S.decide(err, A.max_steps);
+        if (acc) hmax_acc = fmax(hmax_acc, fabs(hs));
         if (acc) {
 #pragma unroll
           for (int v = 0; v < NV; v++) { y[v] = in[v]; c0[v] = out[v]; }
@@ -999,6 +1027,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       if (h == 0) { A.dD[b * M + i] = dD_i; A.Lpart[b * M + i] = L_i; }
       if (idx == 0) {
         A.dl_out[b] = delta;
+        if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
         acc_max = S.nacc > acc_max ? S.nacc : acc_max;
@@ -1232,6 +1261,7 @@ int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, co
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
   a.y_in = z; a.y_out = x_out; a.stats = stats;
   return dispatch_fwd<0>(stream, n, d, a);
 }
@@ -1246,6 +1276,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
   return dispatch_fwd<1>(stream, n, d, a);
 }
@@ -1282,6 +1313,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
   return dispatch_fwd<2>(stream, n, d, a);
 }

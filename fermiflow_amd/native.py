@@ -114,31 +114,31 @@ def _stats(device, want):
     return torch.zeros(int(os.environ.get("FF_STATS_WORDS", "32")), dtype=torch.int32, device=device) if want else None
 
 
-def cnf_generate(net, z, t0, t1, rtol, atol, want_stats=False, walker_cost=None, walker_order=None):
+def cnf_generate(net, z, t0, t1, rtol, atol, want_stats=False, walker_cost=None, walker_order=None, **warm):
     z = L.dev(z, name="z")
     B, n, d = z.shape
     x = torch.empty_like(z)
     st = _stats(z.device, want_stats)
-    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order)
+    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     L.check(L.lib().ff_cnf_generate(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(z), L.ptr(x), L.ptr(st)),
             "ff_cnf_generate")
     return (x, st) if want_stats else x
 
 
-def cnf_delta_logp(net, x, t0, t1, rtol, atol, want_stats=False, walker_cost=None, walker_order=None):
+def cnf_delta_logp(net, x, t0, t1, rtol, atol, want_stats=False, walker_cost=None, walker_order=None, **warm):
     x = L.dev(x, name="x")
     B, n, d = x.shape
     z = torch.empty_like(x)
     dl = torch.empty(B, dtype=torch.float64, device=x.device)
     st = _stats(x.device, want_stats)
-    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order)
+    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     L.check(L.lib().ff_cnf_delta_logp(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(x), L.ptr(z), L.ptr(dl),
                                       L.ptr(st)), "ff_cnf_delta_logp")
     return (z, dl, st) if want_stats else (z, dl)
 
 
 def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, want_stats=False, walker_cost=None,
-                walker_order=None):
+                walker_order=None, **warm):
     """Adjoint sweep from t_from (where y_start, a_z, a_d are given) to t_to."""
     y = L.dev(y_start, name="y_start"); a_z = L.dev(a_z, name="a_z"); a_d = L.dev(a_d, name="a_d")
     B, n, d = y.shape
@@ -147,14 +147,14 @@ def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, 
     nbytes = L.lib().ff_cnf_adjoint_workspace_bytes(L.i64(B), n, d, net.He, net.Hm)
     ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=y.device)
     st = _stats(y.device, want_stats)
-    o = L.ode(t_from, t_to, rtol, atol, walker_cost=walker_cost, walker_order=walker_order)
+    o = L.ode(t_from, t_to, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     L.check(L.lib().ff_cnf_adjoint(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(a_d),
                                    L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint")
     return (gx, gp, st) if want_stats else (gx, gp)
 
 
 def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker_state=None, want_stats=False,
-         pass1_events=None, walker_cost=None, walker_order=None):
+         pass1_events=None, walker_cost=None, walker_order=None, **warm):
     """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity kernel
     only (bench.py times the dominant kernel with it)."""
     x = L.dev(x, name="x")
@@ -165,7 +165,7 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, 2)
     ws = torch.empty(max(1, nbytes // 8), **f)
     st = _stats(x.device, want_stats)
-    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order)
+    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     if pass1_events is not None:
         pass1_events[0].record()
     L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, 2, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),

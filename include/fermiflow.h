@@ -49,6 +49,15 @@ typedef struct ff_ode {
    * Results are written to each walker's own slot, so the order changes timing only. */
   int32_t* walker_cost;
   const int32_t* walker_order;
+  /* Step-size warm start, optional (NULL).  The cold start (Hairer's rule, as scipy/torchdiffeq) spends one RHS
+   * evaluation on a probe and then opens with a step ~20x smaller than the controller settles on, which the x10 growth
+   * cap turns into two nearly free steps: 26 evaluations where 14-20 do.  walker_h_init (in, B): first step size to
+   * try, times walker_h_scale; entries <= 0 (or NaN) start cold.  walker_h_out (out, B): the largest step size accepted
+   * for the walker in this call -- a scale for the next integration along the same trajectory.  The error control of
+   * every step is unchanged. */
+  const double* walker_h_init;
+  double walker_h_scale;
+  double* walker_h_out;
 } ff_ode;
 
 int ff_version(void);

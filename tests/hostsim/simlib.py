@@ -19,7 +19,8 @@ class FFNet(C.Structure):
 
 class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
-                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p)]
+                ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
+                ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p)]
 
 
 def build():
@@ -145,9 +146,18 @@ def mlp(r, w1, b1, w2):
     return v, dv
 
 
+_WARM = {}     # set by warm(h_init=..., h_scale=..., h_out=...) for the next calls (keeps the wrappers' signatures short)
+
+
+def warm(h_init=None, h_scale=1.0, h_out=None):
+    _WARM.clear()
+    _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out)
+
+
 def _ode(t0, t1, rtol, atol, steps=None, order=None):
-    return FFOde(t0, t1, rtol, atol, 0, steps.ctypes.data if steps is not None else None,
-                 order.ctypes.data if order is not None else None)
+    q = lambda a: a.ctypes.data if a is not None else None
+    return FFOde(t0, t1, rtol, atol, 0, q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
+                 q(_WARM.get("h_out")))
 
 
 def walker_order(cost):

@@ -454,3 +454,51 @@ def test_off_table_radii_are_served_by_the_direct_kernels(golden, dev):
             else:
                 assert not torch.equal(xt, xe) and (xt - xe).abs().max() < 1e-10
                 assert not torch.equal(rt["lap"], re["lap"])
+
+
+def test_step_size_warm_start(dev):
+    """ff_ode.walker_h_init/_scale/_out: opening every integration with the step size the previous one
+    along the same trajectory settled on saves the probe evaluation and the two tiny first steps of the cold start --
+    a quarter of the RHS evaluations -- while the per-step error control, hence the accuracy, stays what it was:
+    warm and cold results agree far inside the solver tolerance and are equally close to a tight-tolerance solve."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    B = 8192
+    torch.manual_seed(9)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    f = dict(dtype=torch.float64, device=dev)
+    hg, he = torch.zeros(B, **f), torch.zeros(B, **f)
+    x, st_c = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, want_stats=True, walker_h_out=hg)
+    assert 0.0 < float(hg.min()) and float(hg.max()) <= 1.0
+    # entries <= 0 start cold: bit-identical to no warm start at all
+    x0 = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_h_init=torch.zeros(B, **f), walker_h_scale=1.0)
+    assert torch.equal(x0, x)
+    xw, st_w = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, want_stats=True, walker_h_init=hg, walker_h_scale=0.75)
+    assert int(st_w[0]) < 0.75 * int(st_c[0]) and (xw - x).abs().max().item() < 1e-6
+    tight = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)
+    cold = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True)
+    warm = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True,
+                       walker_h_init=hg, walker_h_scale=0.6, walker_h_out=he)
+    assert int(warm["stats"][0]) < 0.8 * int(cold["stats"][0]) and int(warm["stats"][3]) == 0
+    rel = lambda r: ((r["eloc"] - tight["eloc"]).abs() / tight["eloc"].abs()).max().item()
+    assert rel(warm) < ELOC_RTOL / 10 and rel(warm) < 10 * rel(cold) + 1e-8, (rel(warm), rel(cold))
+    w = (tight["eloc"] - tight["eloc"].mean()) / B
+    args = (tight["z"], w[:, None, None] * tight["glogp0"], -w, 0.0, 1.0)
+    _, g_t = native.cnf_adjoint(net, *args, 1e-11, 1e-13, need_gx=False)
+    _, g_c, sc = native.cnf_adjoint(net, *args, 1e-6, 1e-8, need_gx=False, want_stats=True)
+    _, g_w, sw = native.cnf_adjoint(net, *args, 1e-6, 1e-8, need_gx=False, want_stats=True, walker_h_init=he, walker_h_scale=1.25)
+    assert int(sw[0]) < 0.75 * int(sc[0])
+    err = lambda g: ((g - g_t).norm() / g_t.norm()).item()
+    assert err(g_w) < 1e-6 and err(g_w) < 10 * err(g_c) + 1e-8, (err(g_w), err(g_c))
+    # the sweep uses it by default; switching it off changes the estimate only at the solver-tolerance level
+    Es = []
+    for flag in (True, False):
+        m = Gm._model(dev, 3, 3, 2.0)
+        m.warm_start = flag
+        torch.manual_seed(21)
+        m(4096); m(4096)                      # second sweep: the flow pass is warm too
+        Es.append((m.E, m.E_std))
+    assert abs(Es[0][0] - Es[1][0]) < 1e-6 * abs(Es[1][0]) and abs(Es[0][1] - Es[1][1]) < 1e-5 * Es[1][1]

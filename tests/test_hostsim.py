@@ -210,3 +210,40 @@ def test_walker_schedule_changes_nothing_but_the_order_of_work(golden):
         gx1, gp1, _ = S.cnf_adjoint(r0["z"], w[:, None, None] * r0["glogp0"], -w, net, steps=st1, order=S.walker_order(st0))
         assert np.array_equal(gx0, gx1) and np.array_equal(st0, st1)
         np.testing.assert_allclose(gp1, gp0, rtol=1e-10, atol=1e-14)
+
+
+def test_step_size_warm_start_semantics(golden):
+    """ff_ode.walker_h_init / walker_h_scale / walker_h_out in the kernels' host build: non-positive entries start cold
+    (bit-identical), positive ones skip the probe stage and open with that step; h_out is the largest accepted step."""
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    net = S.Net(eta, mu, table=True)
+    x = G["z2_nt_x"][:7]
+    B = len(x)
+    try:
+        hg = np.zeros(B)
+        S.warm(h_out=hg)
+        z0, st0 = S.cnf_generate(x, net)
+        assert np.all(hg > 0) and np.all(hg <= 1.0)
+        S.warm(h_init=np.zeros(B))
+        z1, st1 = S.cnf_generate(x, net)
+        assert np.array_equal(z0, z1) and st0[0] == st1[0]
+        S.warm(h_init=hg, h_scale=0.75)
+        z2, st2 = S.cnf_generate(x, net)
+        assert st2[0] < st0[0] and np.abs(z2 - z0).max() < 1e-6
+        he = np.zeros(B)
+        S.warm()
+        r0 = S.eloc(x, 3, 3, net, 2.0)
+        S.warm(h_init=hg, h_scale=0.6, h_out=he)
+        r1 = S.eloc(x, 3, 3, net, 2.0)
+        assert r1["stats"][0] < r0["stats"][0] and np.all(he > 0)
+        np.testing.assert_allclose(r1["eloc"], r0["eloc"], rtol=1e-6)
+        w = (r0["eloc"] - r0["eloc"].mean()) / B
+        S.warm()
+        _, gp0, s0 = S.cnf_adjoint(r0["z"], w[:, None, None] * r0["glogp0"], -w, net)
+        S.warm(h_init=he, h_scale=1.25)
+        _, gp1, s1 = S.cnf_adjoint(r0["z"], w[:, None, None] * r0["glogp0"], -w, net)
+        assert s1[0] < s0[0]
+        np.testing.assert_allclose(gp1, gp0, rtol=1e-5, atol=1e-9 * np.abs(gp0).max())
+    finally:
+        S.warm()
