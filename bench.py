@@ -160,7 +160,7 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         nbytes = Bm * S * (8 * M + 8 + 1) + Bm * (2 * 8 * M + 8)     # noise + uniforms + accept mask; init + final x, logp
         del g0, g, u
-        out["roofline_hbm"] = {"kernel": f"ff_mcmc_kernel<{args.nup},{args.ndown},noise>", "bound": "hbm",
+        out["roofline_hbm"] = {"kernel": (f"ff_mcmc_spin_kernel<{args.nup},noise>" if args.nup == args.ndown and 1 <= args.nup <= 6 else f"ff_mcmc_kernel<{args.nup},{args.ndown},noise>"), "bound": "hbm",
                                "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
                                "walker_steps_per_s": Bm * S / (ms * 1e-3)}

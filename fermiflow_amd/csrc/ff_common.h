@@ -80,6 +80,18 @@ FF_D void ff_sqrt_rcp(double r2, double& r, double& ri) {
 #endif
 }
 
+// value held by the neighbouring lane (lane ^ 1): one DPP quad permutation per 32-bit half, no LDS
+FF_D double ff_swap1(double v) {
+#ifdef FF_HOSTSIM
+  return ff_sim_swap1(v);
+#else
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
+
 // --- exp for |x| <= 708.  Rounding and scaling use the integer pipe instead of the quarter-rate
 //     v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64: adding 1.5*2^52 leaves round(x*log2e) in the low mantissa word, and
 //     2^k is applied by adding k to the exponent field (the polynomial value is in [0.7,1.42], |k| <= 1010: always normal).

@@ -5,6 +5,7 @@
 // wave of 64 consecutive walkers reads one contiguous 64*n*d*8-byte span (fully used cache lines).
 // The Metropolis sweep keeps a walker's coordinates and log-probability in VGPRs for all `steps` proposals:
 // per walker-step the only HBM traffic is the proposal noise (parity mode) or nothing at all (Philox mode).
+#include <stdlib.h>
 #include "ff_common.h"
 #include "ff_slater.h"
 #include "ff_rng.h"
@@ -152,6 +153,109 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
   for (int i = 0; i < MAXM; i++) if (i < M) x_out[b * M + i] = x[i];
   if (logp_out) logp_out[b] = logp;
   if (acc_count) acc_count[b] = nacc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Metropolis chain with TWO lanes per walker, one per spin species (NU = ND = NS): at 65 536 walkers one lane per
+// walker is one wave per SIMD and nothing hides the latency of its serial chain (Philox rounds, Box-Muller, pivots).
+// Lane (b, spin) draws the proposals of its own particles, evaluates its own determinant; the two log|det| meet through
+// one DPP swap (a + b is commutative: both lanes form the identical sum, and it is the reference's 2*(up + down)), both
+// lanes take the same accept decision.  Same noise stream, same results, bit for bit, as ff_mcmc_kernel.
+template <int NS, bool NOISE>
+__global__ void __launch_bounds__(128)
+ff_mcmc_spin_kernel(int64_t B, const int* __restrict__ tab_up, const int* __restrict__ tab_dn, const int* __restrict__ wstate,
+                    int steps, double tau, const double* __restrict__ g0, const double* __restrict__ g,
+                    const double* __restrict__ u, uint64_t seed, int64_t woff, double* __restrict__ x_out,
+                    double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
+  constexpr int MS = 2 * NS, M = 2 * MS, n = 2 * NS;
+  // quads (Philox blocks of four normals, coordinates 4q..4q+3 of the walker) that cover one spin's coordinates
+  constexpr int NQ0 = (MS - 1) / 4 + 1, NQ1 = (2 * MS - 1) / 4 - MS / 4 + 1, NQ = NQ0 > NQ1 ? NQ0 : NQ1;
+  __shared__ int s_md;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1), off = sp * MS;
+  if (threadIdx.x == 0) s_md = 0;
+  __syncthreads();
+  const bool live = b < B;
+  if (!live) b = B - 1;
+  const int st = wstate ? wstate[b] : 0;
+  const int* __restrict__ tab = sp ? tab_dn : tab_up;
+  int oo[2 * NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) ff_orb_decode(tab[st * NS + j], oo[j], oo[NS + j]);
+  int md = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * NS; j++) md = oo[j] > md ? oo[j] : md;
+  atomicMax(&s_md, md);
+  __syncthreads();
+  md = FF_UNIFORM(s_md);
+
+  double x[MS], nx[MS];
+  const uint64_t wid = (uint64_t)(woff + b);
+  const int q0 = off >> 2;
+  auto draw = [&](uint32_t step, double* dst, bool propose) {   // this spin's normals of one step
+    double Z[NQ][4];
+#pragma unroll
+    for (int qq = 0; qq < NQ; qq++) ff_normal_quad(seed, wid, step, (uint32_t)(q0 + qq), Z[qq]);
+#pragma unroll
+    for (int i = 0; i < MS; i++) {
+      // coordinate off + i of the walker sits in quad (off + i) / 4; both spins' positions are compile-time constants
+      const double za = Z[i >> 2][i & 3], zb = Z[((MS + i) >> 2) - (MS >> 2)][(MS + i) & 3];
+      const double zv = (MS % 4 == 0) ? za : (sp ? zb : za);
+      dst[i] = propose ? ff_add_rn(x[i], ff_mul_rn(tau, zv)) : zv;
+    }
+  };
+  if (NOISE) {
+#pragma unroll
+    for (int i = 0; i < MS; i++) x[i] = g0[b * M + off + i];
+  } else {
+    draw(0u, x, false);
+  }
+  const double L0 = ff_slater_logabsdet_reg<NS>(oo, oo + NS, x, md);
+  double logp = 2.0 * (L0 + ff_swap1(L0));
+  int nacc = 0;
+  double gq[MS], uq = 0.0;
+  if (NOISE && steps > 0) {
+#pragma unroll
+    for (int i = 0; i < MS; i++) gq[i] = g[b * M + off + i];
+    uq = u[b];
+  }
+  for (int s = 0; s < steps; s++) {
+    double ucur = 0.0;
+    if (NOISE) {
+#pragma unroll
+      for (int i = 0; i < MS; i++) nx[i] = ff_add_rn(x[i], ff_mul_rn(tau, gq[i]));
+      ucur = uq;
+      if (s + 1 < steps) {
+        const double* gs = g + ((int64_t)(s + 1) * B + b) * M + off;
+#pragma unroll
+        for (int i = 0; i < MS; i++) gq[i] = gs[i];
+        uq = u[(int64_t)(s + 1) * B + b];
+      }
+    } else {
+      draw((uint32_t)(s + 1), nx, true);
+    }
+    const double L = ff_slater_logabsdet_reg<NS>(oo, oo + NS, nx, md);
+    const double nl = 2.0 * (L + ff_swap1(L));
+    const double dlp = nl - logp;
+    const double p = !(dlp == dlp) ? dlp : (dlp < -708.0 ? 0.0 : ff_exp(fmin(dlp, 708.0)));
+    const double uu = NOISE ? ucur : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)n);
+    const bool acc = uu < p;
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < MS; i++) x[i] = nx[i];
+      logp = nl;
+      nacc++;
+    }
+    if (accept && live && sp == 0) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+  }
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < MS; i++) x_out[b * M + off + i] = x[i];
+  if (sp == 0) {
+    if (logp_out) logp_out[b] = logp;
+    if (acc_count) acc_count[b] = nacc;
+  }
 }
 
 // materialise the Philox noise stream of ff_mcmc_kernel<.., false>
@@ -349,6 +453,19 @@ template <int NU, int ND>
 static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
                         int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
                         double* x_out, double* logp_out, uint8_t* accept, int* acc_count) {
+  if constexpr (NU == ND && NU >= 1 && NU <= 6) {
+    // two lanes per walker (one per spin): twice the waves, half the chain per lane; FF_MCMC_ONE_LANE=1 keeps one lane
+    static const bool one_lane = getenv("FF_MCMC_ONE_LANE") != nullptr;
+    if (!one_lane) {
+      if (noise)
+        FF_LAUNCH((ff_mcmc_spin_kernel<NU, true>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, g, u, seed, woff,
+                  x_out, logp_out, accept, acc_count);
+      else
+        FF_LAUNCH((ff_mcmc_spin_kernel<NU, false>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, g, u, seed, woff,
+                  x_out, logp_out, accept, acc_count);
+      return;
+    }
+  }
   if (noise)
     FF_LAUNCH((ff_mcmc_kernel<NU, ND, true>), ff_grid(B, 128), 128, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff,
               x_out, logp_out, accept, acc_count);

@@ -59,6 +59,16 @@ inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (in
 inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &b, 8); return d; }
 inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 
+// lane ^ 1 exchange (DPP on the GPU): through a static array and the workgroup barrier; every lane must call it
+static double ff_sim_swap_buf[1024];
+inline double ff_sim_swap1(double v) {
+  ff_sim_swap_buf[threadIdx.x] = v;
+  __syncthreads();
+  const double o = ff_sim_swap_buf[threadIdx.x ^ 1];
+  __syncthreads();
+  return o;
+}
+
 template <class K, class... A>
 inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   pthread_barrier_t bar;
