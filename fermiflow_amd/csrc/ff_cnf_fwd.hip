@@ -1058,19 +1058,22 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 // block of J^T is ONE contiguous read (the one-lane-per-walker version of this contraction fetched every cache line
 // ~8 times: 730 MB per launch against 100 MB of sensitivities), each lane contracts its own direction, three LDS sums
 // finish the walker.
-// slots of Q: [0,M) g0 | [M, M+3n) S (particle-major) | then T_up (2 nup^2), T_dn (2 ndn^2) | last: logp0
+// slots of Q: [0,M) g0 | [M, M+3n) S (particle-major) | then T_up (2 nup^2), T_dn (2 ndn^2) | last two: 2 log|det| per spin
+// (one lane per (walker, spin species): twice the waves for a latency-bound serial routine)
 __global__ void __launch_bounds__(128)
 ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
                       const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1);
   if (b >= B) return;
   const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
   double zl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS], S[3 * FF_MAX_NS];
   double lp0 = 0.0;
-  int tq = M + 3 * n;
-  for (int sp = 0; sp < 2; sp++) {
+  int tq = M + 3 * n + (sp ? 2 * nup * nup : 0);
+  {
     const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-    if (!ns) continue;
+    if (!ns) { Q[(int64_t)(M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp) * B + b] = 0.0; return; }
     for (int k = 0; k < 2 * ns; k++) zl[k] = z0[b * M + 2 * off + k];
     lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T, S);
     for (int a = 0; a < ns; a++) {
@@ -1079,14 +1082,13 @@ ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_u
       for (int k = 0; k < 3; k++) Q[(int64_t)(M + 3 * (off + a) + k) * B + b] = S[3 * a + k];
     }
     for (int k = 0; k < 2 * ns * ns; k++) Q[(int64_t)(tq + k) * B + b] = T[k];
-    tq += 2 * ns * ns;
   }
-  Q[(int64_t)tq * B + b] = 2.0 * lp0;
+  Q[(int64_t)(M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp) * B + b] = 2.0 * lp0;
 }
 
 // dynamic LDS: [G*M*M J^T block | G*nq Slater slots | 64 x | 3*64 partial sums]  (10 KB at n = 6: many waves per CU)
 static size_t ff_contract_lds_bytes(int nup, int ndn) {
-  const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M, nq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 1;
+  const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M, nq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;
   return sizeof(double) * ((size_t)G * M * M + (size_t)G * nq + 4 * FF_WAVE);
 }
 __global__ void __launch_bounds__(FF_WAVE)
@@ -1099,7 +1101,7 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
   const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M;
   const int lane = threadIdx.x, g = lane / M, i = lane - g * M;
   const bool ingrp = g < G;
-  const int tsz = 2 * (nup * nup + ndn * ndn), nq = M + 3 * n + tsz + 1;
+  const int tsz = 2 * (nup * nup + ndn * ndn), nq = M + 3 * n + tsz + 2;
   double* const s_u = ff_fin_lds;                            // [g][i][k] = dz_k/dx_i
   double* const s_q = s_u + G * M * M;                       // [g][slot]
   double* const s_x = s_q + G * nq;
@@ -1162,7 +1164,7 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
     if (valid && i == 0) {
       double g2 = 0.0, lapv = 0.0, Vv = 0.0;
       for (int k = 0; k < M; k++) { g2 += s_red[0][g * M + k]; lapv += s_red[1][g * M + k]; Vv += s_red[2][g * M + k]; }
-      if (logp) logp[b] = s_q[g * nq + nq - 1] - delta[b];
+      if (logp) logp[b] = (s_q[g * nq + nq - 2] + s_q[g * nq + nq - 1]) - delta[b];
       if (lap) lap[b] = lapv;
       if (V) V[b] = Vv;
       if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv;
@@ -1284,7 +1286,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
 // sensitivities (z0, Jt, kbar, dD, Lpart, Delta) + the Slater table of the finish (g0, S, T <= 2 n^2, logp0)
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
   size_t M = (size_t)n * d;
-  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 1);
+  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 2);
 }
 
 struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl, *Q; };
@@ -1331,7 +1333,7 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
   const size_t M = (size_t)n * 2;
   ff_eloc_ws w = eloc_carve((void*)workspace, B, M);
   FF_CHECK(2 * n <= FF_WAVE, FF_EUNSUPPORTED, "ff_eloc_finish: n*d > 64");
-  FF_LAUNCH(ff_eloc_slater_kernel, (unsigned)((B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state,
+  FF_LAUNCH(ff_eloc_slater_kernel, (unsigned)((2 * B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state,
             (const double*)w.z0, w.Q);
   FF_LAUNCH_CHECK();
   {

@@ -8,12 +8,22 @@ import torch
 from . import _lib as L
 
 
+_TABLES = {}   # (orbital indices, device) -> device table; a host->device copy is a synchronisation point, so tables
+               # are uploaded once (they are a few integers that never change for a model)
+
+
 def orbital_table(idx, device):
-    """int32 device table [n_states, n_spin] from a (list of) orbital index list(s)."""
+    """int32 device table [n_states, n_spin] from a (list of) orbital index list(s); cached per device."""
     t = torch.as_tensor(idx, dtype=torch.int32)
     if t.dim() == 1:
         t = t[None]
-    return t.contiguous().to(device)
+    key = (tuple(t.shape), tuple(t.reshape(-1).tolist()), str(torch.device(device)))
+    tab = _TABLES.get(key)
+    if tab is None:
+        if len(_TABLES) > 256:
+            _TABLES.clear()
+        tab = _TABLES[key] = t.contiguous().to(device)
+    return tab
 
 
 def _state(ws):
