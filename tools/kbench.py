@@ -37,7 +37,14 @@ res = {"tag": a.tag, "B": a.B, "blocks": os.environ.get("FF_PERSIST_BLOCKS", "de
 res["mcmc_ms"], _ = timeit(lambda: native.mcmc_sample(tu, td, a.nup, a.ndown, a.B, 100, 0.1, 1, dev))
 steps = torch.empty(a.B, dtype=torch.int32, device=dev)
 sched = not os.environ.get("FF_NO_SCHED")
-res["generate_ms"], (x, st) = timeit(lambda: native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, want_stats=True, walker_cost=steps))
+warm = not os.environ.get("FF_NO_WARM")
+hg = torch.zeros(a.B, dtype=torch.float64, device=dev); he = torch.zeros_like(hg)
+x0 = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_h_out=hg)
+hprev = hg.clone() if warm else None
+res["generate_ms"], (x, st) = timeit(lambda: native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, want_stats=True, walker_cost=steps,
+                                                                 walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg))
+wk = dict(walker_h_init=hg, walker_h_scale=0.6, walker_h_out=he) if warm else {}
+wa = dict(walker_h_init=he, walker_h_scale=1.25) if warm else {}
 res["order_ms"], order = timeit(lambda: native.walker_order(steps))
 if not sched:
     order = None
@@ -46,20 +53,20 @@ res["logp_ms"], (_, _, st) = timeit(lambda: native.cnf_delta_logp(net, x, 0.0, 1
 res["logp_evals"] = st[0].item() / a.B
 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 steps2 = torch.empty_like(steps)
-r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_cost=steps2, walker_order=order)
+r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_cost=steps2, walker_order=order, **wk)
 order2 = native.walker_order(steps2) if sched else None
 res["steps_corr"] = float(torch.corrcoef(torch.stack([steps.double(), steps2.double()]))[0, 1])
 res["steps_max"] = [int(steps.max()), int(steps2.max())]
 tot = 0.0
 for _ in range(a.reps):
-    r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=ev, walker_order=order)
+    r = native.eloc(tu, td, a.nup, a.ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=ev, walker_order=order, **wk)
     torch.cuda.synchronize(); tot += ev[0].elapsed_time(ev[1])
 res["eloc_pass1_ms"] = tot / a.reps
 res["eloc_evals"] = r["stats"][0].item() / a.B
 res["eloc_rej"] = r["stats"][2].item() / a.B
 w = (r["eloc"] - r["eloc"].mean()) / a.B
 res["adjoint_ms"], (_, gp, st) = timeit(lambda: native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,
-                                                                   need_gx=False, want_stats=True, walker_order=order2))
+                                                                   need_gx=False, want_stats=True, walker_order=order2, **wa))
 res["adjoint_evals"] = st[0].item() / a.B
 sa = st[8:26].view(torch.int64)[:9].double()
 if sa.sum() > 0:   # 0 stage input, 1 publish, 2 radius, 3 component, 4 consume, 5 consume of stage 6 (deposit), per wave-eval
