@@ -58,6 +58,10 @@ class GSVMC(torch.nn.Module):
         # ODE step-size warm start inside forward(); FERMIFLOW_WARM_START=0 restores the cold start
         self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
         self._h_flow = None
+        # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
+        # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
+        n = nup + ndown
+        self._h_scale_eloc = 0.6 if n <= 8 else (0.45 if n <= 10 else 0.4)
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
     @property
@@ -120,9 +124,10 @@ class GSVMC(torch.nn.Module):
             net = self.cnf.v_wrapper.v.net()
             steps = torch.empty(nloc, dtype=torch.int32, device=z.device)
             # Step-size warm start (ff_ode.walker_h_*): the three integrations of a sweep follow the same trajectories, so
-            # each one opens with the step size the previous one settled on (scaled: the sensitivity system wants ~0.6 of
-            # the flow's step, the adjoint ~1.25 of the sensitivities') instead of the ~20x too small Hairer start; the
-            # flow pass itself starts from the step sizes of the previous sweep.  Error control per step is unchanged.
+            # each one opens with the step size the previous one settled on instead of the ~20x too small Hairer start
+            # (scaled: the sensitivity system wants 0.4-0.6 of the flow's step depending on the particle number, the
+            # adjoint ~1.25 of the sensitivities'); the flow pass
+            # itself starts from the step sizes of the previous sweep.  Error control per step is unchanged.
             warm = self.warm_start
             hg = torch.empty(nloc, dtype=torch.float64, device=z.device) if warm else None
             hprev = self._h_flow if (warm and self._h_flow is not None and self._h_flow.shape[0] == nloc
@@ -138,7 +143,7 @@ class GSVMC(torch.nn.Module):
             r = native.eloc(tu, td, self.nup, self.ndown, net, x, t0, t1, self.cnf.rtol,
                             self.cnf.atol, getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None,
                             want_stats=prof is not None, pass1_events=p1, walker_order=order,
-                            walker_h_init=hg, walker_h_scale=0.6, walker_h_out=he)
+                            walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he)
             mark("eloc")
             Eloc = r["eloc"]
             # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the

@@ -835,33 +835,25 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
 }
 
 // Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
-// One workgroup per FF_DEPR_E consecutive entries: lane (q, c) adds entry c of the tables q, q + Q, q + 2Q, ... -- every
-// read is a full 256-byte span of one table (one workgroup per entry read 8 bytes of every cache line it touched) -- and a
-// fixed tree over q finishes (deterministic).
-#define FF_DEPR_E 32
-__global__ void __launch_bounds__(256)
+// One workgroup per entry, lanes stride over the private tables, fixed-tree reduction (deterministic).
+__global__ void __launch_bounds__(128)
 ff_dep_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nblocks, const double* __restrict__ rows,
                      double* __restrict__ wtot) {
   const double* rtab = net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0)) return;
-  __shared__ double sm[256];
-  const int Q = blockDim.x / FF_DEPR_E > 0 ? blockDim.x / FF_DEPR_E : 1;   // table groups (8; the host simulator runs tiny blocks)
-  const int nent = 2 * FF_DEP_NLDS * FF_DEP_ROW;
-  for (int c0 = 0; c0 < FF_DEPR_E; c0 += blockDim.x / Q) {                  // one pass on the GPU
-    const int c = c0 + (int)threadIdx.x % (blockDim.x / Q), q = (int)threadIdx.x / (blockDim.x / Q);
-    const int e = blockIdx.x * FF_DEPR_E + c;
-    double s = 0.0;
-    if (c < FF_DEPR_E && e < nent)
-      for (int b = q; b < nblocks; b += Q) s += rows[(size_t)b * nent + e];
-    sm[threadIdx.x] = s;
+  __shared__ double sm[128];
+  const int e = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += rows[(size_t)b * 2 * FF_DEP_NLDS * FF_DEP_ROW + e];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
     __syncthreads();
-    if (q == 0 && c < FF_DEPR_E && e < nent) {
-      double tsum = 0.0;
-      for (int k = 0; k < Q; k++) tsum += sm[k * (blockDim.x / Q) + (int)threadIdx.x];
-      const int t = e / (FF_DEP_NLDS * FF_DEP_ROW), rem = e - t * FF_DEP_NLDS * FF_DEP_ROW;
-      wtot[(size_t)t * FF_DEP_NTOT * FF_DEP_ROW + rem] = tsum;
-    }
-    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int t = e / (FF_DEP_NLDS * FF_DEP_ROW), rem = e - t * FF_DEP_NLDS * FF_DEP_ROW;
+    wtot[(size_t)t * FF_DEP_NTOT * FF_DEP_ROW + rem] = sm[0];
   }
 }
 
@@ -1003,7 +995,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
     double* wtot = a.trows + (size_t)nblk * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_E - 1) / FF_DEPR_E), FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk,
+    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, (const double*)a.off_table, nblk,
               (const double*)a.trows, wtot);
     FF_LAUNCH_CHECK();
     FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)a.off_table,
