@@ -26,6 +26,9 @@ def _worker(rank, world, port, eloc_all, logp_all, g_all, out):
     off, cnt = D.shard(B)
     e = eloc_all[off:off + cnt]
     E, E_std, n = D.global_mean_std(e.sum(), cnt, lambda m: ((e - m) ** 2).sum())
+    # the sweep's variant: tensors in, tensors out, global count known on the host (no .item() anywhere)
+    Et, St = D.global_mean_std_dev(e.sum(), B, lambda tot, scale: ((e - tot[0] * scale) ** 2).sum())
+    assert isinstance(Et, torch.Tensor) and abs(Et.item() - E) < 1e-13 * abs(E) and abs(St.item() - E_std) < 1e-12 * E_std
     w = (e - E) / n
     buf = torch.cat([(logp_all[off:off + cnt] * w).sum().reshape(1), (w[:, None] * g_all[off:off + cnt]).sum(0)])
     D.all_reduce_sum_(buf)
