@@ -58,6 +58,11 @@ class GSVMC(torch.nn.Module):
         # ODE step-size warm start inside forward(); FERMIFLOW_WARM_START=0 restores the cold start
         self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
         self._h_flow = None
+        # Persistent walkers (off by default: the reference draws fresh N(0,1) walkers and runs 100 steps in every
+        # iteration, src/base_dist.py:62-64): keep the chains and advance them `persistent_steps` steps per sweep.
+        self.persistent_walkers = False
+        self.persistent_steps = 10
+        self._z_prev = None
         # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
         # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
         n = nup + ndown
@@ -115,7 +120,13 @@ class GSVMC(torch.nn.Module):
                 ev[name] = e
         with torch.no_grad():
             mark("t0")
-            z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
+            if self.persistent_walkers and self._z_prev is not None and self._z_prev.shape[0] == nloc:
+                # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
+                z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
+                                         equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
+            else:
+                z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
+            self._z_prev = z if self.persistent_walkers else None
             mark("mcmc")
             # Walker schedule (include/fermiflow.h, ff_ode.walker_cost/_order): the flow pass reports a cost class per
             # walker (how close its trajectory comes to a vanishing radius); the local-energy pass, whose step count

@@ -37,15 +37,20 @@ class FreeFermion(BaseDist):
         td = native.orbital_table(orbital_indices(orbitals_down), self.device) if len(orbitals_down) else None
         return tu, td
 
-    def sample(self, orbitals_up, orbitals_down, sample_shape, equilibrim_steps=100, tau=0.1):
-        """100-step Metropolis chain from N(0,1) walkers, fused in one kernel (src/base_dist.py:58-71)."""
+    def sample(self, orbitals_up, orbitals_down, sample_shape, equilibrim_steps=100, tau=0.1, x_init=None):
+        """100-step Metropolis chain from N(0,1) walkers, fused in one kernel (src/base_dist.py:58-71).
+        x_init (not in the reference): continue the chain of these walkers instead of starting from N(0,1)."""
         nup, ndown = len(orbitals_up), len(orbitals_down)
         B = 1
         for s in sample_shape:
             B *= int(s)
         tu, td = self._tables(orbitals_up, orbitals_down)
-        x, _, _ = native.mcmc_sample(tu, td, nup, ndown, B, equilibrim_steps, tau, _draw_seed(), self.device,
-                                     walker_offset=self.walker_offset)
+        if x_init is not None:
+            x, _, _ = native.mcmc_continue(tu, td, nup, ndown, x_init.reshape(B, nup + ndown, 2), equilibrim_steps, tau,
+                                           _draw_seed(), walker_offset=self.walker_offset)
+        else:
+            x, _, _ = native.mcmc_sample(tu, td, nup, ndown, B, equilibrim_steps, tau, _draw_seed(), self.device,
+                                         walker_offset=self.walker_offset)
         return x.reshape(*sample_shape, nup + ndown, 2)
 
     def sample_with_noise(self, orbitals_up, orbitals_down, g0, g, u, tau=0.1):

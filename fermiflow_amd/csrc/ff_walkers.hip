@@ -86,7 +86,7 @@ ff_mcmc_kernel(int64_t B, int nup_rt, int ndn_rt, const int* __restrict__ tab_up
 
   double x[MAXM], nx[MAXM];
   const uint64_t wid = (uint64_t)(woff + b);
-  if (NOISE) {
+  if (NOISE || g0 != nullptr) {   // explicit initial walkers (parity mode; ff_mcmc_continue)
 #pragma unroll
     for (int i = 0; i < MAXM; i++) if (i < M) x[i] = g0[b * M + i];
   } else {
@@ -205,7 +205,7 @@ ff_mcmc_spin_kernel(int64_t B, const int* __restrict__ tab_up, const int* __rest
       dst[i] = propose ? ff_add_rn(x[i], ff_mul_rn(tau, zv)) : zv;
     }
   };
-  if (NOISE) {
+  if (NOISE || g0 != nullptr) {   // explicit initial walkers (parity mode; ff_mcmc_continue)
 #pragma unroll
     for (int i = 0; i < MS; i++) x[i] = g0[b * M + off + i];
   } else {
@@ -579,6 +579,14 @@ int ff_mcmc_sample(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
                    const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
                    double* x_out, double* logp_out, int32_t* accept_count) {
   return mcmc_dispatch(false, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, nullptr, nullptr, nullptr, seed,
+                       walker_offset, x_out, logp_out, nullptr, accept_count);
+}
+
+int ff_mcmc_continue(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                     const double* x_init, double* x_out, double* logp_out, int32_t* accept_count) {
+  FF_CHECK(x_init != nullptr || B == 0, FF_EINVAL, "ff_mcmc_continue: null x_init");
+  return mcmc_dispatch(false, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, x_init, nullptr, nullptr, seed,
                        walker_offset, x_out, logp_out, nullptr, accept_count);
 }
 

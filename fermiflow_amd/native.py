@@ -70,6 +70,19 @@ def mcmc_sample(tab_up, tab_dn, nup, ndn, B, steps, tau, seed, device, walker_of
     return x, logp, cnt
 
 
+def mcmc_continue(tab_up, tab_dn, nup, ndn, x_init, steps, tau, seed, walker_offset=0, walker_state=None):
+    """ff_mcmc_continue: `steps` more Metropolis steps from the walkers x_init (B,n,2)."""
+    x0 = L.dev(x_init, name="x_init")
+    B = x0.shape[0]
+    x = torch.empty_like(x0)
+    logp = torch.empty(B, dtype=torch.float64, device=x0.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=x0.device)
+    L.check(L.lib().ff_mcmc_continue(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                     int(steps), L.f64(tau), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
+                                     L.ptr(x0), L.ptr(x), L.ptr(logp), L.ptr(cnt)), "ff_mcmc_continue")
+    return x, logp, cnt
+
+
 def mcmc_sample_noise(tab_up, tab_dn, nup, ndn, g0, g, u, tau=0.1, walker_state=None):
     g0, g, u = L.dev(g0, name="g0"), L.dev(g, name="g"), L.dev(u, name="u")
     B, steps = g0.shape[0], g.shape[0]

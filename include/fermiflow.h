@@ -91,6 +91,12 @@ int ff_mcmc_sample_noise(void* stream, int64_t B, int nup, int ndn, const int32_
 int ff_mcmc_sample(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
                    const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
                    double* x_out, double* logp_out, int32_t* accept_count);
+/* Persistent walkers (no upstream counterpart: the reference re-equilibrates from N(0,1) in every iteration,
+ * src/base_dist.py:62-64): the same chain, started from x_init (B,n,2) instead of fresh N(0,1) walkers; proposal noise
+ * and uniforms are the stream (seed, walker_offset) of ff_mcmc_sample from step 1 on.  x_out may alias x_init. */
+int ff_mcmc_continue(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                     const double* x_init, double* x_out, double* logp_out, int32_t* accept_count);
 /* The very noise ff_mcmc_sample consumes, materialised (for tests: feed it to ff_mcmc_sample_noise). */
 int ff_rng_fill(void* stream, int64_t B, int n, int steps, uint64_t seed, int64_t walker_offset,
                 double* g0, double* g, double* u);

@@ -119,6 +119,15 @@ def mcmc(B, nup, ndn, steps, seed, offset=0, tau=0.1):
     return x, lp, cnt
 
 
+def mcmc_continue(x_init, nup, ndn, steps, seed, offset=0, tau=0.1):
+    x0 = _d(x_init); B = x0.shape[0]
+    tu, td = _tabs(nup, ndn, None, None)
+    x = np.empty_like(x0); lp = np.empty(B); cnt = np.empty(B, dtype=np.int32)
+    _ck(lib().ff_mcmc_continue(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), None, steps, C.c_double(tau),
+                               C.c_uint64(seed), C.c_int64(offset), _p(x0), _p(x), _p(lp), _p(cnt)))
+    return x, lp, cnt
+
+
 def rng_fill(B, n, steps, seed, offset=0):
     g0 = np.empty((B, n, 2)); g = np.empty((steps, B, n, 2)); u = np.empty((steps, B))
     _ck(lib().ff_rng_fill(None, C.c_int64(B), n, steps, C.c_uint64(seed), C.c_int64(offset), _p(g0), _p(g), _p(u)))

@@ -502,3 +502,34 @@ def test_step_size_warm_start(dev):
         m(4096); m(4096)                      # second sweep: the flow pass is warm too
         Es.append((m.E, m.E_std))
     assert abs(Es[0][0] - Es[1][0]) < 1e-6 * abs(Es[1][0]) and abs(Es[0][1] - Es[1][1]) < 1e-5 * Es[1][1]
+
+
+def test_persistent_walkers_opt_in(dev):
+    """SURVEY 8(f).1, off by default: ff_mcmc_continue is the same chain as ff_mcmc_sample_noise fed the walkers and the
+    materialised Philox stream; a GSVMC that keeps its walkers and advances them 10 steps per sweep samples the same
+    distribution (energy agrees with fresh 100-step walkers within the statistical error)."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    tu, td = model._tables(dev)
+    B, steps = 4096, 25
+    torch.manual_seed(2)
+    x0 = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    _, g, u = native.rng_fill(B, 6, steps, 77, dev, walker_offset=5)
+    xr, lr, acc = native.mcmc_sample_noise(tu, td, 3, 3, x0, g, u, 0.1)
+    xc, lc, cnt = native.mcmc_continue(tu, td, 3, 3, x0, steps, 0.1, 77, walker_offset=5)
+    assert torch.equal(xc, xr) and torch.equal(lc, lr) and torch.equal(cnt.long(), acc.long().sum(0))
+    Es = {}
+    for flag in (False, True):
+        m = Gm._model(dev, 3, 3, 2.0)
+        m.persistent_walkers = flag
+        torch.manual_seed(4)
+        vals = []
+        for _ in range(6):
+            m(16384)
+            vals.append((m.E, m.E_std))
+        Es[flag] = vals
+    e_fresh = sum(v[0] for v in Es[False]) / 6
+    e_keep = sum(v[0] for v in Es[True][1:]) / 5
+    sigma = max(v[1] for v in Es[False]) / (16384 ** 0.5)
+    assert abs(e_keep - e_fresh) < 6 * sigma, (e_keep, e_fresh, sigma)

@@ -247,3 +247,19 @@ def test_step_size_warm_start_semantics(golden):
         np.testing.assert_allclose(gp1, gp0, rtol=1e-5, atol=1e-9 * np.abs(gp0).max())
     finally:
         S.warm()
+
+
+@pytest.mark.parametrize("nup,ndn", [(3, 3), (3, 0)])
+def test_mcmc_continue_is_the_same_chain_from_given_walkers(nup, ndn):
+    """ff_mcmc_continue (persistent walkers): from x_init, with the Philox stream of (seed, offset) from step 1 on --
+    i.e. exactly ff_mcmc_sample_noise fed x_init and the materialised stream; 0 steps return x_init and its log-prob."""
+    rng = np.random.default_rng(11)
+    n, B, steps = nup + ndn, 9, 7
+    x0 = rng.normal(size=(B, n, 2))
+    _, g, u = S.rng_fill(B, n, steps, seed=42, offset=3)
+    xr, lr, acc = S.mcmc_noise(x0, g, u, nup, ndn)
+    xc, lc, cnt = S.mcmc_continue(x0, nup, ndn, steps, seed=42, offset=3)
+    assert np.array_equal(xc, xr) and np.array_equal(lc, lr) and np.array_equal(cnt, acc.sum(0))
+    xz, lz, _ = S.mcmc_continue(x0, nup, ndn, 0, seed=1)
+    assert np.array_equal(xz, x0)
+    np.testing.assert_allclose(lz, S.logprob(x0, nup, ndn)[0], rtol=1e-13)
