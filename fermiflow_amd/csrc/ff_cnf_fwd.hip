@@ -1086,6 +1086,36 @@ ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_u
   Q[(int64_t)(M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp) * B + b] = 2.0 * lp0;
 }
 
+// the same for equal (or single) determinant sizes known at compile time: everything in registers (ff_slater_fixed)
+template <int NS>
+__global__ void __launch_bounds__(128)
+ff_eloc_slater_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                            const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1);
+  if (b >= B) return;
+  const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
+  const int lpq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp;
+  const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+  if (!ns) { Q[(int64_t)lpq * B + b] = 0.0; return; }      // ns is NS here
+  double zl[2 * NS], T[2 * NS * NS], S[3 * NS];
+#pragma unroll
+  for (int k = 0; k < 2 * NS; k++) zl[k] = z0[b * M + 2 * off + k];
+  const double lp0 = ff_slater_fixed<NS>((sp ? tab_dn : tab_up) + st * NS, zl, T, S);
+#pragma unroll
+  for (int a = 0; a < NS; a++) {
+    Q[(int64_t)(2 * (off + a)) * B + b] = 2.0 * T[a * NS + a];
+    Q[(int64_t)(2 * (off + a) + 1) * B + b] = 2.0 * T[NS * NS + a * NS + a];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Q[(int64_t)(M + 3 * (off + a) + k) * B + b] = S[3 * a + k];
+  }
+  const int tq = M + 3 * n + (sp ? 2 * nup * nup : 0);
+#pragma unroll
+  for (int k = 0; k < 2 * NS * NS; k++) Q[(int64_t)(tq + k) * B + b] = T[k];
+  Q[(int64_t)lpq * B + b] = 2.0 * lp0;
+}
+
 // dynamic LDS: [G*M*M J^T block | G*nq Slater slots | 64 x | 3*64 partial sums]  (10 KB at n = 6: many waves per CU)
 static size_t ff_contract_lds_bytes(int nup, int ndn) {
   const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M, nq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;
@@ -1333,8 +1363,17 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
   const size_t M = (size_t)n * 2;
   ff_eloc_ws w = eloc_carve((void*)workspace, B, M);
   FF_CHECK(2 * n <= FF_WAVE, FF_EUNSUPPORTED, "ff_eloc_finish: n*d > 64");
-  FF_LAUNCH(ff_eloc_slater_kernel, (unsigned)((2 * B + 127) / 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state,
-            (const double*)w.z0, w.Q);
+  {
+    const int nsf = (nup == ndn || ndn == 0) ? nup : (nup == 0 ? ndn : 0);   // one determinant size for both spin species
+    const unsigned sgrid = (unsigned)((2 * B + 127) / 128);
+#define FF_SF(NS_) case NS_: FF_LAUNCH((ff_eloc_slater_fixed_kernel<NS_>), sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q); break;
+    switch (nsf) {
+      FF_SF(1) FF_SF(2) FF_SF(3) FF_SF(4)
+      default:
+        FF_LAUNCH(ff_eloc_slater_kernel, sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q);
+    }
+#undef FF_SF
+  }
   FF_LAUNCH_CHECK();
   {
     const int Gf = FF_WAVE / (2 * n);

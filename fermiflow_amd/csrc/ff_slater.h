@@ -211,3 +211,80 @@ FF_D double ff_slater_general(int ns, const int* __restrict__ orb, const double*
   }
   return acc;
 }
+
+// The same routine for a compile-time determinant size: every loop unrolls, the row exchange of the pivoting is a chain
+// of selects, and A, Inv, T live in registers instead of private (scratch) memory.  Same operations in the same order as
+// ff_slater_general with T and S requested: bit-identical results.
+template <int NS>
+FF_D double ff_slater_fixed(const int* __restrict__ orb, const double* x, double* T /* [2*NS*NS] */, double* S /* [3*NS] */) {
+  double A[NS * NS], Inv[NS * NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    const double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      double v;
+      ff_orbital<false>(orb[j], x[2 * i], x[2 * i + 1], gs, v, nullptr, nullptr);
+      A[i * NS + j] = v;
+      Inv[i * NS + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < NS; c++) {
+    int p = c;
+    double best = fabs(A[c * NS + c]);
+#pragma unroll
+    for (int r = c + 1; r < NS; r++) {
+      const double a = fabs(A[r * NS + c]);
+      if (a > best) { best = a; p = r; }
+    }
+#pragma unroll
+    for (int r = c + 1; r < NS; r++) {
+      const bool sw = (r == p);
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const double ac = A[c * NS + j], ar = A[r * NS + j], ic = Inv[c * NS + j], ir = Inv[r * NS + j];
+        A[c * NS + j] = sw ? ar : ac; A[r * NS + j] = sw ? ac : ar;
+        Inv[c * NS + j] = sw ? ir : ic; Inv[r * NS + j] = sw ? ic : ir;
+      }
+    }
+    const double piv = A[c * NS + c];
+    acc += log(fabs(piv));
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int j = 0; j < NS; j++) { A[c * NS + j] *= ip; Inv[c * NS + j] *= ip; }
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+      if (r == c) continue;
+      const double f = A[r * NS + c];
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        A[r * NS + j] = fma(-f, A[c * NS + j], A[r * NS + j]);
+        Inv[r * NS + j] = fma(-f, Inv[c * NS + j], Inv[r * NS + j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NS; a++) {
+    const double gs = ff_gauss2d(x[2 * a], x[2 * a + 1]);
+#pragma unroll
+    for (int b = 0; b < NS; b++) { T[a * NS + b] = 0.0; T[NS * NS + a * NS + b] = 0.0; }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      double v, g[2], hs[3];
+      ff_orbital<true>(orb[j], x[2 * a], x[2 * a + 1], gs, v, g, hs);
+#pragma unroll
+      for (int b = 0; b < NS; b++) {
+        const double di = Inv[j * NS + b];
+        T[a * NS + b] = fma(g[0], di, T[a * NS + b]);
+        T[NS * NS + a * NS + b] = fma(g[1], di, T[NS * NS + a * NS + b]);
+      }
+      const double da = Inv[j * NS + a];
+      s0 = fma(hs[0], da, s0); s1 = fma(hs[1], da, s1); s2 = fma(hs[2], da, s2);
+    }
+    S[3 * a] = s0; S[3 * a + 1] = s1; S[3 * a + 2] = s2;
+  }
+  return acc;
+}
