@@ -23,13 +23,21 @@ class _ScalarWithParamGrads(torch.autograd.Function):
     """value (0-dim) that back-propagates pre-computed gradients into the given parameters."""
 
     @staticmethod
-    def forward(ctx, value, grads, *params):
-        ctx.grads = grads
+    def forward(ctx, value, flat_grads, *params):
+        ctx.flat, ctx.shapes = flat_grads, [p.shape for p in params]
         return value.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return (None, None) + tuple(g * gk for gk in ctx.grads)
+        scaled = g * ctx.flat        # one launch for all parameters; the per-parameter gradients are views of it
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(scaled[off:off + n].reshape(shp))
+            off += n
+        return (None, None) + tuple(out)
 
 
 def _flow_params(cnf):
@@ -75,7 +83,8 @@ class GSVMC(torch.nn.Module):
 
     @property
     def E_std(self):
-        return self._E_std_dev.item()
+        n = self._E_n
+        return (self._E_ss / (n - 1)).sqrt().item() if n > 1 else float("nan")
 
     # -- pieces with the reference's names ---------------------------------------------------------
     def sample(self, sample_shape):
@@ -160,8 +169,9 @@ class GSVMC(torch.nn.Module):
             # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the
             # sweep, so kernel launches keep running ahead of the GPU
             s0 = native.reduce_moments(Eloc, 0.0)
-            self._E_dev, self._E_std_dev = D.global_mean_std_dev(
+            self._E_dev, self._E_ss = D.global_mean_ss_dev(
                 s0[0], batch, lambda tot, scale: native.reduce_moments(Eloc, shift_dev=tot, shift_dev_scale=scale)[1])
+            self._E_n = batch
             w = (Eloc - self._E_dev) / batch
             v, params = _flow_params(self.cnf)
             mark("estimator")
@@ -176,8 +186,7 @@ class GSVMC(torch.nn.Module):
             prof.setdefault("pass1", []).append(p1)
             prof.setdefault("eloc_stats", []).append(r["stats"])
         self.Eloc, self.x = Eloc, x
-        grads = _split_like(buf[1:], params)
-        return _ScalarWithParamGrads.apply(buf[0], grads, *params)
+        return _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
 
 
 class BetaVMC(torch.nn.Module):
@@ -275,6 +284,6 @@ class BetaVMC(torch.nn.Module):
             buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
             D.all_reduce_sum_(buf)
         self.Eloc, self.x = Eloc, x
-        gradF_phi = _ScalarWithParamGrads.apply(stat[3, 0].to(self.log_state_weights.device), [g_phi], self.log_state_weights)
-        gradF_theta = _ScalarWithParamGrads.apply(buf[0], _split_like(buf[1:], params), *params)
+        gradF_phi = _ScalarWithParamGrads.apply(stat[3, 0].to(self.log_state_weights.device), g_phi.reshape(-1), self.log_state_weights)
+        gradF_theta = _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
         return gradF_phi, gradF_theta

@@ -38,6 +38,16 @@ def shard(batch, rank=None, world_size=None):
     return offset, count
 
 
+def global_mean_ss_dev(sum_e, n_global, centered_sumsq_fn):
+    """As global_mean_std_dev, but returns (mean, centred sum of squares) -- the caller forms the std when it is read."""
+    buf = sum_e.reshape(1).clone()
+    all_reduce_sum_(buf)
+    mean = buf[0] / n_global
+    ss = centered_sumsq_fn(buf, 1.0 / n_global).reshape(1)
+    all_reduce_sum_(ss)
+    return mean, ss[0]
+
+
 def global_mean_std_dev(sum_e, n_global, centered_sumsq_fn):
     """Mean and unbiased std over all ranks as 0-dim DEVICE tensors, without a host synchronisation.
     sum_e: 0-dim tensor, the local sum; n_global: the global number of samples (known on the host: the shards are a
