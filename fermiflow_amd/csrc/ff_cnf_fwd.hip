@@ -9,12 +9,17 @@
 //
 // Per RHS evaluation (all lanes of the wave):
 //   1. every lane publishes its stage value z_i (and kbar_i) to LDS;
-//   2. "radius phase": the wave's G*R radii (pairs r_ab, one-body r_a) are dealt one per lane; a lane
-//      evaluates the H sigmoids of eta (or mu) at its radius and leaves the NH derivative heads in LDS;
-//   3. "jet phase" (MODE 2): lane (g,i) pushes its direction u_i = dz/dx_i through every pair term as a
-//      2nd-order Taylor jet (first-order part -> dJ/dt column, quadratic part -> source of kbar and lap Delta);
-//   4. "component phase": lane (g,i) assembles v_i, (Dv[kbar])_i, (grad div)_i from the heads of the pairs
-//      its particle takes part in.
+//   2. "radius phase": the wave's G*R radii (pairs r_ab, one-body r_a) are dealt one per lane (the assignment is fixed for
+//      the launch); a lane gets the derivative heads of eta (or mu) at its radius -- from the per-launch table (TAB
+//      instantiations) or by evaluating the H sigmoids (direct instantiations) -- and leaves in LDS what does not depend
+//      on the direction: MODE 0/1 the heads, MODE 2 a record per radius plus the radius' contributions to its particles'
+//      own rows (v, Dv[kbar], grad div);
+//   3. MODE 2 "jet sweep": lane (g,i) gathers its own row, then pushes its direction u_i = dz/dx_i through every radius
+//      term as a 2nd-order Taylor jet (first-order part -> dJ/dt column, quadratic part -> source of kbar and lap Delta);
+//      MODE 0/1 "component phase": lane (g,i) assembles v_i (and div v) from the heads of its particle's radii;
+//   4. Dormand-Prince stage bookkeeping; per-walker error norm and step-size control (ff_ode.h).
+// n >= 8 uses ff_eloc_split_kernel (two lanes per direction) for MODE 2.  The local-energy finish (Slater table +
+// contraction with the sensitivities) is at the end of the file.
 #include <atomic>
 #include "ff_common.h"
 #include "ff_ode.h"
