@@ -63,6 +63,9 @@ struct ff_fwd_args {
   // same id returns at once unless it finds its id there.  ids are unique per process, so slots need no reset.
   double* evt;
   double evt_id;
+  // Work queue (optional): with `queue` set the launch is a persistent grid and every workgroup takes its next walker
+  // group from this counter (slot 0: table kernel, slot 1: direct kernel), zeroed by the host before the launch.
+  unsigned long long* queue;
 };
 
 #ifndef FF_SWEEP_CH
@@ -173,7 +176,15 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const unsigned long long stamp_t0 = stamp_prev, stamp_r0 = __builtin_readcyclecounter() * 0 + wall_clock64();
 #endif
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  __shared__ long long s_next;
+  for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+      __syncthreads();
+      if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
+      __syncthreads();
+      grp = s_next;
+    }
+    if (grp >= ngroups) break;
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
     const int64_t b = (valid && A.order) ? A.order[bq] : bq;   // the walker this lane group integrates
@@ -707,7 +718,15 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   long long ev_sum = 0;
   int acc_max = 0, rej_sum = 0, fail_any = 0;
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  __shared__ long long s_next;
+  for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+      __syncthreads();
+      if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
+      __syncthreads();
+      grp = s_next;
+    }
+    if (grp >= ngroups) break;
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
     const int64_t b = (valid && A.order) ? A.order[bq] : bq;
@@ -1218,11 +1237,24 @@ static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERS
 
 // With a radial table: the table kernel, then the direct-evaluation kernel as its (normally idle) fallback -- it returns
 // in its first instructions unless the table kernel left this launch's id in the event slot.  Without: direct only.
+// persistent grid of the queue mode: one wave per SIMD (FF_QUEUE_BLOCKS overrides, tuning)
+static int64_t fwd_queue_blocks() {
+  static int64_t n = 0;
+  if (n == 0) {
+    const char* e = getenv("FF_QUEUE_BLOCKS");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = e ? atoll(e) : 4 * (int64_t)cus;
+  }
+  return n;
+}
+
 template <int N, int D, int MODE>
 static void launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
-  const int64_t cap = ff_persist_blocks(1 << 20);   // measured: one workgroup per walker group balances best
+  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);   // without a queue: one workgroup per walker group
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   if (a.evt) FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, stream, a);
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
@@ -1234,7 +1266,7 @@ template <int N, int D>
 static void launch_split(void* stream, const ff_fwd_args& a) {
   constexpr int G = FF_WAVE / (2 * N * D);
   int64_t ngroups = (a.B + G - 1) / G;
-  const int64_t cap = ff_persist_blocks(1 << 20);
+  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   if (a.evt) FF_LAUNCH((ff_eloc_split_kernel<N, D, true>), grid, FF_WAVE, stream, a);
   FF_LAUNCH((ff_eloc_split_kernel<N, D, false>), grid, FF_WAVE, stream, a);
@@ -1321,10 +1353,10 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
 // sensitivities (z0, Jt, kbar, dD, Lpart, Delta) + the Slater table of the finish (g0, S, T <= 2 n^2, logp0)
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
   size_t M = (size_t)n * d;
-  return sizeof(double) * (size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 2);
+  return sizeof(double) * ((size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 2) + 2);   // + the work counters
 }
 
-struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl, *Q; };
+struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl, *Q; unsigned long long* queue; };
 static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
   double* w = (double*)workspace;
   ff_eloc_ws o;
@@ -1335,6 +1367,7 @@ static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
   o.Lp = w;   w += (size_t)B * M;
   o.dl = w;   w += (size_t)B;
   o.Q = w;
+  o.queue = (unsigned long long*)((double*)workspace + (size_t)B * (M * M + 4 * M + 1 + M + 3 * (M / 2) + 2 * (M / 2) * (M / 2) + 2));
   return o;
 }
 
@@ -1352,6 +1385,11 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
+  static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
+  if (use_queue) {
+    if (hipMemsetAsync(w.queue, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+    a.queue = w.queue;
+  }
   return dispatch_fwd<2>(stream, n, d, a);
 }
 
