@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--nup", type=int, default=3)
     ap.add_argument("--ndown", type=int, default=3)
     ap.add_argument("--Z", type=float, default=2.0)
-    ap.add_argument("--lr", type=float, default=1e-4,
+    ap.add_argument("--lr", type=float, default=2e-5,
                     help="Adam step; small so the synthetic weights (hence the ODE step counts) stay put over the run")
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel and CPU-baseline legs")
