@@ -19,6 +19,7 @@
  */
 #ifndef FERMIFLOW_H
 #define FERMIFLOW_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {

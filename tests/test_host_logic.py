@@ -21,6 +21,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.ff_version() >= 100
 
 
+def test_header_is_plain_c_and_matches_the_ctypes_structs():
+    """include/fermiflow.h compiles as C99 on its own (the boundary is a C ABI), and the ctypes mirrors of ff_net /
+    ff_ode have the sizes the C compiler gives the structs."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from fermiflow_amd import _lib
+    src = '#include "fermiflow.h"\n#include <stdio.h>\nint main(void) { printf("%zu %zu\\n", sizeof(ff_net), sizeof(ff_ode)); return 0; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        net_sz, ode_sz = (int(v) for v in subprocess.check_output([exe]).split())
+    assert net_sz == C.sizeof(_lib.FFNet) and ode_sz == C.sizeof(_lib.FFOde)
+
+
 def test_abi_argument_errors_without_gpu():
     """invalid arguments are rejected before any launch (status 1 / 2), so this runs on CPU."""
     import ctypes as C
