@@ -45,7 +45,7 @@ typedef struct ff_ode {
    *   min(31, steps attempted in this call + max(0, -log2(r_min^2) - 1)),  r_min = the smallest pair or one-body radius
    *   any stage of the call saw (the backflow field is only C^1 where a radius vanishes, so its second-order
    *   sensitivities -- the local-energy pass -- need many small steps near such points even when this call did not;
-   *   ff_cnf_adjoint reports the attempted steps only).
+   *   ff_cnf_adjoint and the n >= 8 local-energy kernel report the attempted steps only).
    * walker_order (in, B): a permutation of 0..B-1 (ff_walker_order); workgroups take walkers in this order.
    * Results are written to each walker's own slot, so the order changes timing only. */
   int32_t* walker_cost;
