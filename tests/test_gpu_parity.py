@@ -533,3 +533,26 @@ def test_persistent_walkers_opt_in(dev):
     e_keep = sum(v[0] for v in Es[True][1:]) / 5
     sigma = max(v[1] for v in Es[False]) / (16384 ** 0.5)
     assert abs(e_keep - e_fresh) < 6 * sigma, (e_keep, e_fresh, sigma)
+
+
+def test_adjoint_is_linear_in_its_seeds_full_size(dev):
+    """Size-independent property of the theta-gradient adjoint at the benchmark's walker count: the result is linear
+    in the incoming gradients (a_z, a_Delta) up to the solver tolerance, and invariant under a permutation of the
+    walkers (a sum over walkers) to rounding."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    B = 65536
+    torch.manual_seed(13)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    g = torch.Generator(device="cpu").manual_seed(1)
+    a1, a2 = (torch.randn(B, 6, 2, generator=g, dtype=torch.float64).to(dev) / B for _ in range(2))
+    d1, d2 = (torch.randn(B, generator=g, dtype=torch.float64).to(dev) / B for _ in range(2))
+    run = lambda zz, az, ad: native.cnf_adjoint(net, zz, az, ad, 0.0, 1.0, 1e-9, 1e-11, need_gx=False)[1]
+    g1, g2, g12 = run(z, a1, d1), run(z, a2, d2), run(z, a1 + 2.0 * a2, d1 + 2.0 * d2)
+    scale = (g1.abs() + 2.0 * g2.abs()).max().item()
+    assert (g12 - (g1 + 2.0 * g2)).abs().max().item() < 1e-7 * scale
+    perm = torch.randperm(B, generator=g).to(dev)
+    gp = run(z[perm].contiguous(), a1[perm].contiguous(), d1[perm].contiguous())
+    assert (gp - g1).abs().max().item() < 1e-11 * g1.abs().max().item()
