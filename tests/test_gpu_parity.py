@@ -556,3 +556,26 @@ def test_adjoint_is_linear_in_its_seeds_full_size(dev):
     perm = torch.randperm(B, generator=g).to(dev)
     gp = run(z[perm].contiguous(), a1[perm].contiguous(), d1[perm].contiguous())
     assert (gp - g1).abs().max().item() < 1e-11 * g1.abs().max().item()
+
+
+def test_local_energy_is_invariant_under_same_spin_exchange(dev):
+    """Domain property at full size: |psi|^2 of the flow-transformed Slater state is symmetric under the exchange of two
+    same-spin particles (the backflow field is permutation equivariant, the determinant changes sign only), so logp and
+    E_loc are unchanged -- through the flow solve, its sensitivities and the Slater contraction."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    B = 32768
+    torch.manual_seed(17)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8)
+    xs = x.clone()
+    xs[:, [0, 2]] = x[:, [2, 0]]          # two spin-up particles
+    xs[:, [3, 4]] = x[:, [4, 3]]          # two spin-down particles
+    r = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-9, 1e-11, 2.0, True)
+    rs = native.eloc(tu, td, 3, 3, net, xs, 0.0, 1.0, 1e-9, 1e-11, 2.0, True)
+    assert ((r["logp"] - rs["logp"]).abs() / r["logp"].abs()).max().item() < 1e-7
+    assert ((r["eloc"] - rs["eloc"]).abs() / r["eloc"].abs()).max().item() < 1e-6
+    assert (r["grad"][:, [2, 1, 0, 4, 3, 5]] - rs["grad"]).abs().max().item() < 1e-5 * r["grad"].abs().max().item()
