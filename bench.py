@@ -167,6 +167,32 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         nbytes = Bm * S * (8 * M + 8 + 1) + Bm * (2 * 8 * M + 8)     # noise + uniforms + accept mask; init + final x, logp
         del g0, g, u
+        # ---- the stand-alone pairwise kernels (potentials.py / equivariant_funs.py entry points; inside the sweep these
+        #      terms are fused into the ODE kernels): Coulomb + trap energy is HBM-bound, backflow v + div is fp64-bound
+        Bp = 16 * args.walkers_per_gpu
+        xp = torch.randn(Bp, n, 2, dtype=torch.float64, device=dev)
+
+        def timed(fn, reps=5):
+            fn(); e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        ms_p = timed(lambda: native.potential(xp, args.Z, True))
+        netp = model.cnf.v_wrapper.v.net(radial="exact")
+        xb = xp[: args.walkers_per_gpu]
+        ms_b = timed(lambda: native.backflow_v_div(netp, xb))
+        bytes_p = Bp * (8 * M + 8)
+        flop_b = args.walkers_per_gpu * R * (H * FLOP_PER_SIGMOID_UNIT + 20)
+        out["roofline_pairwise"] = {
+            "potential": {"kernel": "ff_potential_stream_kernel (HO + Coulomb pairs)", "bound": "hbm", "walkers": Bp, "avg_launch_ms": ms_p,
+                          "achieved": bytes_p / (ms_p * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": bytes_p / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "backflow": {"kernel": "ff_backflow_kernel (v and div v, direct sigmoids)", "bound": "mfma", "walkers": args.walkers_per_gpu,
+                         "avg_launch_ms": ms_b, "achieved": flop_b / (ms_b * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop_b / (ms_b * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                         "note": "fp64 VALU (exp/rcp chains); no MFMA: 1->H->1 layers"}}
+        del xp
         out["roofline_hbm"] = {"kernel": (f"ff_mcmc_spin_kernel<{args.nup},noise>" if args.nup == args.ndown and 1 <= args.nup <= 6 else f"ff_mcmc_kernel<{args.nup},{args.ndown},noise>"), "bound": "hbm",
                                "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,

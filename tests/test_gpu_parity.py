@@ -579,3 +579,17 @@ def test_local_energy_is_invariant_under_same_spin_exchange(dev):
     assert ((r["logp"] - rs["logp"]).abs() / r["logp"].abs()).max().item() < 1e-7
     assert ((r["eloc"] - rs["eloc"]).abs() / r["eloc"].abs()).max().item() < 1e-6
     assert (r["grad"][:, [2, 1, 0, 4, 3, 5]] - rs["grad"]).abs().max().item() < 1e-5 * r["grad"].abs().max().item()
+
+
+@pytest.mark.parametrize("n,d,B", [(6, 2, 1000), (12, 2, 129), (6, 3, 64), (7, 2, 333)])
+def test_potential_kernels_against_the_formula(dev, n, d, B):
+    """ff_potential (HO.V + CoulombPairPotential.V, src/potentials.py:13,23-47): the HBM-streaming instantiations and the
+    generic kernel (n = 7 has no instantiation) against the plain formula, ragged batch sizes."""
+    from fermiflow_amd import native
+    g = torch.Generator().manual_seed(n * 100 + d)
+    x = torch.randn(B, n, d, generator=g, dtype=torch.float64).to(dev)
+    rij = (x[:, :, None] - x[:, None]).norm(dim=-1)
+    iu = torch.triu_indices(n, n, 1, device=dev)
+    ref = 1.7 / rij[:, iu[0], iu[1]]
+    np.testing.assert_allclose(N(native.potential(x, 1.7, True)), N(ref.sum(1) + 0.5 * (x ** 2).sum((1, 2))), rtol=1e-13)
+    np.testing.assert_allclose(N(native.potential(x, 1.7, False)), N(ref.sum(1)), rtol=1e-13)
