@@ -215,9 +215,9 @@ FF_D double ff_slater_general(int ns, const int* __restrict__ orb, const double*
 // The same routine for a compile-time determinant size: every loop unrolls, the row exchange of the pivoting is a chain
 // of selects, and A, Inv, T live in registers instead of private (scratch) memory.  Same operations in the same order as
 // ff_slater_general with T and S requested: bit-identical results.
-template <int NS>
+template <int NS, bool DERIV = true>
 FF_D double ff_slater_fixed(const int* __restrict__ orb, const double* x, double* T /* [2*NS*NS] */, double* S /* [3*NS] */) {
-  double A[NS * NS], Inv[NS * NS];
+  double A[NS * NS], Inv[DERIV ? NS * NS : 1];
 #pragma unroll
   for (int i = 0; i < NS; i++) {
     const double gs = ff_gauss2d(x[2 * i], x[2 * i + 1]);
@@ -226,7 +226,7 @@ FF_D double ff_slater_fixed(const int* __restrict__ orb, const double* x, double
       double v;
       ff_orbital<false>(orb[j], x[2 * i], x[2 * i + 1], gs, v, nullptr, nullptr);
       A[i * NS + j] = v;
-      Inv[i * NS + j] = (i == j) ? 1.0 : 0.0;
+      if constexpr (DERIV) Inv[i * NS + j] = (i == j) ? 1.0 : 0.0;
     }
   }
   double acc = 0.0;
@@ -244,47 +244,61 @@ FF_D double ff_slater_fixed(const int* __restrict__ orb, const double* x, double
       const bool sw = (r == p);
 #pragma unroll
       for (int j = 0; j < NS; j++) {
-        const double ac = A[c * NS + j], ar = A[r * NS + j], ic = Inv[c * NS + j], ir = Inv[r * NS + j];
+        const double ac = A[c * NS + j], ar = A[r * NS + j];
         A[c * NS + j] = sw ? ar : ac; A[r * NS + j] = sw ? ac : ar;
-        Inv[c * NS + j] = sw ? ir : ic; Inv[r * NS + j] = sw ? ic : ir;
+        if constexpr (DERIV) {
+          const double ic = Inv[c * NS + j], ir = Inv[r * NS + j];
+          Inv[c * NS + j] = sw ? ir : ic; Inv[r * NS + j] = sw ? ic : ir;
+        }
       }
     }
     const double piv = A[c * NS + c];
     acc += log(fabs(piv));
     const double ip = 1.0 / piv;
+    if constexpr (!DERIV) {   // value only: plain elimination below the pivot (as ff_slater_general without T)
 #pragma unroll
-    for (int j = 0; j < NS; j++) { A[c * NS + j] *= ip; Inv[c * NS + j] *= ip; }
+      for (int r = c + 1; r < NS; r++) {
+        const double f = A[r * NS + c] * ip;
 #pragma unroll
-    for (int r = 0; r < NS; r++) {
-      if (r == c) continue;
-      const double f = A[r * NS + c];
+        for (int j = c + 1; j < NS; j++) A[r * NS + j] = fma(-f, A[c * NS + j], A[r * NS + j]);
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < NS; j++) {
-        A[r * NS + j] = fma(-f, A[c * NS + j], A[r * NS + j]);
-        Inv[r * NS + j] = fma(-f, Inv[c * NS + j], Inv[r * NS + j]);
+      for (int j = 0; j < NS; j++) { A[c * NS + j] *= ip; Inv[c * NS + j] *= ip; }
+#pragma unroll
+      for (int r = 0; r < NS; r++) {
+        if (r == c) continue;
+        const double f = A[r * NS + c];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+          A[r * NS + j] = fma(-f, A[c * NS + j], A[r * NS + j]);
+          Inv[r * NS + j] = fma(-f, Inv[c * NS + j], Inv[r * NS + j]);
+        }
       }
     }
   }
+  if constexpr (DERIV) {
 #pragma unroll
-  for (int a = 0; a < NS; a++) {
-    const double gs = ff_gauss2d(x[2 * a], x[2 * a + 1]);
+    for (int a = 0; a < NS; a++) {
+      const double gs = ff_gauss2d(x[2 * a], x[2 * a + 1]);
 #pragma unroll
-    for (int b = 0; b < NS; b++) { T[a * NS + b] = 0.0; T[NS * NS + a * NS + b] = 0.0; }
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int b = 0; b < NS; b++) { T[a * NS + b] = 0.0; T[NS * NS + a * NS + b] = 0.0; }
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < NS; j++) {
-      double v, g[2], hs[3];
-      ff_orbital<true>(orb[j], x[2 * a], x[2 * a + 1], gs, v, g, hs);
+      for (int j = 0; j < NS; j++) {
+        double v, g[2], hs[3];
+        ff_orbital<true>(orb[j], x[2 * a], x[2 * a + 1], gs, v, g, hs);
 #pragma unroll
-      for (int b = 0; b < NS; b++) {
-        const double di = Inv[j * NS + b];
-        T[a * NS + b] = fma(g[0], di, T[a * NS + b]);
-        T[NS * NS + a * NS + b] = fma(g[1], di, T[NS * NS + a * NS + b]);
+        for (int b = 0; b < NS; b++) {
+          const double di = Inv[j * NS + b];
+          T[a * NS + b] = fma(g[0], di, T[a * NS + b]);
+          T[NS * NS + a * NS + b] = fma(g[1], di, T[NS * NS + a * NS + b]);
+        }
+        const double da = Inv[j * NS + a];
+        s0 = fma(hs[0], da, s0); s1 = fma(hs[1], da, s1); s2 = fma(hs[2], da, s2);
       }
-      const double da = Inv[j * NS + a];
-      s0 = fma(hs[0], da, s0); s1 = fma(hs[1], da, s1); s2 = fma(hs[2], da, s2);
+      if (S) { S[3 * a] = s0; S[3 * a + 1] = s1; S[3 * a + 2] = s2; }
     }
-    S[3 * a] = s0; S[3 * a + 1] = s1; S[3 * a + 2] = s2;
   }
   return acc;
 }

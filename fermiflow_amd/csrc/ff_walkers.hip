@@ -337,6 +337,68 @@ ff_logprob_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, c
   if (lap) lap[b] = 2.0 * lpl;
 }
 
+// Register-resident instantiations of the three kernels above for one compile-time determinant size NS (both spin
+// species the same size, or one species): same arithmetic as the generic routine (ff_slater_fixed), no private arrays.
+template <int NS>
+__global__ void __launch_bounds__(128)
+ff_slater_fwd_fixed_kernel(int64_t B, const int* __restrict__ tab, const int* __restrict__ wstate,
+                           const double* __restrict__ x, double* __restrict__ lad) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xl[2 * NS];
+#pragma unroll
+  for (int i = 0; i < 2 * NS; i++) xl[i] = x[b * 2 * NS + i];
+  lad[b] = ff_slater_fixed<NS, false>(tab + (wstate ? wstate[b] : 0) * NS, xl, nullptr, nullptr);
+}
+
+template <int NS>
+__global__ void __launch_bounds__(128)
+ff_slater_bwd_fixed_kernel(int64_t B, const int* __restrict__ tab, const int* __restrict__ wstate,
+                           const double* __restrict__ x, const double* __restrict__ gout, double* __restrict__ gx) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xl[2 * NS], T[2 * NS * NS];
+#pragma unroll
+  for (int i = 0; i < 2 * NS; i++) xl[i] = x[b * 2 * NS + i];
+  ff_slater_fixed<NS, true>(tab + (wstate ? wstate[b] : 0) * NS, xl, T, nullptr);
+  const double go = gout[b];
+#pragma unroll
+  for (int a = 0; a < NS; a++) {
+    gx[b * 2 * NS + 2 * a] = go * T[a * NS + a];
+    gx[b * 2 * NS + 2 * a + 1] = go * T[NS * NS + a * NS + a];
+  }
+}
+
+template <int NS, bool DERIV>
+__global__ void __launch_bounds__(128)
+ff_logprob_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                        const int* __restrict__ wstate, const double* __restrict__ x, double* __restrict__ logp,
+                        double* __restrict__ grad, double* __restrict__ lap) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = nup + ndn, st = wstate ? wstate[b] : 0;
+  double lp = 0.0, lpl = 0.0;
+#pragma unroll 1
+  for (int sp = 0; sp < 2; sp++) {
+    const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+    if (!ns) continue;                       // ns == NS otherwise
+    double xl[2 * NS], T[DERIV ? 2 * NS * NS : 1], S[DERIV ? 3 * NS : 1];
+#pragma unroll
+    for (int i = 0; i < 2 * NS; i++) xl[i] = x[b * 2 * n + 2 * off + i];
+    lp += ff_slater_fixed<NS, DERIV>((sp ? tab_dn : tab_up) + st * NS, xl, T, S);
+    if constexpr (DERIV) {
+#pragma unroll
+      for (int a = 0; a < NS; a++) {
+        const double gxa = T[a * NS + a], gya = T[NS * NS + a * NS + a];
+        if (grad) { grad[b * 2 * n + 2 * (off + a)] = 2.0 * gxa; grad[b * 2 * n + 2 * (off + a) + 1] = 2.0 * gya; }
+        lpl += S[3 * a] + S[3 * a + 2] - gxa * gxa - gya * gya;
+      }
+    }
+  }
+  logp[b] = 2.0 * lp;
+  if (lap) lap[b] = 2.0 * lpl;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // HO.V + CoulombPairPotential.V (src/potentials.py:13,23-47)
 __global__ void __launch_bounds__(128)
@@ -660,6 +722,9 @@ int ff_slater_logabsdet_fwd(void* stream, int64_t B, int n, const int32_t* orb_t
   FF_CHECK(B >= 0 && n > 0 && orb_table && x && logabsdet, FF_EINVAL, "ff_slater_logabsdet_fwd: bad argument");
   FF_CHECK(n <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_slater_logabsdet_fwd: n > FF_MAX_NS");
   if (B == 0) return FF_OK;
+#define FF_SFW(NS_) case NS_: FF_LAUNCH((ff_slater_fwd_fixed_kernel<NS_>), ff_grid(B, 128), 128, stream, B, orb_table, walker_state, x, logabsdet); FF_LAUNCH_CHECK(); return FF_OK;
+  switch (n) { FF_SFW(1) FF_SFW(2) FF_SFW(3) FF_SFW(4) FF_SFW(5) FF_SFW(6) default: break; }
+#undef FF_SFW
   FF_LAUNCH(ff_slater_fwd_kernel, ff_grid(B, 128), 128, stream, B, n, orb_table, walker_state, x, logabsdet);
   FF_LAUNCH_CHECK();
   return FF_OK;
@@ -670,6 +735,9 @@ int ff_slater_logabsdet_bwd(void* stream, int64_t B, int n, const int32_t* orb_t
   FF_CHECK(B >= 0 && n > 0 && orb_table && x && grad_out && grad_x, FF_EINVAL, "ff_slater_logabsdet_bwd: bad argument");
   FF_CHECK(n <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_slater_logabsdet_bwd: n > FF_MAX_NS");
   if (B == 0) return FF_OK;
+#define FF_SBW(NS_) case NS_: FF_LAUNCH((ff_slater_bwd_fixed_kernel<NS_>), ff_grid(B, 128), 128, stream, B, orb_table, walker_state, x, grad_out, grad_x); FF_LAUNCH_CHECK(); return FF_OK;
+  switch (n) { FF_SBW(1) FF_SBW(2) FF_SBW(3) FF_SBW(4) default: break; }
+#undef FF_SBW
   FF_LAUNCH(ff_slater_bwd_kernel, ff_grid(B, 128), 128, stream, B, n, orb_table, walker_state, x, grad_out, grad_x);
   FF_LAUNCH_CHECK();
   return FF_OK;
@@ -681,6 +749,16 @@ int ff_logprob(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up,
   FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_logprob: null orbital table");
   FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_logprob: determinant larger than FF_MAX_NS");
   if (B == 0) return FF_OK;
+  {
+    const int nsf = (nup == ndn || ndn == 0) ? nup : (nup == 0 ? ndn : 0);   // one determinant size for both spin species
+    const bool deriv = grad || lap;
+#define FF_LPF(NS_) case NS_: \
+      if (deriv) FF_LAUNCH((ff_logprob_fixed_kernel<NS_, true>), ff_grid(B, 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, x, logp, grad, lap); \
+      else FF_LAUNCH((ff_logprob_fixed_kernel<NS_, false>), ff_grid(B, 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, x, logp, grad, lap); \
+      FF_LAUNCH_CHECK(); return FF_OK;
+    switch (nsf) { FF_LPF(1) FF_LPF(2) FF_LPF(3) FF_LPF(4) default: break; }
+#undef FF_LPF
+  }
   FF_LAUNCH(ff_logprob_kernel, ff_grid(B, 128), 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, x, logp, grad, lap);
   FF_LAUNCH_CHECK();
   return FF_OK;
