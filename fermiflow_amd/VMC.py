@@ -66,6 +66,7 @@ class GSVMC(torch.nn.Module):
         # ODE step-size warm start inside forward(); FERMIFLOW_WARM_START=0 restores the cold start
         self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
         self._h_flow = None
+        self._E_dev = None
         # Persistent walkers (off by default: the reference draws fresh N(0,1) walkers and runs 100 steps in every
         # iteration, src/base_dist.py:62-64): keep the chains and advance them `persistent_steps` steps per sweep.
         self.persistent_walkers = False
@@ -168,9 +169,13 @@ class GSVMC(torch.nn.Module):
             Eloc = r["eloc"]
             # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the
             # sweep, so kernel launches keep running ahead of the GPU
-            s0 = native.reduce_moments(Eloc, 0.0)
-            self._E_dev, self._E_ss = D.global_mean_ss_dev(
-                s0[0], batch, lambda tot, scale: native.reduce_moments(Eloc, shift_dev=tot, shift_dev_scale=scale)[1])
+            # One pass, one all-reduce: first and second moment about a shift every rank knows -- the previous sweep's E
+            # (0 on the first sweep) -- so the subtraction below cancels nothing that matters (|E - shift| << E_std).
+            shift = self._E_dev.reshape(1) if self._E_dev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
+            mom = native.reduce_moments(Eloc, shift_dev=shift)          # [sum(e - c), sum((e - c)^2)]
+            D.all_reduce_sum_(mom)
+            self._E_dev = shift[0] + mom[0] / batch
+            self._E_ss = mom[1] - mom[0] * mom[0] / batch
             self._E_n = batch
             w = (Eloc - self._E_dev) / batch
             v, params = _flow_params(self.cnf)
