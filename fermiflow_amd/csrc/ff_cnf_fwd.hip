@@ -68,6 +68,9 @@ struct ff_fwd_args {
   unsigned long long* queue;
 };
 
+#ifndef FF_FORM_EARLY
+#define FF_FORM_EARLY 1   // MODE 2: form the stage input between the two halves of the radius phase
+#endif
 #ifndef FF_SWEEP_CH
 #define FF_SWEEP_CH 2   // records per look-ahead chunk of the jet sweep (measured at n = 6: 2 -> 1.49 ms, 3 -> 1.52, 4 spills)
 #endif
@@ -293,6 +296,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           if (act && !rq_ok[qk]) off_table = true;
         }
       }
+      // the full stage input is formed here, while the table rows requested above are on their way
+      double in[NV], out[NV];
+      if constexpr (MODE == 2 && FF_FORM_EARLY) form(in, 0, NV, 1);
 #pragma unroll
       for (int qk = 0; qk < NQ; qk++) {
         const int id = rq_id[qk];
@@ -346,8 +352,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       nev++;
       FF_STAMP(2);
       // ------------------------------------------------------------------ right-hand side
-      double in[NV], out[NV];
-      form(in, 0, NV, 1);   // at stage 6 this is the candidate new state
+      if constexpr (!(MODE == 2 && FF_FORM_EARLY)) form(in, 0, NV, 1);   // at stage 6 this is the candidate new state
       FF_STAMP(6);
       const double* sz = s_z[gg];
       double sumq = 0.0, ddiv = 0.0, qdiv = 0.0, divv = 0.0;
