@@ -152,7 +152,8 @@ FF_D double ff_pow02(double x, float e) {
 #ifdef FF_HOSTSIM
   return (double)powf((float)x, e);
 #else
-  return (double)__powf((float)x, e);
+  // v_log_f32 / v_exp_f32 (base 2, ~1e-7 relative): six instructions where the library powf is ~90
+  return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x));
 #endif
 }
 
