@@ -132,13 +132,13 @@ def main():
                 "flop_per_walker_eval": flop_per_eval, "radial_functions": radial}
 
     # HBM bytes of the dominant kernel: not measurable live; taken from the committed rocprofv3 PMC pass
-    # (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01_j_hbm_traffic.json
+    # (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01_k_hbm_traffic.json
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")))
         key = [k for k in tj if "ff_ode_fwd_kernel<%d, 2, 2, true>" % n in k]
         if key and radial == "table" and args.walkers_per_gpu == 65536:
             roofline["traffic"] = tj[key[0]]["hbm_bytes_fetchx2_plus_write"]
-            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_j_hbm_traffic.json), bytes per launch"
+            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_k_hbm_traffic.json), bytes per launch"
             roofline["algorithmic_bytes"] = args.walkers_per_gpu * 8 * (M + M * M + 4 * M + 1)
     except Exception:
         pass
