@@ -1171,7 +1171,11 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
     const bool valid = ingrp && b < B;
     const int nw = (int)((B - b0) < G ? (B - b0) : G);       // walkers of this wave
     __syncthreads();
-    for (int e = lane; e < nw * M * M; e += FF_WAVE) s_u[e] = Jt[b0 * M * M + e];
+    {   // the wave's J^T block: one contiguous span, 16-byte loads (M*M is even, so the span is whole pairs)
+      const double2* __restrict__ J2 = reinterpret_cast<const double2*>(Jt + b0 * M * M);
+      double2* u2 = reinterpret_cast<double2*>(s_u);
+      for (int e = lane; e < nw * M * M / 2; e += FF_WAVE) u2[e] = J2[e];
+    }
     for (int e = lane; e < nw * nq; e += FF_WAVE) { const int q = e / nw, w = e - q * nw; s_q[w * nq + q] = Q[(int64_t)q * B + b0 + w]; }
     if (valid) s_x[lane] = x[b * M + i];
     __syncthreads();
