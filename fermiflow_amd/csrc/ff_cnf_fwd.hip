@@ -1082,8 +1082,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 //   lap    = sum_i u_i^T H0 u_i + g0 . kbar - sum_i L_i
 //   E_loc  = -lap/4 - |grad|^2/8 + V(x)            (src/VMC.py:49-55)
 // Two launches.  (1) ff_eloc_slater_kernel, one lane per walker: the Slater quantities of z(t0) (runtime determinant
-// sizes, private arrays -- serial per walker, so 64 walkers per wave) into a slot-major table Q[slot][walker]
-// (coalesced).  (2) ff_eloc_contract_kernel, M = 2n lanes per walker as in the sensitivity kernels: the wave's G*M*M
+// sizes, private arrays -- serial per walker, so 64 walkers per wave) into a table Q[walker][slot].  (2) ff_eloc_contract_kernel, M = 2n lanes per walker as in the sensitivity kernels: the wave's G*M*M
 // block of J^T is ONE contiguous read (the one-lane-per-walker version of this contraction fetched every cache line
 // ~8 times: 730 MB per launch against 100 MB of sensitivities), each lane contracts its own direction, three LDS sums
 // finish the walker.
@@ -1097,22 +1096,23 @@ ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_u
   const int sp = (int)(gid & 1);
   if (b >= B) return;
   const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
+  const int64_t nqs = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;   // slots per walker
   double zl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS], S[3 * FF_MAX_NS];
   double lp0 = 0.0;
   int tq = M + 3 * n + (sp ? 2 * nup * nup : 0);
   {
     const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-    if (!ns) { Q[(int64_t)(M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp) * B + b] = 0.0; return; }
+    if (!ns) { Q[b * nqs + (M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp)] = 0.0; return; }
     for (int k = 0; k < 2 * ns; k++) zl[k] = z0[b * M + 2 * off + k];
     lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T, S);
     for (int a = 0; a < ns; a++) {
-      Q[(int64_t)(2 * (off + a)) * B + b] = 2.0 * T[a * ns + a];
-      Q[(int64_t)(2 * (off + a) + 1) * B + b] = 2.0 * T[ns * ns + a * ns + a];
-      for (int k = 0; k < 3; k++) Q[(int64_t)(M + 3 * (off + a) + k) * B + b] = S[3 * a + k];
+      Q[b * nqs + (2 * (off + a))] = 2.0 * T[a * ns + a];
+      Q[b * nqs + (2 * (off + a) + 1)] = 2.0 * T[ns * ns + a * ns + a];
+      for (int k = 0; k < 3; k++) Q[b * nqs + (M + 3 * (off + a) + k)] = S[3 * a + k];
     }
-    for (int k = 0; k < 2 * ns * ns; k++) Q[(int64_t)(tq + k) * B + b] = T[k];
+    for (int k = 0; k < 2 * ns * ns; k++) Q[b * nqs + (tq + k)] = T[k];
   }
-  Q[(int64_t)(M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp) * B + b] = 2.0 * lp0;
+  Q[b * nqs + (M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp)] = 2.0 * lp0;
 }
 
 // the same for equal (or single) determinant sizes known at compile time: everything in registers (ff_slater_fixed)
@@ -1125,24 +1125,25 @@ ff_eloc_slater_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__
   const int sp = (int)(gid & 1);
   if (b >= B) return;
   const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
+  const int64_t nqs = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;   // slots per walker
   const int lpq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp;
   const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-  if (!ns) { Q[(int64_t)lpq * B + b] = 0.0; return; }      // ns is NS here
+  if (!ns) { Q[b * nqs + lpq] = 0.0; return; }      // ns is NS here
   double zl[2 * NS], T[2 * NS * NS], S[3 * NS];
 #pragma unroll
   for (int k = 0; k < 2 * NS; k++) zl[k] = z0[b * M + 2 * off + k];
   const double lp0 = ff_slater_fixed<NS>((sp ? tab_dn : tab_up) + st * NS, zl, T, S);
 #pragma unroll
   for (int a = 0; a < NS; a++) {
-    Q[(int64_t)(2 * (off + a)) * B + b] = 2.0 * T[a * NS + a];
-    Q[(int64_t)(2 * (off + a) + 1) * B + b] = 2.0 * T[NS * NS + a * NS + a];
+    Q[b * nqs + (2 * (off + a))] = 2.0 * T[a * NS + a];
+    Q[b * nqs + (2 * (off + a) + 1)] = 2.0 * T[NS * NS + a * NS + a];
 #pragma unroll
-    for (int k = 0; k < 3; k++) Q[(int64_t)(M + 3 * (off + a) + k) * B + b] = S[3 * a + k];
+    for (int k = 0; k < 3; k++) Q[b * nqs + (M + 3 * (off + a) + k)] = S[3 * a + k];
   }
   const int tq = M + 3 * n + (sp ? 2 * nup * nup : 0);
 #pragma unroll
-  for (int k = 0; k < 2 * NS * NS; k++) Q[(int64_t)(tq + k) * B + b] = T[k];
-  Q[(int64_t)lpq * B + b] = 2.0 * lp0;
+  for (int k = 0; k < 2 * NS * NS; k++) Q[b * nqs + (tq + k)] = T[k];
+  Q[b * nqs + lpq] = 2.0 * lp0;
 }
 
 // dynamic LDS: [G*M*M J^T block | G*nq Slater slots | 64 x | 3*64 partial sums]  (10 KB at n = 6: many waves per CU)
@@ -1176,7 +1177,7 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
       double2* u2 = reinterpret_cast<double2*>(s_u);
       for (int e = lane; e < nw * M * M / 2; e += FF_WAVE) u2[e] = J2[e];
     }
-    for (int e = lane; e < nw * nq; e += FF_WAVE) { const int q = e / nw, w = e - q * nw; s_q[w * nq + q] = Q[(int64_t)q * B + b0 + w]; }
+    for (int e = lane; e < nw * nq; e += FF_WAVE) s_q[e] = Q[b0 * nq + e];   // the wave's walkers: one contiguous span
     if (valid) s_x[lane] = x[b * M + i];
     __syncthreads();
     double gi = 0.0, lap_i = 0.0, v_i = 0.0;
