@@ -36,6 +36,27 @@ PEAK_FP64_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (vendor;
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+def self_launch(n):
+    """Start n ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
+    child process and pass its output through.  The parent never initialises a GPU: device_count() only counts."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if os.environ.get("FF_BENCH_BACKEND", "nccl") == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} requested but {have} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +71,11 @@ def main():
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel and CPU-baseline legs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched bare (`python bench.py --gpus N`): this parent starts the N ranks itself -- before anything here has
+        # touched a GPU -- and relays rank 0's JSON line.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -69,8 +95,15 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend=backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        # never report n_gpus != --gpus: a launcher that started the wrong number of ranks is an error
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
+    if backend == "nccl" and torch.cuda.device_count() < (local_rank + 1):
+        print(f"bench.py: rank {rank} needs cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible",
+              file=sys.stderr)
+        sys.exit(2)
     n_gpus = world
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)

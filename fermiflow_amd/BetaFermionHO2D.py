@@ -1,43 +1,68 @@
-"""Finite-temperature VMC driver with the reference's command line (src/BetaFermionHO2D.py:15-85)."""
+"""Finite-temperature VMC driver with the reference's command line (src/BetaFermionHO2D.py:15-85).
+
+    python -m fermiflow_amd.BetaFermionHO2D --beta 10.0 --nup 3 --boltzmann --batch 65536
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m fermiflow_amd.BetaFermionHO2D ...
+
+Same flags and defaults; under torch.distributed (one process per GPU, RCCL) `--batch` is the global walker count.
+`--save/--resume` add the state_dict checkpoint the reference lacks (fermiflow_amd/checkpoint.py)."""
+import os
 import time
 
 import torch
 
-from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, BetaVMC
+from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, BetaVMC, checkpoint
 
 
 def main(argv=None):
     import argparse
     parser = argparse.ArgumentParser(description="Finite-temperature variational Monte Carlo simulation")
-    parser.add_argument("--beta", type=float, default=10.0, help="inverse temperature")
+    parser.add_argument("--beta", type=float, default=2.0, help="inverse temperature")
     parser.add_argument("--nup", type=int, default=6, help="number of spin-up electrons")
-    parser.add_argument("--ndown", type=int, default=0, help="number of spin-down electrons (must be 0)")
+    parser.add_argument("--ndown", type=int, default=0, help="number of spin-down electrons")
     parser.add_argument("--Z", type=float, default=0.5, help="Coulomb interaction strength")
     parser.add_argument("--deltaE", type=float, default=2.0, help="energy cutoff of the many-body states")
     parser.add_argument("--boltzmann", action="store_true", help="initialise the state weights to the Boltzmann distribution")
     parser.add_argument("--cuda", type=int, default=0, help="GPU device number")
-    parser.add_argument("--Deta", type=int, default=50)
-    parser.add_argument("--nomu", action="store_true")
-    parser.add_argument("--Dmu", type=int, default=50)
-    parser.add_argument("--t0", type=float, default=0.0)
-    parser.add_argument("--t1", type=float, default=1.0)
-    parser.add_argument("--iternum", type=int, default=1000)
-    parser.add_argument("--batch", type=int, default=8000)
+    parser.add_argument("--Deta", type=int, default=50, help="hidden layer size of the two-body backflow potential eta")
+    parser.add_argument("--nomu", action="store_true", help="do not use the one-body backflow potential mu")
+    parser.add_argument("--Dmu", type=int, default=50, help="hidden layer size of the one-body backflow potential mu")
+    parser.add_argument("--t0", type=float, default=0.0, help="starting time")
+    parser.add_argument("--t1", type=float, default=1.0, help="ending time")
+    parser.add_argument("--iternum", type=int, default=1000, help="number of new iterations")
+    parser.add_argument("--batch", type=int, default=8000, help="batch size (global, over all ranks)")
+    parser.add_argument("--save", type=str, default=None, help="checkpoint file written after every iteration")
+    parser.add_argument("--resume", type=str, default=None, help="checkpoint file to resume from")
     args = parser.parse_args(argv)
 
-    device = torch.device("cuda:%d" % args.cuda)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = torch.device("cuda:%d" % (local_rank if world > 1 else args.cuda))
     torch.cuda.set_device(device)
-    eta = MLP(1, args.Deta); eta.init_zeros()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=device)
+
+    eta = MLP(1, args.Deta)
+    eta.init_zeros()
     mu = None
     if not args.nomu:
-        mu = MLP(1, args.Dmu); mu.init_zeros()
+        mu = MLP(1, args.Dmu)
+        mu.init_zeros()
     cnf = CNF(Backflow(eta, mu=mu), (args.t0, args.t1))
     model = BetaVMC(args.beta, args.nup, args.ndown, args.deltaE, args.boltzmann, HO2D(), FreeFermion(device=device), cnf,
                     CoulombPairPotential(args.Z), sp_potential=HO())
     model.to(device=device)
-    print("beta = %.1f, nup = %d, ndown = %d, Z = %.1f, Nstates = %d" % (args.beta, args.nup, args.ndown, args.Z, model.Nstates))
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
-    for i in range(1, args.iternum + 1):
+    start_iter = 1
+    if args.resume:
+        start_iter = checkpoint.load(args.resume, model, optimizer, device) + 1
+    if rank == 0:
+        print("beta = %.1f, nup = %d, ndown = %d, Z = %.1f" % (args.beta, args.nup, args.ndown, args.Z))
+        print("deltaE = %.1f, total number of states = %d" % (args.deltaE, model.Nstates))
+        print("batch = %d, iternum = %d." % (args.batch, args.iternum))
+
+    for i in range(start_iter, start_iter + args.iternum):
         start = time.time()
         gradF_phi, gradF_theta = model(args.batch)
         optimizer.zero_grad()
@@ -45,9 +70,15 @@ def main(argv=None):
         gradF_theta.backward()
         optimizer.step()
         torch.cuda.synchronize()
-        print("iter: %03d" % i, "F:", model.F, "F_std:", model.F_std, "E:", model.E, "E_std:", model.E_std,
-              "S:", model.S, "S_analytical:", model.S_analytical,
-              "Instant speed (hours per 100 iters):", (time.time() - start) * 100 / 3600)
+        speed = (time.time() - start) * 100 / 3600
+        if rank == 0:
+            print("iter: %03d" % i, "F:", model.F, "F_std:", model.F_std, "E:", model.E, "E_std:", model.E_std,
+                  "S:", model.S, "S_analytical:", model.S_analytical,
+                  "Instant speed (hours per 100 iters):", speed)
+            if args.save:
+                checkpoint.save(args.save, model, optimizer, i, device)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, GSVMC
+from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, GSVMC, checkpoint
 
 
 def main(argv=None):
@@ -58,8 +58,7 @@ def main(argv=None):
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
     start_iter = 1
     if args.resume:
-        ck = torch.load(args.resume, map_location=device)
-        model.load_state_dict(ck["model"]); optimizer.load_state_dict(ck["optimizer"]); start_iter = ck["iter"] + 1
+        start_iter = checkpoint.load(args.resume, model, optimizer, device) + 1
     if rank == 0:
         print("nup = %d, ndown = %d, Z = %.1f" % (args.nup, args.ndown, args.Z))
         print("batch = %d, iternum = %d." % (args.batch, args.iternum))
@@ -75,7 +74,7 @@ def main(argv=None):
         if rank == 0:
             print("iter: %03d" % i, "E:", model.E, "E_std:", model.E_std, "Instant speed (hours per 100 iters):", speed)
             if args.save:
-                torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(), "iter": i}, args.save)
+                checkpoint.save(args.save, model, optimizer, i, device)
     if world > 1:
         torch.distributed.destroy_process_group()
 

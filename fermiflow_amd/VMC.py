@@ -7,9 +7,14 @@ and return a scalar whose .backward() deposits that gradient in the parameters' 
 reference training loop (`gradE = model(batch); gradE.backward(); optimizer.step()`,
 src/FermionHO2D.py:66-72) runs unchanged.  With torch.distributed initialised, `batch` is the GLOBAL
 number of walkers; each rank handles its contiguous shard and the estimator sums are all-reduced (dist.py).
+
+`forward_from(z, ...)` is the same sweep on GIVEN base-distribution walkers (every line after the sampling is
+shared with forward()); the parity tests feed it the reference's walkers.
+
+Nothing inside a sweep waits for the host: E, E_std (F, F_std, S ...) stay on the device and are converted when
+the attributes are read.
 """
 import os
-import time
 from collections import Counter
 
 import torch
@@ -45,15 +50,109 @@ def _flow_params(cnf):
     return v, list(v.parameters())
 
 
-def _split_like(flat, params):
-    out, off = [], 0
-    for p in params:
-        out.append(flat[off:off + p.numel()].reshape(p.shape))
-        off += p.numel()
-    return out
+class _Sweep:
+    """What GSVMC and BetaVMC share: flow + local energy of given base walkers with the walker schedule and the
+    step-size warm start, the lazily converted device scalars, and the checkpointable sweep state."""
+
+    def _init_sweep(self, n):
+        self.profile = None          # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats
+        # ODE step-size warm start inside the sweep (DESIGN.md 4); FERMIFLOW_WARM_START=0 restores the cold start
+        self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
+        self._h_flow = None          # previous sweep's accepted flow steps: per walker (persistent walkers) or their mean
+        self._dev = {}               # device scalars of the last sweep (E, E_ss, ...), converted on attribute access
+        self._synced = False
+        # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
+        # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
+        self._h_scale_eloc = 0.6 if n <= 8 else (0.45 if n <= 10 else 0.4)
+
+    def _mark(self, ev, name):
+        if self.profile is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[name] = e
+
+    def _first_sweep_sync(self):
+        if not self._synced:
+            D.sync_parameters(self)
+            self._synced = True
+
+    def _flow_and_local_energy(self, net, z, tu, td, nup, ndown, walker_state, ev, per_walker_h=False):
+        """x = CNF.generate(z) and the local energy of x.
+        Walker schedule (include/fermiflow.h, ff_ode.walker_cost/_order): the flow pass reports a cost class per walker
+        (how close its trajectory comes to a vanishing radius); the local-energy pass, whose step count depends on exactly
+        that, takes the expensive walkers first.
+        Step-size warm start (ff_ode.walker_h_*): the three integrations of a sweep follow the same trajectories, so each
+        one opens with the step size the previous one settled on instead of the ~20x too small Hairer start (scaled: the
+        sensitivity system wants 0.4-0.6 of the flow's step depending on the particle number, the adjoint ~1.25 of the
+        sensitivities').  The flow pass itself opens with 0.75 x the MEAN step the previous sweep's flow accepted (one
+        number for all walkers: fresh walkers are unrelated to last sweep's) -- or, with persistent walkers, each
+        chain's own.  Error control per step is unchanged."""
+        prof = self.profile
+        nloc = z.shape[0]
+        t0, t1 = self.cnf.t_span
+        cost = torch.empty(nloc, dtype=torch.int32, device=z.device)
+        warm = self.warm_start
+        hg = torch.empty(nloc, dtype=torch.float64, device=z.device) if warm else None
+        hprev, uniform = None, False
+        if warm and self._h_flow is not None and self._h_flow.device == z.device:
+            if per_walker_h and self._h_flow.shape[0] == nloc:
+                hprev = self._h_flow
+            elif self._h_flow.numel() == 1:
+                hprev, uniform = self._h_flow, True
+        x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=cost,
+                                walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg, walker_h_uniform=uniform)
+        if warm:
+            self._h_flow = hg if per_walker_h else hg.mean().reshape(1)
+        he = torch.empty_like(hg) if warm else None
+        order = native.walker_order(cost)
+        self._mark(ev, "generate")
+        p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
+        r = native.eloc(tu, td, nup, ndown, net, x, t0, t1, self.cnf.rtol, self.cnf.atol,
+                        getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None, walker_state=walker_state,
+                        want_stats=prof is not None, pass1_events=p1, walker_order=order,
+                        walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he)
+        self._mark(ev, "eloc")
+        if prof is not None:
+            prof.setdefault("pass1", []).append(p1)
+            prof.setdefault("eloc_stats", []).append(r["stats"])
+        return x, r, he
+
+    def _moments(self, e, key, n_global):
+        """[sum(e - c), sum((e - c)^2)] about a shift c every rank knows -- the previous sweep's mean (0 on the first sweep)
+        -- so that mean and variance come out of ONE pass and ONE all-reduce without cancellation (|mean - c| << std)."""
+        prev = self._dev.get(key)
+        shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=e.dtype, device=e.device)
+        return shift, native.reduce_moments(e, shift_dev=shift)
+
+    def _set_moments(self, key, shift, mom, n_global):
+        self._dev[key] = shift[0] + mom[0] / n_global
+        self._dev[key + "_ss"] = mom[1] - mom[0] * mom[0] / n_global
+        self._n_global = n_global
+
+    def _scalar(self, key):
+        return self._dev[key].item()
+
+    def _std(self, key):
+        n = self._n_global
+        return (self._dev[key + "_ss"] / (n - 1)).sqrt().item() if n > 1 else float("nan")
+
+    # sweep state that a checkpoint must carry for the next iteration to repeat exactly (torch.nn.Module hooks: the
+    # values travel inside state_dict() under "_extra_state")
+    def get_extra_state(self):
+        st = {"h_flow": self._h_flow, "dev": dict(self._dev), "n_global": getattr(self, "_n_global", 0)}
+        if getattr(self, "_z_prev", None) is not None:
+            st["z_prev"] = self._z_prev
+        return st
+
+    def set_extra_state(self, st):
+        self._h_flow = st.get("h_flow")
+        self._dev = dict(st.get("dev", {}))
+        self._n_global = st.get("n_global", 0)
+        if "z_prev" in st:
+            self._z_prev = st["z_prev"]
 
 
-class GSVMC(torch.nn.Module):
+class GSVMC(_Sweep, torch.nn.Module):
     def __init__(self, nup, ndown, orbitals, basedist, cnf, pair_potential, sp_potential=None):
         super(GSVMC, self).__init__()
         self.orbitals_up, self.orbitals_down = orbitals.orbitals[:nup], orbitals.orbitals[:ndown]
@@ -62,30 +161,21 @@ class GSVMC(torch.nn.Module):
         self.cnf = cnf
         self.pair_potential = pair_potential
         self.sp_potential = sp_potential
-        self.profile = None
-        # ODE step-size warm start inside forward(); FERMIFLOW_WARM_START=0 restores the cold start
-        self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
-        self._h_flow = None
-        self._E_dev = None
+        self._init_sweep(nup + ndown)
         # Persistent walkers (off by default: the reference draws fresh N(0,1) walkers and runs 100 steps in every
         # iteration, src/base_dist.py:62-64): keep the chains and advance them `persistent_steps` steps per sweep.
         self.persistent_walkers = False
         self.persistent_steps = 10
         self._z_prev = None
-        # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
-        # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
-        n = nup + ndown
-        self._h_scale_eloc = 0.6 if n <= 8 else (0.45 if n <= 10 else 0.4)
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
     @property
     def E(self):
-        return self._E_dev.item()
+        return self._scalar("E")
 
     @property
     def E_std(self):
-        n = self._E_n
-        return (self._E_ss / (n - 1)).sqrt().item() if n > 1 else float("nan")
+        return self._std("E")
 
     # -- pieces with the reference's names ---------------------------------------------------------
     def sample(self, sample_shape):
@@ -120,16 +210,9 @@ class GSVMC(torch.nn.Module):
         rank, ws = D.world()
         offset, nloc = D.shard(batch, rank, ws)
         self.basedist.walker_offset = offset
-        prof = self.profile          # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats
         ev = {}
-
-        def mark(name):
-            if prof is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                ev[name] = e
+        self._mark(ev, "t0")
         with torch.no_grad():
-            mark("t0")
             if self.persistent_walkers and self._z_prev is not None and self._z_prev.shape[0] == nloc:
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
@@ -137,64 +220,46 @@ class GSVMC(torch.nn.Module):
             else:
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
             self._z_prev = z if self.persistent_walkers else None
-            mark("mcmc")
-            # Walker schedule (include/fermiflow.h, ff_ode.walker_cost/_order): the flow pass reports a cost class per
-            # walker (how close its trajectory comes to a vanishing radius); the local-energy pass, whose step count
-            # depends on exactly that, takes the expensive walkers first.
+        self._mark(ev, "mcmc")
+        return self._sweep(z, batch, ev)
+
+    def forward_from(self, z, batch=None):
+        """forward() on GIVEN base walkers z (nloc, n, 2) -- this rank's shard of a global batch of `batch` walkers
+        (default: z is the whole batch).  Everything after the Metropolis sampling is the code forward() runs."""
+        ev = {}
+        self._mark(ev, "t0")
+        self._mark(ev, "mcmc")
+        return self._sweep(z.detach().contiguous(), int(batch if batch is not None else z.shape[0]), ev)
+
+    def _sweep(self, z, batch, ev):
+        self._first_sweep_sync()
+        prof = self.profile
+        with torch.no_grad():
             t0, t1 = self.cnf.t_span
-            net = self.cnf.v_wrapper.v.net()
-            steps = torch.empty(nloc, dtype=torch.int32, device=z.device)
-            # Step-size warm start (ff_ode.walker_h_*): the three integrations of a sweep follow the same trajectories, so
-            # each one opens with the step size the previous one settled on instead of the ~20x too small Hairer start
-            # (scaled: the sensitivity system wants 0.4-0.6 of the flow's step depending on the particle number, the
-            # adjoint ~1.25 of the sensitivities'); the flow pass
-            # itself starts from the step sizes of the previous sweep.  Error control per step is unchanged.
-            warm = self.warm_start
-            hg = torch.empty(nloc, dtype=torch.float64, device=z.device) if warm else None
-            hprev = self._h_flow if (warm and self._h_flow is not None and self._h_flow.shape[0] == nloc
-                                     and self._h_flow.device == z.device) else None
-            x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=steps,
-                                    walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg)
-            self._h_flow = hg
-            he = torch.empty_like(hg) if warm else None
-            order = native.walker_order(steps)
-            mark("generate")
-            p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
-            tu, td = self._tables(x.device)
-            r = native.eloc(tu, td, self.nup, self.ndown, net, x, t0, t1, self.cnf.rtol,
-                            self.cnf.atol, getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None,
-                            want_stats=prof is not None, pass1_events=p1, walker_order=order,
-                            walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he)
-            mark("eloc")
-            Eloc = r["eloc"]
-            # E and E_std stay on the device (model.E / model.E_std convert on access): no host round trip inside the
-            # sweep, so kernel launches keep running ahead of the GPU
-            # One pass, one all-reduce: first and second moment about a shift every rank knows -- the previous sweep's E
-            # (0 on the first sweep) -- so the subtraction below cancels nothing that matters (|E - shift| << E_std).
-            shift = self._E_dev.reshape(1) if self._E_dev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
-            mom = native.reduce_moments(Eloc, shift_dev=shift)          # [sum(e - c), sum((e - c)^2)]
-            D.all_reduce_sum_(mom)
-            self._E_dev = shift[0] + mom[0] / batch
-            self._E_ss = mom[1] - mom[0] * mom[0] / batch
-            self._E_n = batch
-            w = (Eloc - self._E_dev) / batch
             v, params = _flow_params(self.cnf)
-            mark("estimator")
-            _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
+            net = v.net(refresh=True)
+            tu, td = self._tables(z.device)
+            x, r, he = self._flow_and_local_energy(net, z, tu, td, self.nup, self.ndown, None, ev,
+                                                   per_walker_h=self.persistent_walkers)
+            Eloc = r["eloc"]
+            shift, mom = self._moments(Eloc, "E", batch)          # [sum(e - c), sum((e - c)^2)]
+            D.all_reduce_sum_(mom)
+            self._set_moments("E", shift, mom, batch)
+            w = (Eloc - self._dev["E"]) / batch
+            self._mark(ev, "estimator")
+            _, gp = native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
                                        self.cnf.rtol, self.cnf.atol, need_gx=False,   # (uniform cost: no schedule)
                                        walker_h_init=he, walker_h_scale=1.25)
             buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
             D.all_reduce_sum_(buf)
-            mark("adjoint")
+            self._mark(ev, "adjoint")
         if prof is not None:
             prof.setdefault("events", []).append(ev)
-            prof.setdefault("pass1", []).append(p1)
-            prof.setdefault("eloc_stats", []).append(r["stats"])
         self.Eloc, self.x = Eloc, x
         return _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
 
 
-class BetaVMC(torch.nn.Module):
+class BetaVMC(_Sweep, torch.nn.Module):
     def __init__(self, beta, nup, ndown, deltaE, boltzmann, orbitals, basedist, cnf, pair_potential, sp_potential=None):
         super(BetaVMC, self).__init__()
         self.beta = beta
@@ -208,22 +273,64 @@ class BetaVMC(torch.nn.Module):
         self.cnf = cnf
         self.pair_potential = pair_potential
         self.sp_potential = sp_potential
+        self._init_sweep(nup + ndown)
+        self._ws = None
+
+    E = property(lambda self: self._scalar("E"))
+    E_std = property(lambda self: self._std("E"))
+    F = property(lambda self: self._scalar("F"))
+    F_std = property(lambda self: self._std("F"))
+    S = property(lambda self: self._scalar("S"))
+    S_analytical = property(lambda self: self._scalar("S_analytical"))
+
+    # the reference's Counter {state index: number of walkers} of this rank's shard (src/VMC.py:96), built on demand
+    @property
+    def state_indices_collection(self):
+        if self._coll is None:
+            self._coll = Counter(self._ws.tolist())
+        return self._coll
+
+    @state_indices_collection.setter
+    def state_indices_collection(self, coll):
+        self._coll = Counter(dict(coll))
+
+    _coll = None
+
+    def _draw_states(self, batch):
+        """Many-body state of every walker of the GLOBAL batch, sorted as the reference does (src/VMC.py:94-96), on the
+        device; rank 0 draws and broadcasts so that every rank cuts its shard from the same list."""
+        logits = self.log_state_weights.detach()
+        idx = torch.multinomial(torch.softmax(logits, dim=0), int(batch), replacement=True)   # = Categorical(logits).sample
+        idx, _ = torch.sort(idx)
+        D.broadcast_(idx)
+        return idx
+
+    def _set_shard(self, idx_global):
+        rank, world = D.world()
+        off, cnt = D.shard(idx_global.numel(), rank, world)
+        self._ws = idx_global[off:off + cnt].to(device=self.basedist.device, dtype=torch.int32).contiguous()
+        self._coll = None
+        self._nglobal = idx_global.numel()
+        self.basedist.walker_offset = off
+        return cnt
 
     def sample(self, sample_shape, nframes=None):
-        """Draw the many-body state of every walker of the GLOBAL batch (CPU generator, so every rank draws the same
-        list), sort by state as the reference does (src/VMC.py:94-96) and keep this rank's contiguous shard."""
         from torch.distributions.categorical import Categorical
         self.state_dist = Categorical(logits=self.log_state_weights)
-        cpu_dist = Categorical(logits=self.log_state_weights.detach().cpu())
-        all_idx = sorted(cpu_dist.sample(sample_shape).tolist())
-        rank, world = D.world()
-        off, cnt = D.shard(len(all_idx), rank, world)
-        self.state_indices_collection = Counter(all_idx[off:off + cnt])
-        self.basedist.walker_offset = off
-        self._nglobal = len(all_idx)
-        z = self.basedist.sample_multstates(self.states, self.state_indices_collection, (cnt,))
+        batch = 1
+        for s in sample_shape:
+            batch *= int(s)
+        cnt = self._set_shard(self._draw_states(batch))
+        z = self._sample_base(cnt)
         x = self.cnf.generate(z, nframes=nframes)
         return z, x
+
+    def _sample_base(self, cnt):
+        from .base_dist import _draw_seed
+        tu, td = self._state_tables(self.basedist.device)
+        z, _, _ = native.mcmc_sample(tu, td, self.nup, self.ndown, cnt, 100, 0.1, _draw_seed(), self.basedist.device,
+                                     walker_offset=self.basedist.walker_offset, walker_state=self._ws)
+        return z
 
     def logp(self, x, params_require_grad=False):
         z, delta_logp = self.cnf.delta_logp(x, params_require_grad=params_require_grad)
@@ -247,48 +354,78 @@ class BetaVMC(torch.nn.Module):
         return r["logp"], r["grad"], r["lap"]
 
     def _walker_state(self, device):
-        return torch.tensor(list(self.state_indices_collection.elements()), dtype=torch.int32, device=device)
+        return self._ws.to(device)
 
     def forward(self, batch):
         """Finite-temperature sweep (src/VMC.py:114-171).  Under torch.distributed `batch` is the global walker count;
-        the per-state sums and both gradients are all-reduced (2*Nstates + Nstates + 3(He+Hm) doubles)."""
+        the per-state sums and both gradients are all-reduced (2*Nstates + 4 doubles, then 1 + 3(He+Hm))."""
+        self._first_sweep_sync()
+        ev = {}
+        self._mark(ev, "t0")
         with torch.no_grad():
-            _, x = self.sample((batch,))
-            device = x.device
-            ws = self._walker_state(device)
-            nloc, nglob = ws.numel(), self._nglobal
-            r = self.local_energy(x, ws)
+            cnt = self._set_shard(self._draw_states(batch))
+            z = self._sample_base(cnt)
+        self._mark(ev, "mcmc")
+        return self._sweep(z, ev)
+
+    def forward_from(self, z, state_indices, batch=None):
+        """forward() on GIVEN base walkers z (nloc, n, 2) in the given many-body states (int tensor / sequence, sorted as
+        the reference keeps them; this rank's shard of a global batch of `batch` walkers)."""
+        self._first_sweep_sync()
+        ws = torch.as_tensor(state_indices).to(device=self.basedist.device, dtype=torch.int32).contiguous()
+        self._ws, self._coll = ws, None
+        self._nglobal = int(batch if batch is not None else ws.numel())
+        ev = {}
+        self._mark(ev, "t0")
+        self._mark(ev, "mcmc")
+        return self._sweep(z.detach().contiguous(), ev)
+
+    def _sweep(self, z, ev):
+        prof = self.profile
+        with torch.no_grad():
+            device = z.device
+            ws, nglob, Ns = self._ws, self._nglobal, self.Nstates
+            t0, t1 = self.cnf.t_span
+            v, params = _flow_params(self.cnf)
+            net = v.net(refresh=True)
+            tu, td = self._state_tables(device)
+            x, r, he = self._flow_and_local_energy(net, z, tu, td, self.nup, self.ndown, ws, ev)
             Eloc = r["eloc"]
-            self.E, self.E_std, _ = D.global_mean_std(Eloc.sum(), nloc, lambda m: ((Eloc - m) ** 2).sum())
             state_indices = ws.to(torch.int64)
-            logits = self.log_state_weights.detach().to(device)
-            logp_all = torch.log_softmax(logits, dim=0)
+            logp_all = torch.log_softmax(self.log_state_weights.detach().to(device), dim=0)
             logp_states = logp_all[state_indices]
             Floc = Eloc + logp_states / self.beta
-            self.F, self.F_std, _ = D.global_mean_std(Floc.sum(), nloc, lambda m: ((Floc - m) ** 2).sum())
-            # per-state sums: entropy estimate, baseline of the theta-gradient, gradient wrt the state logits
-            cF = (Floc - self.F) / nglob
-            stat = torch.zeros(4, self.Nstates, dtype=torch.float64, device=device)
+            # one all-reduce: moments of E_loc and F_loc about the previous sweep's means + per-state (sum E_loc, count)
+            shE, momE = self._moments(Eloc, "E", nglob)
+            shF, momF = self._moments(Floc, "F", nglob)
+            stat = torch.zeros(2, Ns, dtype=torch.float64, device=device)
             stat[0].index_add_(0, state_indices, Eloc)
             stat[1].index_add_(0, state_indices, torch.ones_like(Eloc))
-            stat[2].index_add_(0, state_indices, cF)
-            stat[3, 0] = (logp_states * cF).sum()           # value of gradF_phi (local part)
-            D.all_reduce_sum_(stat)
-            sums, cnts, cF_state = stat[0], stat[1], stat[2]
-            self.S = -(cnts * logp_all).sum().item() / nglob
+            buf1 = torch.cat([momE, momF, stat.reshape(-1)])
+            D.all_reduce_sum_(buf1)
+            self._set_moments("E", shE, buf1[0:2], nglob)
+            self._set_moments("F", shF, buf1[2:4], nglob)
+            sums, cnts = buf1[4:4 + Ns], buf1[4 + Ns:4 + 2 * Ns]
+            self._dev["S"] = -(cnts * logp_all).sum() / nglob                      # -mean log p(state), src/VMC.py:155
+            self._dev["S_analytical"] = -(logp_all * logp_all.exp()).sum()
             self.logp_states_all = logp_all.to(self.log_state_weights.device)
-            self.S_analytical = -(logp_all * logp_all.exp()).sum().item()
-            # d/dlogits sum_b cF_b log_softmax(logits)[s_b] = cF_state - softmax * sum(cF_state)
+            # gradF_phi = mean(logp_states (Floc - F)) (src/VMC.py:162) and its gradient wrt the logits, from the per-state
+            # sums alone:  sum_b cF_b log_softmax(logits)[s_b],  cF_s = sum_{b in s} (Floc_b - F)/n
+            cF_state = (sums + cnts * logp_all / self.beta - cnts * self._dev["F"]) / nglob
+            gphi_val = (logp_all * cF_state).sum()
             g_phi = (cF_state - logp_all.exp() * cF_state.sum()).to(self.log_state_weights.device)
             Eloc_x_mean = (sums / cnts.clamp(min=1.0))[state_indices]       # per-state baseline (src/VMC.py:164-169)
             w = (Eloc - Eloc_x_mean) / nglob
-            v, params = _flow_params(self.cnf)
-            t0, t1 = self.cnf.t_span
-            _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
-                                       self.cnf.rtol, self.cnf.atol, need_gx=False)
+            self._mark(ev, "estimator")
+            _, gp = native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
+                                       self.cnf.rtol, self.cnf.atol, need_gx=False,
+                                       walker_h_init=he, walker_h_scale=1.25)
             buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
             D.all_reduce_sum_(buf)
+            self._mark(ev, "adjoint")
+        if prof is not None:
+            prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
-        gradF_phi = _ScalarWithParamGrads.apply(stat[3, 0].to(self.log_state_weights.device), g_phi.reshape(-1), self.log_state_weights)
+        gradF_phi = _ScalarWithParamGrads.apply(gphi_val.to(self.log_state_weights.device), g_phi.reshape(-1), self.log_state_weights)
         gradF_theta = _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
         return gradF_phi, gradF_theta

@@ -39,6 +39,7 @@ struct ff_adj_args {
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
   double h_scale;
+  int h_stride;              // 1: one entry per walker; 0: h_init[0] for every walker (ff_ode.walker_h_uniform)
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
@@ -116,7 +117,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -394,8 +395,11 @@ ff_ode_adj_kernel(ff_adj_args A) {
       }
     }
     if (valid) {
-      if (A.gx_out) A.gx_out[b * M + i] = y[1];
+      // failed integration (NaN error norm, max_steps): NaN into this walker's x-gradient and into the parameter gradient
+      const double bad = S.fail ? __builtin_nan("") : 0.0;
+      if (A.gx_out) A.gx_out[b * M + i] = y[1] + bad;
       if (i == 0) {
+        if (S.fail) row_add(0, 0, 0, bad);
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
@@ -583,7 +587,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -804,8 +808,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       if (s_before == 6) FF_STAMP(5); else FF_STAMP(4);
     }
     if (valid) {
-      if (A.gx_out) A.gx_out[b * M + i] = y[1];
+      const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN gradients (see ff_ode_adj_kernel)
+      if (A.gx_out) A.gx_out[b * M + i] = y[1] + bad;
       if (i == 0) {
+        if (S.fail) atomicAdd(&s_W[0][0][0], bad);
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
@@ -970,7 +976,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);

@@ -55,6 +55,7 @@ struct ff_fwd_args {
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
   double h_scale;
+  int h_stride;              // 1: one entry per walker; 0: h_init[0] for every walker (ff_ode.walker_h_uniform)
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place
@@ -210,7 +211,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -583,8 +584,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       __syncthreads();
     }
     if (valid) {
-      A.y_out[b * M + i] = y[0];
-      if constexpr (MODE >= 1) { if (i == 0) A.dl_out[b] = y[IDL]; }
+      // a walker whose integration failed (NaN error norm, max_steps) must not pass for a result: its outputs are NaN,
+      // which every consumer (finish kernel, estimator, parameter gradient) propagates -- the stats word is only a diagnostic
+      const double bad = S.fail ? __builtin_nan("") : 0.0;
+      A.y_out[b * M + i] = y[0] + bad;
+      if constexpr (MODE >= 1) { if (i == 0) A.dl_out[b] = y[IDL] + bad; }
       if constexpr (MODE == 2) {
 #pragma unroll
         for (int k = 0; k < M; k++) A.Jt[(b * M + i) * M + k] = y[1 + k];
@@ -745,7 +749,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -1050,12 +1054,13 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     const double L_i = s_err[gg][i] + s_err[gg][M + i];
     __syncthreads();
     if (valid) {
-      if (owner) { A.y_out[b * M + i] = y[0]; A.kbar[b * M + i] = y[MH + 1]; }
+      const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN results (see ff_ode_fwd_kernel)
+      if (owner) { A.y_out[b * M + i] = y[0] + bad; A.kbar[b * M + i] = y[MH + 1]; }
 #pragma unroll
       for (int k = 0; k < MH; k++) A.Jt[(b * M + i) * M + h * MH + k] = y[1 + k];
       if (h == 0) { A.dD[b * M + i] = dD_i; A.Lpart[b * M + i] = L_i; }
       if (idx == 0) {
-        A.dl_out[b] = delta;
+        A.dl_out[b] = delta + bad;
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         ev_sum += nev;
@@ -1340,7 +1345,7 @@ int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, co
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
   a.y_in = z; a.y_out = x_out; a.stats = stats;
   return dispatch_fwd<0>(stream, n, d, a);
 }
@@ -1355,7 +1360,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
   return dispatch_fwd<1>(stream, n, d, a);
 }
@@ -1393,7 +1398,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {

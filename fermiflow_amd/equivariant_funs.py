@@ -16,13 +16,19 @@ class Backflow(torch.nn.Module):
         self.eta = eta
         self.mu = mu
 
-    def net(self, radial=None):
-        """Device view of the weights (+ the radial table built for them); cached until a parameter changes, so the
-        three kernels of one iteration share one table."""
+    def net(self, radial=None, refresh=False):
+        """Device view of the weights (+ the radial table built for them, ~20 us).  The VMC sweeps call this with
+        refresh=True once per sweep and hand the result to their three integrations.  Other callers get a cached view
+        keyed on the parameters' (data_ptr, _version): in-place edits through `p.data` (EMA code, hand-written
+        optimisers) do NOT bump _version -- call invalidate() after such an edit (or pass refresh=True)."""
         key = (radial or L.RADIAL_MODE,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if getattr(self, "_net_key", None) != key:
+        if refresh or getattr(self, "_net_key", None) != key:
             self._net_key, self._net = key, L.Net(self.eta, self.mu, radial=radial)
         return self._net
+
+    def invalidate(self):
+        """Forget the cached radial table (needed only after `p.data` edits, which autograd's version counter misses)."""
+        self._net_key = None
 
     def forward(self, x):
         v, _ = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=True, need_div=False)

@@ -86,13 +86,26 @@ class Orbitals(object):
         return indices, totals
 
     def fermion_states(self, nup, ndown, deltaE):
-        if ndown != 0:
-            raise ValueError("Only the polarized case (i.e., ndown = 0) is allowed "
-                             "in the present implementation.")
-        E0 = sum(self.Es[:nup])
-        indices, Es = self.subsets(nup, E0 + deltaE, self.Es)
-        states = tuple((tuple(self.orbitals[i] for i in subset), ()) for subset in indices)
-        return states, Es
+        """Low-lying Slater-determinant states (src/orbitals.py:33-54) as ((orbitals_up, orbitals_down), ...) and their
+        energies, enumerated natively (ff_fermion_states, host C++).  ndown = 0 gives the reference's states in the
+        reference's order; ndown != 0 -- which the reference rejects (src/orbitals.py:47-49) -- gives all pairs of
+        subsets within deltaE of the ground state, by total energy, ties in (up, down)-lexicographic order."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib as L
+        if nup < 0 or ndown < 0 or nup + ndown == 0:
+            raise ValueError("fermion_states: need nup, ndown >= 0 and at least one particle")
+        E = np.ascontiguousarray(self.Es, dtype=np.float64)
+        args = (len(E), E.ctypes.data_as(C.c_void_p), int(nup), int(ndown), C.c_double(float(deltaE)))
+        ns = L.lib().ff_fermion_states(*args, C.c_int64(0), None, None, None)
+        if ns < 0:
+            raise ValueError("fermion_states: " + L.lib().ff_last_error().decode())
+        up = np.empty((ns, nup), dtype=np.int32); dn = np.empty((ns, ndown), dtype=np.int32); Es = np.empty(ns)
+        L.lib().ff_fermion_states(*args, C.c_int64(ns), up.ctypes.data_as(C.c_void_p), dn.ctypes.data_as(C.c_void_p),
+                                  Es.ctypes.data_as(C.c_void_p))
+        states = tuple((tuple(self.orbitals[i] for i in u), tuple(self.orbitals[i] for i in d)) for u, d in zip(up.tolist(), dn.tolist()))
+        ints = all(float(e).is_integer() for e in self.Es)
+        return states, tuple(int(e) if ints else float(e) for e in Es)
 
 
 class HO2D(Orbitals):

@@ -59,6 +59,8 @@ typedef struct ff_ode {
   const double* walker_h_init;
   double walker_h_scale;
   double* walker_h_out;
+  int32_t walker_h_uniform;   /* nonzero: walker_h_init holds ONE entry, the first step size of every walker (a statistic of an
+                                 earlier call on other walkers of the same distribution, e.g. the mean of its walker_h_out) */
 } ff_ode;
 
 int ff_version(void);
@@ -66,6 +68,18 @@ int ff_version(void);
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);
 const char* ff_last_error(void);
+
+/* ---- many-body state enumeration (host code, no GPU) ------------------------------------------ */
+/* Orbitals.fermion_states (src/orbitals.py:33-54; the subset search of :14-31): all Slater-determinant states of nup
+ * spin-up and ndn spin-down fermions in n_orb orbitals with energies orb_E (non-decreasing) whose total energy does
+ * not exceed the ground state's by more than deltaE.  The reference implements ndn = 0 only (src/orbitals.py:47-49);
+ * for ndn = 0 states and order are the reference's (by energy, ties in lexicographic order of the index tuple);
+ * with two species a state is a pair (up subset, down subset) and ties keep the (up, down)-lexicographic order.
+ * Returns the number of states (-1: invalid argument).  If it does not exceed `capacity` the states are written:
+ * states_up int32 [ns][nup], states_dn int32 [ns][ndn] (orbital indices; either may be NULL), states_E [ns].
+ * Call with capacity = 0 to size the buffers. */
+int64_t ff_fermion_states(int n_orb, const double* orb_E, int nup, int ndn, double deltaE, int64_t capacity,
+                          int32_t* states_up, int32_t* states_dn, double* states_E);
 
 /* ---- Slater determinants / base distribution ------------------------------------------------ */
 /* LogAbsSlaterDet.forward (src/slater.py:13-37): logabsdet[b] = log|det phi_j(r_i)|, x (B,n,2). */

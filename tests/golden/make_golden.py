@@ -53,7 +53,8 @@ def g_mcmc(R):
     out = {}
     for name, (nup, ndown, B, seed, steps) in {
             "u3d3": (3, 3, 64, 7, 100), "u6d0": (6, 0, 64, 11, 100), "u6d6": (6, 6, 32, 13, 100),
-            "u1d0": (1, 0, 16, 3, 50), "u10d0": (10, 0, 16, 5, 50)}.items():
+            "u1d0": (1, 0, 16, 3, 50), "u10d0": (10, 0, 16, 5, 50),
+            "u3d3_b512": (3, 3, 512, 7, 100)}.items():   # SURVEY 8c / BASELINE.md 2 anchor: final-x sha d7799a21de62365d, acceptance 0.7527
         up, dn = ho.orbitals[:nup], ho.orbitals[:ndown]
         torch.manual_seed(seed)
         x_ref = bd.sample(up, dn, (B,), equilibrim_steps=steps)
@@ -86,7 +87,10 @@ def g_mcmc(R):
             out[name + "_g0"] = g0.numpy()
             out[name + "_g10"] = gs[:10]
             out[name + "_u10"] = us[:10]
+        out[name + "_x_sha"] = np.array(sha(x.numpy()))
         print("mcmc", name, "acc-rate", acc.mean(), "x sha", sha(x.numpy())[:16])
+        if name == "u3d3_b512":
+            assert sha(x.numpy()).startswith("d7799a21de62365d") and abs(acc.mean() - 0.7527) < 5e-5, "BASELINE.md anchor moved"
     np.savez_compressed(os.path.join(HERE, "g1_mcmc.npz"), **out)
 
 
@@ -318,7 +322,8 @@ def g_betavmc(R_unused):
     cnf = R.flow.CNF(v, (0.0, 1.0))
     beta, nup, dE, B, seed = 10.0, 3, 2.0, 24, 9
     out = {}
-    for tag, boltz, bta in (("boltz", True, 10.0), ("hot", True, 0.5)):
+    for tag, boltz, bta in (("boltz", True, 10.0), ("hot", True, 0.5), ("rand", False, 2.0)):
+        torch.manual_seed(100)      # "rand": the state logits are torch.randn(Nstates) (src/VMC.py:83); kept in the fixture
         model = R.VMC.BetaVMC(bta, nup, 0, dE, boltz, ho, bd, cnf,
                               R.potentials.CoulombPairPotential(2.0), sp_potential=R.potentials.HO())
         # capture the per-walker data of this very forward (x, E_loc, logp) by wrapping the pieces it calls
@@ -344,6 +349,7 @@ def g_betavmc(R_unused):
         out[f"{tag}_beta"] = np.array(bta); out[f"{tag}_dE"] = np.array(dE)
         out[f"{tag}_keys"] = np.array(keys, dtype=np.int64); out[f"{tag}_counts"] = np.array(cnts, dtype=np.int64)
         out[f"{tag}_Es"] = model.Es_original.numpy()
+        out[f"{tag}_logits"] = model.log_state_weights.detach().numpy().copy()
         out[f"{tag}_states"] = np.stack([orbital_indices(ho, s[0]) for s in model.states])
         for k_ in ("E", "E_std", "F", "F_std", "S", "S_analytical"):
             out[f"{tag}_{k_}"] = np.array(getattr(model, k_))

@@ -53,3 +53,31 @@ def test_two_rank_estimator_matches_single_process():
         assert n == B
         assert abs(e - E) < 1e-12 * abs(E) and abs(s - E_std) < 1e-12 * E_std
         np.testing.assert_allclose(buf.numpy(), ref.numpy(), rtol=1e-10, atol=1e-13)
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fermiflow_amd import dist as D
+    torch.manual_seed(100 + rank)                      # ranks build DIFFERENT parameters (e.g. BetaVMC's random state logits)
+    m = torch.nn.Sequential(torch.nn.Linear(1, 5), torch.nn.Linear(5, 1)).double()
+    m.register_buffer("shift", torch.randn(3, dtype=torch.float64))
+    before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    D.sync_parameters(m)
+    after = torch.cat([p.detach().reshape(-1) for p in m.parameters()] + [m.shift])
+    idx = torch.arange(10) * (rank + 1)
+    D.broadcast_(idx)
+    out[rank] = (before, after, idx)
+    dist.destroy_process_group()
+
+
+def test_ranks_adopt_rank0_parameters_and_state_list():
+    """ranks with differently seeded models must not all-reduce gradients of different functions --
+    sync_parameters (called by the estimators' first sweep) and broadcast_ (BetaVMC's state list) make rank 0 authoritative."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert not torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1][:out[0][0].numel()], out[0][0])
+    assert torch.equal(out[0][2], out[1][2]) and out[1][2].tolist() == list(range(10))

@@ -86,3 +86,40 @@ def test_betavmc_two_ranks_equal_one_rank():
         for a, b in zip(got[:7], ref[:7]):
             assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (a, b)
         np.testing.assert_allclose(got[7], ref[7], rtol=0, atol=1e-10 * np.abs(ref[7]).max())
+
+
+def _run_nccl_single(rank, port, B, out):
+    """One rank, backend nccl (= RCCL): every collective of the sweep really runs (FERMIFLOW_DIST_FORCE)."""
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["FERMIFLOW_DIST_FORCE"] = "1"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from fermiflow_amd import dist as D
+    t = torch.arange(4, dtype=torch.float64, device=dev)
+    D.all_reduce_sum_(t); D.broadcast_(t)
+    assert t.tolist() == [0.0, 1.0, 2.0, 3.0]
+    model = G._model(dev, 3, 3, 2.0)
+    torch.manual_seed(123)
+    g = model(B)
+    g.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    out[0] = (model.E, model.E_std, g.item(), grads, dist.get_backend())
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_sweep_equals_plain_sweep():
+    """the nccl (RCCL) branch of dist.all_reduce_sum_ / broadcast_ executes, inside a full sweep,
+    and changes nothing."""
+    B = 4096
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    one, rc = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, B, one), nprocs=1, join=True)
+    mp.spawn(_run_nccl_single, args=(_free_port(), B, rc), nprocs=1, join=True)
+    E, Es, g, grads, _, _ = one[0]
+    E2, Es2, g2, grads2, backend = rc[0]
+    assert backend == "nccl"
+    assert E2 == E and Es2 == Es and g2 == g and (grads2 == grads).all()

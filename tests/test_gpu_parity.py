@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import oracle as O
-from tests.common import mcmc_noise_from_seed, net_arrays, cnf_param_grads, gsvmc_param_grads
+from tests.common import mcmc_noise_from_seed, net_arrays, cnf_param_grads, gsvmc_param_grads, GSVMC_PG
 
 pytestmark = pytest.mark.gpu
 ELOC_RTOL = 1e-5     # the bar of the north star; observed ~1e-9
@@ -93,7 +93,7 @@ def test_known_answer_eigenfunctions_full_size(dev):
 
 
 # ------------------------------------------------------------------------------------------------ MCMC
-@pytest.mark.parametrize("name", ["u3d3", "u6d0", "u6d6", "u1d0", "u10d0"])
+@pytest.mark.parametrize("name", ["u3d3", "u6d0", "u6d6", "u1d0", "u10d0", "u3d3_b512"])
 def test_mcmc_bit_exact_vs_reference(golden, dev, name):
     import fermiflow_amd as ff
     G = golden["g1_mcmc"]
@@ -104,6 +104,10 @@ def test_mcmc_bit_exact_vs_reference(golden, dev, name):
     assert (N(acc) == accept).all(), "acceptance indices differ from the reference"
     assert (N(x) == G[name + "_x"]).all(), "final walkers are not bit-identical"
     np.testing.assert_allclose(N(logp), G[name + "_logp"], atol=1e-12)
+    if name == "u3d3_b512":     # BASELINE.md 2 anchor: seed 7, 512 walkers
+        import hashlib
+        assert hashlib.sha256(np.ascontiguousarray(N(x)).tobytes()).hexdigest().startswith("d7799a21de62365d")
+        assert abs(N(acc).mean() - 0.7527) < 5e-5
 
 
 def test_mcmc_full_size_properties(dev):
@@ -255,6 +259,74 @@ def test_gsvmc_iteration_statistics_and_oracle(golden, dev):
     assert 3.0 < model.E_std < 12.0       # heavy-tailed (Coulomb): 4.9 .. 7.4 seen over seeds / noise streams at this B
     np.testing.assert_allclose(model.E, model.Eloc.mean().item(), rtol=1e-13)
     np.testing.assert_allclose(model.E_std, model.Eloc.std().item(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("name,rt,at,vtol,gtol", [("z2_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("z2_nt", 1e-6, 1e-8, 1e-5, 1e-5),
+                                                  ("z05_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("u6_nt", 1e-10, 1e-12, 1e-7, 1e-6),
+                                                  ("z2_nomu", 1e-10, 1e-12, 1e-7, 1e-6)])
+def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gtol):
+    """GSVMC.forward -> .backward() END TO END (src/VMC.py:40-59, src/FermionHO2D.py:69-72) on the reference's base
+    walkers z, through the production sweep (flow with cost classes, cost-ordered local-energy pass, step-size warm
+    start between the three integrations, one-pass moments, _ScalarWithParamGrads): E, E_std, gradE and the .grad of
+    every parameter against the reference's.  Tolerances: values 1e-7 relative at rtol 1e-10 (1e-5, the north-star
+    bar, at the reference's default tolerance), gradients 1e-6 (1e-5) of their largest entry."""
+    import fermiflow_amd as ff
+    G = golden["g5_gsvmc"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    use_mu = bool(G[name + "_use_mu"])
+    eta, mu = net_arrays(G, name + "_", use_mu)
+    cnf = make_flow(eta, mu, dev)
+    cnf.rtol, cnf.atol = rt, at
+    model = ff.GSVMC(nup, ndn, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
+                     ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
+    assert model.warm_start
+    for sweep in range(2):      # the second sweep opens its flow pass with the first one's mean step (warm start across sweeps)
+        gradE = model.forward_from(T(G[name + "_z"], dev))
+        model.zero_grad()
+        gradE.backward()
+        np.testing.assert_allclose(N(model.x), G[name + "_x"], atol=100 * rt)
+        np.testing.assert_allclose(model.E, float(G[name + "_E"]), rtol=vtol)
+        np.testing.assert_allclose(model.E_std, float(G[name + "_E_std"]), rtol=10 * vtol)
+        np.testing.assert_allclose(gradE.item(), float(G[name + "_gradE"]), rtol=100 * vtol, atol=1e-9)
+        ref = gsvmc_param_grads(G, name, use_mu)
+        got = np.concatenate([N(p.grad).reshape(-1) for p in model.parameters()])
+        np.testing.assert_allclose(got, ref, atol=gtol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["boltz", "hot", "rand"])
+def test_betavmc_forward_backward_vs_reference(golden, dev, tag):
+    """BetaVMC.forward -> both .backward()s END TO END (src/VMC.py:114-171, src/BetaFermionHO2D.py:72-79) on the
+    reference's base walkers and state assignment: E, E_std, F, F_std, S, S_analytical, logp_states_all, gradF_phi,
+    gradF_theta, d/d(log_state_weights) and the six flow-parameter gradients.  Values 1e-7 relative, gradients 1e-5 of
+    their largest entry."""
+    import fermiflow_amd as ff
+    G = golden["g6_betavmc"]
+    eta, mu = net_arrays(G, "")
+    cnf = make_flow(eta, mu, dev)
+    cnf.rtol, cnf.atol = 1e-10, 1e-12
+    model = ff.BetaVMC(float(G[tag + "_beta"]), 3, 0, float(G[tag + "_dE"]), tag != "rand", ff.HO2D(), ff.FreeFermion(device=dev), cnf,
+                       ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+    model.to(dev)
+    with torch.no_grad():
+        model.log_state_weights.copy_(T(G[tag + "_logits"], dev))
+    ws = np.repeat(G[tag + "_keys"], G[tag + "_counts"])
+    gphi, gtheta = model.forward_from(T(G[tag + "_z"], dev), ws)
+    model.zero_grad()
+    (gphi + gtheta).backward()
+    np.testing.assert_allclose(N(model.x), G[tag + "_x"], atol=1e-8)
+    for k in ("E", "F", "S", "S_analytical"):
+        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=1e-7, err_msg=k)
+    for k in ("E_std", "F_std"):
+        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=1e-6, err_msg=k)
+    np.testing.assert_allclose(N(model.logp_states_all), G[tag + "_logp_states_all"], atol=1e-12)
+    np.testing.assert_allclose(gphi.item(), float(G[tag + "_gphi"]), rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(gtheta.item(), float(G[tag + "_gtheta"]), rtol=1e-5, atol=1e-10)
+    ref = G[tag + "_pg_log_state_weights"]
+    np.testing.assert_allclose(N(model.log_state_weights.grad), ref, atol=1e-5 * max(np.abs(ref).max(), 1e-12))
+    ref = np.concatenate([G[f"{tag}_pg_{k}"] for k in GSVMC_PG])
+    got = np.concatenate([N(p.grad).reshape(-1) for p in cnf.parameters()])
+    np.testing.assert_allclose(got, ref, atol=1e-5 * np.abs(ref).max())
+    assert dict(model.state_indices_collection) == dict(zip(G[tag + "_keys"].tolist(), G[tag + "_counts"].tolist()))
 
 
 def test_betavmc_vs_reference(golden, dev):
@@ -593,3 +665,92 @@ def test_potential_kernels_against_the_formula(dev, n, d, B):
     ref = 1.7 / rij[:, iu[0], iu[1]]
     np.testing.assert_allclose(N(native.potential(x, 1.7, True)), N(ref.sum(1) + 0.5 * (x ** 2).sum((1, 2))), rtol=1e-13)
     np.testing.assert_allclose(N(native.potential(x, 1.7, False)), N(ref.sum(1)), rtol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+@pytest.mark.parametrize("warm", ["1", "0"])
+def test_checkpoint_resume_reproduces_the_uninterrupted_run(dev, tmp_path, monkeypatch, warm, capsys):
+    """--save / --resume of the ground-state driver: 2 iterations + resume + 1 iteration == 3 iterations, bit for bit
+    (parameters, Adam moments, E of the third iteration) -- with the step-size warm start on (its state travels in the
+    checkpoint) and off."""
+    from fermiflow_amd import FermionHO2D
+    monkeypatch.setenv("FERMIFLOW_WARM_START", warm)
+    a, b = str(tmp_path / "a.pt"), str(tmp_path / "b.pt")
+    common = ["--nup", "3", "--ndown", "3", "--Z", "2.0", "--batch", "2048"]
+    torch.manual_seed(11)
+    FermionHO2D.main(common + ["--iternum", "3", "--save", a])
+    out_a = capsys.readouterr().out
+    torch.manual_seed(11)
+    FermionHO2D.main(common + ["--iternum", "2", "--save", b])
+    torch.manual_seed(999)          # the resumed run must take its RNG streams from the checkpoint, not from here
+    FermionHO2D.main(common + ["--iternum", "1", "--resume", b, "--save", b])
+    out_b = capsys.readouterr().out
+    ca, cb = torch.load(a, weights_only=False), torch.load(b, weights_only=False)
+    assert ca["iter"] == cb["iter"] == 3
+    for k, v in ca["model"].items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, cb["model"][k]), k
+    for sa, sb in zip(ca["optimizer"]["state"].values(), cb["optimizer"]["state"].values()):
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    line3 = lambda o: [l for l in o.splitlines() if l.startswith("iter: 003")][0].split("Instant")[0]
+    assert line3(out_a) == line3(out_b)
+
+
+def test_betavmc_checkpoint_and_two_spin_species(dev, tmp_path, capsys):
+    """Finite-temperature driver: --ndown != 0 runs (the reference rejects it), the reference default
+    --beta 2.0 is back, and --save/--resume continues the run (E/F of the resumed iteration equal the uninterrupted one's
+    to reduction-order noise: the per-state sums use device atomics)."""
+    from fermiflow_amd import BetaFermionHO2D
+    a, b = str(tmp_path / "a.pt"), str(tmp_path / "b.pt")
+    common = ["--nup", "2", "--ndown", "1", "--Z", "1.0", "--deltaE", "1.0", "--boltzmann", "--batch", "1024"]
+    torch.manual_seed(5)
+    BetaFermionHO2D.main(common + ["--iternum", "3", "--save", a])
+    out_a = capsys.readouterr().out
+    assert "beta = 2.0" in out_a and "total number of states = 10" in out_a
+    torch.manual_seed(5)
+    BetaFermionHO2D.main(common + ["--iternum", "2", "--save", b])
+    BetaFermionHO2D.main(common + ["--iternum", "1", "--resume", b, "--save", b])
+    out_b = capsys.readouterr().out
+    ca, cb = torch.load(a, weights_only=False), torch.load(b, weights_only=False)
+    for k, v in ca["model"].items():
+        if isinstance(v, torch.Tensor):
+            np.testing.assert_allclose(N(v), N(cb["model"][k]), rtol=1e-9, atol=1e-12, err_msg=k)
+    vals = lambda o: [float(t) for t in [l for l in o.splitlines() if l.startswith("iter: 003")][0].split("Instant")[0].replace(":", " ").split() if t.replace(".", "").replace("-", "").replace("e", "").isdigit()]
+    np.testing.assert_allclose(vals(out_a), vals(out_b), rtol=1e-9)
+
+
+def test_betavmc_two_spin_species_vs_oracle(dev):
+    """nup = 2, ndown = 1, 10 states: Metropolis chain bit-exact and local energies within the bar against the oracle,
+    every walker in its own (up, down) orbital pair."""
+    import fermiflow_amd as ff
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    h = ff.HO2D()
+    states, Es = h.fermion_states(2, 1, 1.0)
+    up = np.array([[o.k for o in s[0]] for s in states], dtype=np.int32)
+    dn = np.array([[o.k for o in s[1]] for s in states], dtype=np.int32)
+    B, S = 200, 40
+    rng = np.random.RandomState(1)
+    ws = np.sort(rng.randint(0, len(states), B)).astype(np.int32)
+    g0, g, u = rng.randn(B, 3, 2), rng.randn(S, B, 3, 2), rng.rand(S, B)
+    tu, td = native.orbital_table(up, dev), native.orbital_table(dn, dev)
+    x, logp, acc = native.mcmc_sample_noise(tu, td, 2, 1, T(g0, dev), T(g, dev), T(u, dev), walker_state=T(ws, dev, torch.int32))
+    xo, lo, ao = O.mcmc_noise(g0, g, u, 2, 1, tab_up=up, tab_dn=dn, wstate=ws)
+    assert (N(acc) == ao).all() and (N(x) == xo).all()
+    gs = Gm._model(dev, 2, 1, 1.0)
+    model = ff.BetaVMC(2.0, 2, 1, 1.0, True, h, ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(1.0), sp_potential=ff.HO())
+    model.to(dev)
+    assert model.Nstates == 10
+    xs = gs.cnf.generate(x)
+    r = model.local_energy(xs, T(ws, dev, torch.int32))
+    v = gs.cnf.v_wrapper.v
+    net = O.Net(tuple(N(t) for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
+                tuple(N(t) for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+    ref = O.eloc(N(xs)[:64], 2, 1, net, 1.0, rtol=1e-10, atol=1e-12, tab_up=up, tab_dn=dn, wstate=ws[:64])
+    rel = np.abs(N(r["eloc"])[:64] - ref["eloc"]) / np.abs(ref["eloc"])
+    assert rel.max() < ELOC_RTOL, rel.max()
+    np.testing.assert_allclose(N(r["logp"])[:64], ref["logp"], atol=1e-6)
+    torch.manual_seed(3)
+    gphi, gtheta = model(1024)
+    (gphi + gtheta).backward()
+    assert np.isfinite([model.E, model.F, model.S]).all()

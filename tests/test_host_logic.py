@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from fermiflow_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "fermiflow.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(ff_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|size_t|const char\*)\s+(ff_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     lib = _lib.lib()          # loads without a GPU (links against libamdhip64 only)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
@@ -76,9 +76,25 @@ def test_orbitals_and_state_enumeration(golden):
             idx = np.array([[o.k for o in t[0]] for t in s])
             assert (idx == G[f"enum_N{N}_dE{de}_idx"]).all()
             assert (np.array(e) == G[f"enum_N{N}_dE{de}_E"]).all()
+            ip, ep = h.subsets(N, sum(h.Es[:N]) + de, h.Es)      # the Python restatement of src/orbitals.py:14-31
+            assert [tuple(r) for r in idx.tolist()] == list(ip) and list(e) == list(ep)
     assert len(h.fermion_states(3, 0, 2.0)[0]) == 21          # config 3 of BASELINE.json
+    assert len(h.fermion_states(10, 0, 4)[0]) == 1781
+    # two spin species (the reference raises here, src/orbitals.py:47-49): pairs of subsets within deltaE
+    # of the ground state, by total energy, ties in (up, down)-lexicographic order
+    s, e = h.fermion_states(2, 1, 1.0)
+    got = [(tuple(o.k for o in a), tuple(o.k for o in b), E) for (a, b), E in zip(s, e)]
+    assert got == [((0, 1), (0,), 4), ((0, 2), (0,), 4), ((0, 1), (1,), 5), ((0, 1), (2,), 5), ((0, 2), (1,), 5),
+                   ((0, 2), (2,), 5), ((0, 3), (0,), 5), ((0, 4), (0,), 5), ((0, 5), (0,), 5), ((1, 2), (0,), 5)]
+    s, e = h.fermion_states(3, 3, 2.0)
+    assert len(s) == 77 and e[0] == 10 and e[-1] == 12 and list(e) == sorted(e)
+    # brute force over all subset pairs gives the same set
+    import itertools
+    brute = {(u, d) for u in itertools.combinations(range(10), 3) for d in itertools.combinations(range(10), 3)
+             if sum(h.Es[i] for i in u) + sum(h.Es[i] for i in d) <= 12}
+    assert {(tuple(o.k for o in a), tuple(o.k for o in b)) for a, b in s} == brute
     with pytest.raises(ValueError):
-        h.fermion_states(3, 1, 2.0)
+        h.fermion_states(0, 0, 2.0)
 
 
 def test_reference_error_behaviour():

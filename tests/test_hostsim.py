@@ -263,3 +263,43 @@ def test_mcmc_continue_is_the_same_chain_from_given_walkers(nup, ndn):
     xz, lz, _ = S.mcmc_continue(x0, nup, ndn, 0, seed=1)
     assert np.array_equal(xz, x0)
     np.testing.assert_allclose(lz, S.logprob(x0, nup, ndn)[0], rtol=1e-13)
+
+
+def test_failed_integration_poisons_its_outputs(golden):
+    """a walker that hits max_steps (or a NaN error norm) must not hand back its partial state -- every
+    ODE entry point writes NaN for it, independent of the stats word."""
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    x = G["z2_nt_x"][:6]
+    for table in (False, True):
+        net = S.Net(eta, mu, table=table)
+        try:
+            S.warm(max_steps=1)          # cold start: the first, tiny step is accepted, the walker is not done -> failure
+            y, st = S.cnf_generate(x, net)
+            assert st[3] == 1 and np.isnan(y).all()
+            z, dl, st = S.cnf_delta_logp(x, net)
+            assert st[3] == 1 and np.isnan(z).all() and np.isnan(dl).all()
+            r = S.eloc(x, 3, 3, net, 2.0)
+            assert r["stats"][3] == 1 and np.isnan(r["eloc"]).all()
+            gx, gp, st = S.cnf_adjoint(x, np.ones_like(x), np.ones(len(x)), net)
+            assert st[3] == 1 and np.isnan(gx).all() and np.isnan(gp).any()
+        finally:
+            S.warm()
+        y, st = S.cnf_generate(x, net)
+        assert st[3] == 0 and np.isfinite(y).all()
+
+
+def test_uniform_warm_start_entry(golden):
+    """ff_ode.walker_h_uniform: ONE first step size for every walker == the same value repeated per walker."""
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    net = S.Net(eta, mu, table=True)
+    z = G["z2_nt_z"][:7]
+    try:
+        S.warm(h_init=np.full(7, 0.4), h_scale=0.75)
+        xa, sa = S.cnf_generate(z, net)
+        S.warm(h_init=np.array([0.4]), h_scale=0.75, uniform=True)
+        xb, sb = S.cnf_generate(z, net)
+    finally:
+        S.warm()
+    assert (xa == xb).all() and (sa == sb).all()

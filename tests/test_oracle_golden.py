@@ -127,3 +127,72 @@ def test_betavmc_walkers(golden):
         r = O.eloc(G[tag + "_x"], 3, 0, net, 2.0, rtol=1e-10, atol=1e-12, tab_up=G[tag + "_states"], wstate=ws)
         np.testing.assert_allclose(r["eloc"], G[tag + "_Eloc"], rtol=1e-9)
         np.testing.assert_allclose(r["eloc"].mean(), float(G[tag + "_E"]), rtol=1e-10)
+
+
+def test_mcmc_b512_anchor(golden):
+    """BASELINE.md 2 / SURVEY 8c anchor: seed 7, 512 walkers, (3,3): final-x SHA-256 d7799a21de62365d, acceptance 0.7527."""
+    import hashlib
+    G = golden["g1_mcmc"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, "u3d3_b512")
+    x, logp, acc = O.mcmc_noise(g0, g, u, nup, ndn)
+    assert (acc == accept).all() and (x == G["u3d3_b512_x"]).all()
+    assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest().startswith("d7799a21de62365d")
+    assert abs(acc.mean() - 0.7527) < 5e-5
+
+
+def betavmc_estimators(eloc, logp, ws, logits, beta):
+    """src/VMC.py:146-171 restated on given per-walker E_loc / logp: returns E, E_std, F, F_std, S, gphi, gtheta, the
+    gradient of gphi wrt the state logits and the per-walker weights of the theta-gradient."""
+    B = len(eloc)
+    m = logits.max()
+    lsm = logits - (m + np.log(np.exp(logits - m).sum()))
+    lps = lsm[ws]
+    floc = eloc + lps / beta
+    E, F = eloc.mean(), floc.mean()
+    cF = (floc - F) / B
+    gphi = (lps * cF).sum()
+    onehot = np.zeros((B, len(logits))); onehot[np.arange(B), ws] = 1.0
+    g_logits = (cF[:, None] * (onehot - np.exp(lsm)[None, :])).sum(axis=0)
+    base = np.array([eloc[ws == s].mean() for s in ws])
+    w = (eloc - base) / B
+    return dict(E=E, E_std=eloc.std(ddof=1), F=F, F_std=floc.std(ddof=1), S=-lps.mean(), gphi=gphi,
+                gtheta=(logp * w).sum(), g_logits=g_logits, w=w)
+
+
+BETA_PG = ["cnf.v_wrapper.v.eta.fc1.weight", "cnf.v_wrapper.v.eta.fc1.bias", "cnf.v_wrapper.v.eta.fc2.weight",
+           "cnf.v_wrapper.v.mu.fc1.weight", "cnf.v_wrapper.v.mu.fc1.bias", "cnf.v_wrapper.v.mu.fc2.weight"]
+
+
+@pytest.mark.parametrize("tag", ["boltz", "hot", "rand"])
+def test_betavmc_estimators_and_gradients(golden, tag):
+    """F, F_std, S, gradF_phi, gradF_theta (per-state baseline), d gradF_phi / d logits and the six theta-gradients of
+    BetaVMC.forward + backward (src/VMC.py:146-171, src/BetaFermionHO2D.py:72-79) from the reference's walkers."""
+    G = golden["g6_betavmc"]
+    net = O.Net(*net_arrays(G, ""))
+    ws = np.repeat(G[tag + "_keys"], G[tag + "_counts"])
+    beta, logits = float(G[tag + "_beta"]), G[tag + "_logits"]
+    r = O.eloc(G[tag + "_x"], 3, 0, net, 2.0, rtol=1e-10, atol=1e-12, tab_up=G[tag + "_states"], wstate=ws)
+    e = betavmc_estimators(r["eloc"], r["logp"], ws, logits, beta)
+    for k in ("E", "E_std", "F", "F_std", "S"):
+        np.testing.assert_allclose(e[k], float(G[f"{tag}_{k}"]), rtol=1e-9, err_msg=k)
+    np.testing.assert_allclose(e["gphi"], float(G[tag + "_gphi"]), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(e["gtheta"], float(G[tag + "_gtheta"]), rtol=1e-8, atol=1e-12)
+    ref = G[tag + "_pg_log_state_weights"]
+    np.testing.assert_allclose(e["g_logits"], ref, atol=1e-11 * max(1.0, np.abs(ref).max()))
+    z, dl, _ = O.cnf_delta_logp(G[tag + "_x"], net, rtol=1e-10, atol=1e-12)
+    _, g0, _ = O.logprob(z, 3, 0, tab_up=G[tag + "_states"], wstate=ws)
+    _, gp, _ = O.cnf_adjoint(z, dl, e["w"][:, None, None] * g0, -e["w"], net, rtol=1e-10, atol=1e-12)
+    ref = np.concatenate([G[f"{tag}_pg_{k}"] for k in BETA_PG])
+    np.testing.assert_allclose(gp, ref, atol=1e-8 * np.abs(ref).max())
+
+
+def test_gsvmc_estimator(golden):
+    """E, E_std, gradE of GSVMC.forward (src/VMC.py:57-58) from the oracle's local energies of the reference's walkers."""
+    G = golden["g5_gsvmc"]
+    for name in ("z2_nt", "z05_nt", "u6_nt"):
+        nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+        net = O.Net(*net_arrays(G, name + "_", bool(G[name + "_use_mu"])))
+        r = O.eloc(G[name + "_x"], nup, ndn, net, float(G[name + "_Z"]), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r["eloc"].mean(), float(G[name + "_E"]), rtol=1e-10)
+        np.testing.assert_allclose(r["eloc"].std(ddof=1), float(G[name + "_E_std"]), rtol=1e-8)
+        np.testing.assert_allclose((r["logp"] * (r["eloc"] - r["eloc"].mean())).mean(), float(G[name + "_gradE"]), rtol=1e-7, atol=1e-12)
