@@ -38,8 +38,7 @@ struct ff_adj_args {
   double* off_table;    // one double, zeroed per call: set to 1 when a radius falls off the deposit table
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
-  double h_scale;
-  int h_stride;              // 1: one entry per walker; 0: h_init[0] for every walker (ff_ode.walker_h_uniform)
+  double h_scale;          // negative: h_init holds ONE entry used by every walker (ff_ode.walker_h_uniform), scale = -h_scale
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
@@ -87,8 +86,8 @@ ff_ode_adj_kernel(ff_adj_args A) {
   const double rtol = A.rtol, atol = A.atol;
   constexpr double NT = 2 * M;
   const int64_t ngroups = (A.B + G - 1) / G;
-  long long ev_sum = 0;
-  int acc_max = 0, rej_sum = 0, fail_any = 0;
+  __shared__ int s_st[4];   // ODE statistics of this workgroup's walkers (LDS: nothing loop-carried in registers)
+  if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
 
   // This lane's slice of the parameter-gradient row of (workgroup, group-slot): entries of its own units only,
   // so accepted steps are added with plain (non-atomic) read-modify-writes; the API zeroes the rows first.
@@ -117,7 +116,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -402,20 +401,18 @@ ff_ode_adj_kernel(ff_adj_args A) {
         if (S.fail) row_add(0, 0, 0, bad);
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
-        ev_sum += nev;
-        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
-        rej_sum += S.nrej;
-        fail_any |= S.fail;
+        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
     __syncthreads();
   }
   // (rows are summed deterministically by ff_rows_reduce_kernel)
-  if (A.stats && (ev_sum || fail_any)) {
-    atomicAdd(&A.stats[0], (int)ev_sum);
-    atomicMax(&A.stats[1], acc_max);
-    atomicAdd(&A.stats[2], rej_sum);
-    if (fail_any) atomicMax(&A.stats[3], 1);
+  __syncthreads();
+  if (A.stats && threadIdx.x == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
   }
 }
 
@@ -567,8 +564,8 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   bool off_any = false;
   constexpr double NT = 2 * M;
   const int64_t ngroups = (A.B + G - 1) / G;
-  long long ev_sum = 0;
-  int acc_max = 0, rej_sum = 0, fail_any = 0;
+  __shared__ int s_st[4];   // ODE statistics of this workgroup's walkers (LDS: nothing loop-carried in registers)
+  if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
   double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
@@ -587,7 +584,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -814,10 +811,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         if (S.fail) atomicAdd(&s_W[0][0][0], bad);
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
-        ev_sum += nev;
-        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
-        rej_sum += S.nrej;
-        fail_any |= S.fail;
+        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
     __syncthreads();
@@ -832,11 +826,12 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
   }
-  if (A.stats && (ev_sum || fail_any)) {
-    atomicAdd(&A.stats[0], (int)ev_sum);
-    atomicMax(&A.stats[1], acc_max);
-    atomicAdd(&A.stats[2], rej_sum);
-    if (fail_any) atomicMax(&A.stats[3], 1);
+  __syncthreads();
+  if (A.stats && threadIdx.x == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
   }
 }
 
@@ -976,7 +971,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);

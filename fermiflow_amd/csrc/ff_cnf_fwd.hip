@@ -54,8 +54,7 @@ struct ff_fwd_args {
   double* Lpart;        // (B, M)   per-direction parts of lap_x Delta
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
-  double h_scale;
-  int h_stride;              // 1: one entry per walker; 0: h_init[0] for every walker (ff_ode.walker_h_uniform)
+  double h_scale;          // negative: h_init holds ONE entry used by every walker (ff_ode.walker_h_uniform), scale = -h_scale
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place
@@ -161,8 +160,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   const double rtol = A.rtol, atol = A.atol;
   constexpr double NT = MODE == 0 ? M : (MODE == 1 ? M + 1 : M * (M + 4) + 1);
   const int64_t ngroups = (A.B + G - 1) / G;
-  long long ev_sum = 0;
-  int acc_max = 0, rej_sum = 0, fail_any = 0;
+  // ODE statistics of this workgroup's walkers, kept in LDS (nothing loop-carried in registers across the persistent loop)
+  __shared__ int s_st[4];
+  if (lane < 4) s_st[lane] = 0;
   // the radii this lane evaluates in the radius phase (slot qk: radius lane + 64 qk of the wave's G*nrad), fixed for the
   // whole launch: walker slot, particles, radius index packed into one register each
   constexpr int NQ = (G * R + FF_WAVE - 1) / FF_WAVE;
@@ -211,7 +211,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -586,7 +586,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     if (valid) {
       // a walker whose integration failed (NaN error norm, max_steps) must not pass for a result: its outputs are NaN,
       // which every consumer (finish kernel, estimator, parameter gradient) propagates -- the stats word is only a diagnostic
-      const double bad = S.fail ? __builtin_nan("") : 0.0;
+      const bool failed = S.fail != 0;
+#ifdef FF_NO_POISON
+      const double bad = 0.0;
+#else
+      const double bad = failed ? __builtin_nan("") : 0.0;
+#endif
       A.y_out[b * M + i] = y[0] + bad;
       if constexpr (MODE >= 1) { if (i == 0) A.dl_out[b] = y[IDL] + bad; }
       if constexpr (MODE == 2) {
@@ -603,10 +608,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           for (int p = 0; p < nrad; p++) rm = fmin(rm, s_rmin[g][p]);
           A.wcost[b] = ff_cost_class(S.nacc + S.nrej, rm);
         }
-        ev_sum += nev;
-        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
-        rej_sum += S.nrej;
-        fail_any |= S.fail;
+        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
       }
     }
     __syncthreads();
@@ -636,11 +638,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #endif
 #endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  if (A.stats && (ev_sum || fail_any)) {
-    atomicAdd(&A.stats[0], (int)ev_sum);
-    atomicMax(&A.stats[1], acc_max);
-    atomicAdd(&A.stats[2], rej_sum);
-    if (fail_any) atomicMax(&A.stats[3], 1);
+  __syncthreads();
+  if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
   }
 }
 
@@ -724,8 +727,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   }
   constexpr double NT = 2.0 * M + (double)M * M + 3.0 * L;   // z, kbar (owners), u, and three partial scalars per lane
   const int64_t ngroups = (A.B + G - 1) / G;
-  long long ev_sum = 0;
-  int acc_max = 0, rej_sum = 0, fail_any = 0;
+  // ODE statistics of this workgroup's walkers, kept in LDS (nothing loop-carried in registers across the persistent loop)
+  __shared__ int s_st[4];
+  if (lane < 4) s_st[lane] = 0;
 
   __shared__ long long s_next;
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
@@ -749,7 +753,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[b * A.h_stride] * A.h_scale : 0.0;
+    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -1063,20 +1067,18 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         A.dl_out[b] = delta + bad;
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
-        ev_sum += nev;
-        acc_max = S.nacc > acc_max ? S.nacc : acc_max;
-        rej_sum += S.nrej;
-        fail_any |= S.fail;
+        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
     __syncthreads();
   }
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  if (A.stats && (ev_sum || fail_any)) {
-    atomicAdd(&A.stats[0], (int)ev_sum);
-    atomicMax(&A.stats[1], acc_max);
-    atomicAdd(&A.stats[2], rej_sum);
-    if (fail_any) atomicMax(&A.stats[3], 1);
+  __syncthreads();
+  if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
   }
 }
 
@@ -1345,7 +1347,7 @@ int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, co
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.y_in = z; a.y_out = x_out; a.stats = stats;
   return dispatch_fwd<0>(stream, n, d, a);
 }
@@ -1360,7 +1362,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
   return dispatch_fwd<1>(stream, n, d, a);
 }
@@ -1398,7 +1400,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_scale; a.h_stride = ode->walker_h_uniform ? 0 : 1; a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {
