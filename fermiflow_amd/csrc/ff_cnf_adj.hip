@@ -42,6 +42,8 @@ struct ff_adj_args {
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
+  int unit0;               // direct kernel: first hidden unit whose parameter gradient THIS launch integrates (chunks of M*MAXU
+                           // units; wider nets are served by one launch per chunk -- every launch evaluates all units for the heads)
 };
 
 // MAXU: hidden units owned per lane and net (ceil(H/M) for the widths at hand; <= ceil(FF_HMAX/M))
@@ -92,8 +94,11 @@ ff_ode_adj_kernel(ff_adj_args A) {
   // This lane's slice of the parameter-gradient row of (workgroup, group-slot): entries of its own units only,
   // so accepted steps are added with plain (non-atomic) read-modify-writes; the API zeroes the rows first.
   double* const myrow = A.rows + ((int64_t)blockIdx.x * G + (ingrp ? g : 0)) * (3 * He + 3 * Hm);
+  constexpr int UC = M * MAXU;                 // hidden units per gradient chunk
+  const int unit0 = A.unit0;
+  const int nchunks = ((He > Hm ? He : Hm) + UC - 1) / UC;
   auto row_add = [&](int t, int j, int c, double v) {
-    const int k = i + j * M, H = t ? Hm : He;
+    const int k = unit0 + i + j * M, H = t ? Hm : He;
     if (ingrp && k < H) myrow[(t ? 3 * He : 0) + c * H + k] += v;
   };
 
@@ -213,29 +218,35 @@ ff_ode_adj_kernel(ff_adj_args A) {
           for (int p = pc; p < pe; p++) {
           const double r = s_rad[gg][p], ca = s_ca[gg][p], cb = s_cb[gg][p];
           double h0 = 0.0, h1 = 0.0, h2 = 0.0;
-          // this lane's MAXU units side by side (units beyond H are masked: their weights read as zero)
-          ff_wtab w[MAXU];
-          double a[MAXU], sgv[MAXU], mk[MAXU];
+          // this lane's units, MAXU side by side (units beyond H are masked: their weights read as zero); every chunk of
+          // the net contributes to the heads, the chunk starting at unit0 also to this launch's parameter integrands
+          for (int uc = 0; uc < nchunks; uc++) {
+            const bool mine = uc * UC == unit0;
+            ff_wtab w[MAXU];
+            double a[MAXU], sgv[MAXU], mk[MAXU];
 #pragma unroll
-          for (int j = 0; j < MAXU; j++) {
-            const int k = i + j * M;
-            w[j] = s_w[t][k < FF_HMAX ? k : FF_HMAX - 1];
-            mk[j] = k < H ? 1.0 : 0.0;
-            a[j] = fma(w[j].w1, r, w[j].b1);
-          }
-          ff_sigmoid_n<MAXU, false>(a, sgv, s_e2);
+            for (int j = 0; j < MAXU; j++) {
+              const int k = uc * UC + i + j * M;
+              w[j] = s_w[t][k < FF_HMAX ? k : FF_HMAX - 1];
+              mk[j] = k < H ? 1.0 : 0.0;
+              a[j] = fma(w[j].w1, r, w[j].b1);
+            }
+            ff_sigmoid_n<MAXU, false>(a, sgv, s_e2);
 #pragma unroll
-          for (int j = 0; j < MAXU; j++) {
-            const double sg = sgv[j];
-            const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
-            const double w2 = mk[j] * w[j].w2, w2w1 = w2 * w[j].w1;
-            h0 = fma(w2, sg, h0);
-            h1 = fma(w2w1, s1, h1);
-            h2 = fma(w2w1 * w[j].w1, s2, h2);
-            const double w1rs2 = w[j].w1 * r * s2;
-            cur[t][j][0] += w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
-            cur[t][j][1] += fma(ca * w2, s1, cb * w2w1 * s2);
-            cur[t][j][2] += mk[j] * fma(ca, sg, cb * w[j].w1 * s1);
+            for (int j = 0; j < MAXU; j++) {
+              const double sg = sgv[j];
+              const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
+              const double w2 = mk[j] * w[j].w2, w2w1 = w2 * w[j].w1;
+              h0 = fma(w2, sg, h0);
+              h1 = fma(w2w1, s1, h1);
+              h2 = fma(w2w1 * w[j].w1, s2, h2);
+              if (mine) {
+                const double w1rs2 = w[j].w1 * r * s2;
+                cur[t][j][0] += w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
+                cur[t][j][1] += fma(ca * w2, s1, cb * w2w1 * s2);
+                cur[t][j][2] += mk[j] * fma(ca, sg, cb * w[j].w1 * s1);
+              }
+            }
           }
           if (ingrp) { s_ph[g][i][p - pc][0] = h0; s_ph[g][i][p - pc][1] = h1; s_ph[g][i][p - pc][2] = h2; }
           }
@@ -398,10 +409,10 @@ ff_ode_adj_kernel(ff_adj_args A) {
       const double bad = S.fail ? __builtin_nan("") : 0.0;
       if (A.gx_out) A.gx_out[b * M + i] = y[1] + bad;
       if (i == 0) {
-        if (S.fail) row_add(0, 0, 0, bad);
+        if (S.fail && unit0 == 0) row_add(0, 0, 0, bad);
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
-        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
+        if (A.stats && unit0 == 0) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
     __syncthreads();
@@ -927,15 +938,24 @@ static unsigned adj_grid(int64_t B, int G) {
   return (unsigned)(ngroups < cap ? ngroups : cap);
 }
 
+// Direct-evaluation adjoint: a lane keeps the parameter integrands of MAXU of its hidden units in registers, so one launch
+// integrates the gradient of M*MAXU units (all of the reference's default width 50 at once); wider nets (--Deta/--Dmu up to
+// FF_HMAX, src/FermionHO2D.py:24-27) take one launch per chunk of units.
 template <int N, int D>
-static void launch_adj(void* stream, const ff_adj_args& a) {
+static void launch_adj(void* stream, const ff_adj_args& a_in) {
   constexpr int M = ff_geom<N, D>::M;
-  constexpr int MU_FULL = (FF_HMAX + M - 1) / M, MU_50 = (50 + M - 1) / M;   // 50 = the reference's default width
-  const int hmax = a.net.He > a.net.Hm ? a.net.He : a.net.Hm;
-  if (MU_50 < MU_FULL && hmax <= MU_50 * M)
+  constexpr int MU_64 = (64 + M - 1) / M > 16 ? 16 : (64 + M - 1) / M, MU_50 = (50 + M - 1) / M > 16 ? 16 : (50 + M - 1) / M;
+  const int hmax = a_in.net.He > a_in.net.Hm ? a_in.net.He : a_in.net.Hm;
+  ff_adj_args a = a_in;
+  if (MU_50 < MU_64 && hmax <= MU_50 * M) {
+    a.unit0 = 0;
     FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_50>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
-  else
-    FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_FULL>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+  } else {
+    for (int u0 = 0; u0 < hmax; u0 += MU_64 * M) {
+      a.unit0 = u0;
+      FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_64>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+    }
+  }
 }
 
 extern "C" {
@@ -959,7 +979,7 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode && grad_params, FF_EINVAL, "ff_cnf_adjoint: bad argument");
   FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
            "ff_cnf_adjoint: bad net");
-  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf_adjoint: hidden width > 64");
+  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf_adjoint: hidden width > 256");
   FF_CHECK(ode->rtol > 0 && ode->atol > 0, FF_EINVAL, "ff_cnf_adjoint: tolerances must be positive");
   const int P = 3 * net->He + 3 * net->Hm;
   if (B == 0) {
@@ -985,9 +1005,10 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   // (no table / weights too stiff for the deposit grid -> direct evaluation), so the host never has to look at it
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
   FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2) else FF_ND(5, 2) else FF_ND(8, 2) else FF_ND(10, 2)
+  else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2)
 #undef FF_ND
   if (G == 0) {
-    ff_set_error("fused CNF kernels are instantiated for (n,d) in {2,3,4,5,6,8,10,12} x {2}");
+    ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2");
     return FF_EUNSUPPORTED;
   }
   FF_LAUNCH_CHECK();

@@ -1082,6 +1082,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   }
 }
 
+#include "ff_eloc_rows.h"
+#include "ff_eloc_mfma.h"
+
 // ---------------------------------------------------------------------------------------------------
 // Local-energy finish: Slater gradient/Hessian at z(t0) contracted with the sensitivities from the MODE-2 pass.
 // With g0 = grad_z logp0, H0 = Hess_z logp0:
@@ -1249,6 +1252,7 @@ extern void ff_set_error(const char* msg);
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 
 #include <stdlib.h>
+#include <string.h>
 // persistent single-wave workgroups; FF_PERSIST_BLOCKS env overrides (tuning experiments)
 static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
@@ -1289,6 +1293,28 @@ static void launch_split(void* stream, const ff_fwd_args& a) {
   FF_LAUNCH((ff_eloc_split_kernel<N, D, false>), grid, FF_WAVE, stream, a);
 }
 
+// Row-layout local-energy kernel (ff_eloc_rows.h): SPLIT lanes per row chosen so that a walker group fills the wave and
+// the workgroup's LDS stays under 40 KB (four single-wave workgroups per CU)
+template <int N, int D, int SPLIT>
+static void launch_rows(void* stream, const ff_fwd_args& a) {
+  constexpr int G = FF_WAVE / (N * D * SPLIT) > 16 ? 16 : FF_WAVE / (N * D * SPLIT);
+  int64_t ngroups = (a.B + G - 1) / G;
+  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
+  if (a.evt) FF_LAUNCH((ff_eloc_rows_kernel<N, D, SPLIT, true>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_eloc_rows_kernel<N, D, SPLIT, false>), grid, FF_WAVE, stream, a);
+}
+
+// Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12
+template <int N, int D>
+static void launch_mfma(void* stream, const ff_fwd_args& a) {
+  int64_t ngroups = (a.B + 3) / 4;
+  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
+  if (a.evt) FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false>), grid, FF_WAVE, stream, a);
+}
+
 static std::atomic<uint64_t> g_evt_counter{1};
 
 template <int MODE>
@@ -1301,6 +1327,26 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     a.evt = const_cast<double*>(a.net.radial_table) + FF_TAB_EVT0 + (id % FF_TAB_NEVT);
     a.evt_id = (double)(id & ((1ull << 52) - 1)) + 1.0;
   }
+  // Local-energy pass: three kernels compute it (tests/test_hostsim.py::test_three_local_energy_kernels_agree);
+  // FF_ELOC_KERNEL = auto (default) | mfma | rows | columns forces one where it is instantiated.  auto takes the fastest
+  // measured on MI355X (tools/probes/eloc_ab.py): the column sweep up to 8 particles, the row layout from 9 on (and for
+  // every particle number the column sweep is not instantiated for).
+  static const int eloc_kind = [] {
+    const char* e = getenv("FF_ELOC_KERNEL");
+    return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : 0)));
+  }();
+  if (MODE == 2 && eloc_kind == 1) {
+#define FF_MF(N_, D_) if (n == N_ && d == D_) { launch_mfma<N_, D_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+    FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)
+#undef FF_MF
+  }
+  const bool no_columns = n == 1 || n == 7 || n == 9 || n == 11;
+  if (MODE == 2 && (eloc_kind == 2 || no_columns || (eloc_kind == 0 && n >= 9))) {
+#define FF_RW(N_, D_, S_) if (n == N_ && d == D_) { launch_rows<N_, D_, S_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+    FF_RW(6, 2, 1) FF_RW(2, 2, 1) FF_RW(3, 2, 1) FF_RW(4, 2, 1) FF_RW(5, 2, 1) FF_RW(7, 2, 2) FF_RW(8, 2, 2) FF_RW(9, 2, 3)
+    FF_RW(10, 2, 3) FF_RW(11, 2, 2) FF_RW(12, 2, 2) FF_RW(1, 2, 1)
+#undef FF_RW
+  }
   if (MODE == 2 && d == 2 && !getenv("FF_NO_SPLIT")) {
 #define FF_SP(N_) if (n == N_) { launch_split<N_, 2>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_SP(8) FF_SP(10) FF_SP(12)
@@ -1308,8 +1354,9 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   }
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
   FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
+  if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) }   // (their local-energy pass is the row-layout kernel above)
 #undef FF_ND
-  ff_set_error("fused CNF kernels are instantiated for (n,d) in {2,3,4,5,6,8,10,12} x {2}");
+  ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2");
   return FF_EUNSUPPORTED;
 }
 
@@ -1317,7 +1364,7 @@ static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode
   FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode, FF_EINVAL, "ff_cnf: bad argument");
   FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
            "ff_cnf: bad net");
-  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf: hidden width > 64");
+  FF_CHECK(net->He <= FF_HMAX && net->Hm <= FF_HMAX, FF_EUNSUPPORTED, "ff_cnf: hidden width > 256");
   FF_CHECK(ode->rtol > 0 && ode->atol > 0, FF_EINVAL, "ff_cnf: tolerances must be positive");
   return FF_OK;
 }

@@ -16,7 +16,7 @@
 #define FF_WAVE 64
 #define FF_MAX_ORB 36      // HO2D().orbitals has 36 entries (src/orbitals.py:81)
 #define FF_MAX_NS 12       // largest single-spin determinant handled natively
-#define FF_HMAX 64         // hidden width supported by the fused ODE kernels (reference default: 50)
+#define FF_HMAX 256        // hidden width supported by the fused ODE kernels (reference default: 50; --Deta/--Dmu, src/FermionHO2D.py:24-27)
 #define FF_HPAD (FF_HMAX + 8)  // LDS weight table length: zero-padded so unrolled unit loops may overrun H
 
 #ifdef FF_HOSTSIM
@@ -42,6 +42,15 @@
 #define FF_RBLOCK(n) 4
 #else
 #define FF_RBLOCK(n) (n)
+#endif
+
+// An integer the compiler must treat as freshly computed here: blocks the hoisting of everything derived from it (LDS
+// addresses, decoded indices) out of the enclosing loop.  hipcc otherwise precomputes dozens of loop-invariant addresses
+// in the prologue of the fused ODE kernels and spills them -- recomputing them costs one or two integer ops each.
+#ifdef FF_HOSTSIM
+#define FF_OPAQUE(x) asm volatile("" : "+r"(x))
+#else
+#define FF_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
 #define FF_D __device__ __forceinline__
@@ -89,6 +98,40 @@ FF_D double ff_swap1(double v) {
   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
+#endif
+}
+
+// value held by lane ^ 2 of the same quad (DPP quad_perm [2,3,0,1])
+FF_D double ff_swap2(double v) {
+#ifdef FF_HOSTSIM
+  return ff_sim_lane_xor(v, 2);
+#else
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+#endif
+}
+
+// value of v on lane src (any lane of the wave; two ds_bpermute_b32: the LDS crossbar, no LDS memory)
+FF_D double ff_lane_read(double v, int src) {
+#ifdef FF_HOSTSIM
+  return ff_sim_lane_read(v, src);
+#else
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+#endif
+}
+
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per wave, D = A B + C, one f64 per lane and operand.
+// Lane l = 16 k + 4 blk + i supplies A_blk[i][k]; lane 16 k + 4 blk + j supplies B_blk[k][j]; lane 16 i + 4 blk + j holds
+// C/D_blk[i][j] (measured on gfx950: tools/probes/mfma_f64.hip) -- the block is (l / 4) % 4, NOT l / 16.
+FF_D double ff_mfma4(double a, double b, double c) {
+#ifdef FF_HOSTSIM
+  return ff_sim_mfma4(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 #endif
 }
 

@@ -16,7 +16,7 @@
 template <int N, int D>
 struct ff_geom {
   static constexpr int M = N * D;          // coordinates per walker
-  static constexpr int G = FF_WAVE / M;    // walkers per wave
+  static constexpr int G = FF_WAVE / M > 16 ? 16 : FF_WAVE / M;    // walkers per wave (at most 16: the radius ids carry 4 bits of it)
   static constexpr int P = N * (N - 1) / 2;  // electron pairs
   static constexpr int R = P + N;          // radii per walker: pairs then one-body
   static constexpr int RA = R > 0 ? R : 1;

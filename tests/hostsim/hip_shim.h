@@ -70,6 +70,27 @@ inline double ff_sim_swap1(double v) {
   return o;
 }
 
+// generic cross-lane reads and the fp64 4x4x4 (four blocks) matrix instruction, same mechanism; every lane must call them
+inline double ff_sim_lane_read(double v, int src) {
+  ff_sim_swap_buf[threadIdx.x] = v;
+  __syncthreads();
+  const double o = ff_sim_swap_buf[src & 63];
+  __syncthreads();
+  return o;
+}
+inline double ff_sim_lane_xor(double v, int m) { return ff_sim_lane_read(v, (int)threadIdx.x ^ m); }
+static double ff_sim_mfma_a[64], ff_sim_mfma_b[64];
+inline double ff_sim_mfma4(double a, double b, double c) {
+  const int l = threadIdx.x;
+  ff_sim_mfma_a[l] = a; ff_sim_mfma_b[l] = b;
+  __syncthreads();
+  const int i = l / 16, blk = (l / 4) % 4, j = l % 4;   // this lane holds D_blk[i][j]
+  double acc = c;
+  for (int k = 0; k < 4; k++) acc = __builtin_fma(ff_sim_mfma_a[16 * k + 4 * blk + i], ff_sim_mfma_b[16 * k + 4 * blk + j], acc);
+  __syncthreads();
+  return acc;
+}
+
 template <class K, class... A>
 inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   pthread_barrier_t bar;

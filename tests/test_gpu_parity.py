@@ -426,9 +426,9 @@ def test_config4_six_plus_six(golden, dev):
     np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
 
 
-@pytest.mark.parametrize("nup,ndn", [(2, 0), (2, 2), (5, 0), (4, 4), (10, 0)])
+@pytest.mark.parametrize("nup,ndn", [(2, 0), (2, 2), (5, 0), (4, 4), (10, 0), (1, 0), (4, 3), (5, 4), (6, 5)])
 def test_other_particle_numbers_vs_oracle(golden, dev, nup, ndn):
-    """every fused-kernel instantiation (n in {2,3,4,5,6,8,10,12}): flow, local energy and adjoint vs the oracle."""
+    """every particle number 1..12 has fused kernels (odd n: row-layout local-energy kernel): flow, local energy and adjoint vs the oracle."""
     import __graft_entry__ as Gm
     from fermiflow_amd import native
     G = golden["g5_gsvmc"]

@@ -48,7 +48,9 @@ def test_abi_argument_errors_without_gpu():
     net = _lib.FFNet(50, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, None, None, None)
     ode = _lib.FFOde(0.0, 1.0, 1e-6, 1e-8, 0)
     # (n, d) without a fused instantiation -> 2; negative tolerance -> 1
-    assert lib.ff_cnf_generate(None, C.c_int64(4), 7, 2, C.byref(net), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
+    assert lib.ff_cnf_generate(None, C.c_int64(4), 13, 2, C.byref(net), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
+    wide = _lib.FFNet(300, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, None, None, None)      # hidden width > 256
+    assert lib.ff_cnf_generate(None, C.c_int64(4), 6, 2, C.byref(wide), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
     bad = _lib.FFOde(0.0, 1.0, -1.0, 1e-8, 0)
     assert lib.ff_cnf_generate(None, C.c_int64(4), 6, 2, C.byref(net), C.byref(bad), C.c_void_p(8), C.c_void_p(8), None) == 1
 
