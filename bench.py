@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: walker-steps/s of one full VMC training iteration.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W            (N > 1: this script starts the N ranks itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (what the driver runs)
 
 A "step" is one complete iteration of the reference training loop (src/FermionHO2D.py:66-72):
     gradE = model(batch); optimizer.zero_grad(); gradE.backward(); optimizer.step()
 i.e. 100 Metropolis walker-steps per walker + CNF.generate + local energy + E/E_std + parameter gradient
-(adjoint) + Adam.  Workload = BASELINE.json configs[1]: nup = ndown = 3, 2-D, Z = 2.0, H = 50, fp64,
-65 536 walkers PER GPU (weak scaling: walkers shard with no data-path collective, only the three tiny
-estimator all-reduces of fermiflow_amd/dist.py).  value = n_gpus * 65536 * 100 * K / time.
+(adjoint) + Adam.  Default workload = BASELINE.json configs[1]: nup = ndown = 3, 2-D, Z = 2.0, H = 50, fp64,
+65 536 walkers PER GPU (weak scaling: walkers shard with no data-path collective, only the two tiny
+estimator all-reduces of fermiflow_amd/dist.py).  value = n_gpus * walkers * 100 * K / time.
+  --workload beta   BASELINE.json configs[2]: BetaFermionHO2D beta = 10, nup = 3, boltzmann, 65 536 walkers
+  --workload n12    BASELINE.json configs[3]: nup = ndown = 6, 32 768 walkers per GPU
+(parity-test cases; their lines are kept under profiles/, the driver's line is the default workload).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the fused local-energy integration,
-fp64-VALU bound; its algorithmic flops are stated in DESIGN.md), `roofline_hbm` for the one HBM-bound
-kernel of the path (parity-mode Metropolis sweep), `stages` (ms per stage), `cpu_baseline` (the C oracle
-timed on the host cores on a bounded sample; rank 0, N = 1 only).
+Extra objects on the JSON line (rank 0, N = 1): `roofline` for the dominant kernel (the fused local-energy
+integration) with its live HIP-event time, its algorithmic flops and -- from two rocprofv3 --pmc child
+passes of this very script -- its HBM traffic; `roofline_adjoint`, `roofline_mcmc` for the other two kernels above
+10 % of a step; `roofline_hbm` (parity-mode Metropolis sweep: the HBM-bound kernel of the path), `roofline_pairwise`
+(stand-alone potential / backflow kernels); `stages_ms`; `cpu_baseline` (the C oracle on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -25,13 +29,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per RHS evaluation of one walker in the local-energy kernel ("Kernels"):
+# algorithmic work per RHS evaluation of one walker (counted from the sources, FMA = 2 flop):
 FLOP_PER_SIGMOID_UNIT = 30      # 1 exp + 1 rcp + ~8 FMA-class ops      (FERMIFLOW_RADIAL=exact)
 FLOP_PER_TABLE_RADIUS = 60      # 4 heads x 5 Horner FMAs + index/offset arithmetic     (FERMIFLOW_RADIAL=table, default)
 FLOP_PER_RADIUS_RECORD = 55     # r, 1/r, the direction-independent record and the own-row contributions of one radius
-FLOP_PER_PAIR_TERM = 44         # counted from the jet sweep: one (direction, pair) term (FMA = 2); was 55 before the
-FLOP_PER_ONEBODY_TERM = 40      # radius records took the direction-independent part out of the sweep (profiles r01_a..g)
+FLOP_PER_PAIR_TERM = 44         # column sweep: one (direction, pair) term of the second-order jet
+FLOP_PER_ONEBODY_TERM = 40
 FLOP_PER_LANE_GATHER = 30       # own rows (18 adds) + transposition sum (12 adds)
+FLOP_PER_RADIUS_S = 70          # row-layout / matrix-core kernels: W from S, second-order sources of one radius
+FLOP_ADJ_RADIUS = 85            # tabulated adjoint: 45 heads + 40 record and own rows per radius
+FLOP_ADJ_LANE = 18              # own-row gather per coordinate
+FLOP_MCMC_STEP_PER_PARTICLE = 50    # proposal, Hermite recurrences, one row of the determinant update, accept (per particle of a walker-step)
 PEAK_FP64_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (vendor)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
@@ -57,19 +65,81 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def eloc_kernel_name(n):
+    """The local-energy kernel the dispatcher picks (csrc/ff_cnf_fwd.hip, dispatch_fwd)."""
+    kind = os.environ.get("FF_ELOC_KERNEL", "auto")
+    if kind == "mfma" and n <= 6:
+        return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 1>"
+    split = {7: 2, 8: 2, 9: 3, 10: 3, 11: 2, 12: 2}.get(n, 1)
+    if kind == "rows" or n in (1, 7, 9, 11) or (kind in ("auto", "mfma") and n >= 9):
+        return "rows", f"ff_eloc_rows_kernel<{n}, 2, {split}, true, 1>"
+    if n in (8, 10, 12):
+        return "columns", f"ff_eloc_split_kernel<{n}, 2, true>"
+    return "columns", f"ff_ode_fwd_kernel<{n}, 2, 2, true>"
+
+
+def eloc_flop_per_eval(kind, n, H, radial):
+    M, P = 2 * n, n * (n - 1) // 2
+    R = P + n
+    heads = H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else FLOP_PER_TABLE_RADIUS
+    if kind == "columns":
+        return R * (heads + FLOP_PER_RADIUS_RECORD) + M * (P * FLOP_PER_PAIR_TERM + n * FLOP_PER_ONEBODY_TERM) + M * FLOP_PER_LANE_GATHER
+    # rows / mfma: two dense M x M x M products (J' = A J and S = J J^T) + per-radius work
+    return 2 * 2 * M * M * M + R * (heads + FLOP_PER_RADIUS_RECORD + FLOP_PER_RADIUS_S) + M * FLOP_PER_LANE_GATHER
+
+
+def pmc_traffic(kernel_substr, argv):
+    """HBM bytes per launch of one kernel from two `rocprofv3 --pmc` child passes (FETCH_SIZE and WRITE_SIZE do not fit
+    one pass; FETCH_SIZE is doubled on gfx950 -- MI355X_MICROARCH.md, HBM).  The profiled program is this script with
+    --steps 2 --no-extras.  Returns (bytes, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ffpmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + \
+              ["--steps", "2", "--warmup", "1", "--no-extras"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        except Exception as e:      # noqa: BLE001
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 pass failed: {type(e).__name__}"
+        tot, cnt = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    tot += float(row["Counter_Value"]); cnt += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if cnt == 0:
+            return None, f"kernel {kernel_substr} not in the {ctr} pass"
+        out[ctr] = tot / cnt
+    nbytes = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+    return nbytes, {"FETCH_SIZE_KB": out["FETCH_SIZE"], "WRITE_SIZE_KB": out["WRITE_SIZE"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--walkers-per-gpu", type=int, default=65536)
-    ap.add_argument("--nup", type=int, default=3)
-    ap.add_argument("--ndown", type=int, default=3)
+    ap.add_argument("--workload", choices=["gsvmc", "beta", "n12"], default="gsvmc")
+    ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12)")
+    ap.add_argument("--nup", type=int, default=0)
+    ap.add_argument("--ndown", type=int, default=-1)
     ap.add_argument("--Z", type=float, default=2.0)
     ap.add_argument("--lr", type=float, default=2e-5,
-                    help="Adam step; small so the synthetic weights (hence the ODE step counts) stay put over the run")
+                    help="Adam step; small so the synthetic weights (hence the ODE step counts) stay put over the run "
+                         "(the reference's 1e-2 from these weights changes eta by 250 %% per step; --lr 1e-2 runs it)")
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the HBM-kernel and CPU-baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone kernel legs, the PMC passes and the CPU baseline")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -80,7 +150,9 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as G
+    import fermiflow_amd as ff
     from fermiflow_amd import native
+    from fermiflow_amd import _lib as L
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,15 +180,29 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
-    model = G._model(dev, args.nup, args.ndown, args.Z)
+    wl = args.workload
+    nup = args.nup or {"gsvmc": 3, "beta": 3, "n12": 6}[wl]
+    ndown = args.ndown if args.ndown >= 0 else {"gsvmc": 3, "beta": 0, "n12": 6}[wl]
+    wpg = args.walkers_per_gpu or {"gsvmc": 65536, "beta": 65536, "n12": 32768}[wl]
+    n = nup + ndown
+    gs = G._model(dev, nup, ndown, args.Z)
+    if wl == "beta":
+        model = ff.BetaVMC(10.0, nup, ndown, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), gs.cnf,
+                           ff.CoulombPairPotential(args.Z), sp_potential=ff.HO())
+        model.to(dev)
+    else:
+        model = gs
     opt = torch.optim.Adam(model.parameters(), lr=args.lr)
-    B_glob = args.walkers_per_gpu * n_gpus
+    B_glob = wpg * n_gpus
     torch.manual_seed(1234)      # same Philox key on every rank; streams are separated by the global walker index
 
     def step():
-        gradE = model(B_glob)
+        g = model(B_glob)
         opt.zero_grad()
-        gradE.backward()
+        if wl == "beta":
+            g[0].backward(); g[1].backward()
+        else:
+            g.backward()
         opt.step()
 
     def fence():
@@ -149,61 +235,36 @@ def main():
     stages = {k: v / args.steps for k, v in stages.items()}
     k_ms = sum(a.elapsed_time(b) for a, b in prof["pass1"]) / args.steps
     evals = sum(int(s[0].item()) for s in prof["eloc_stats"]) / args.steps          # RHS evaluations summed over walkers
-    n = args.nup + args.ndown
     M, R, H = 2 * n, n * (n - 1) // 2 + n, 50
-    from fermiflow_amd import _lib as L
     radial = L.RADIAL_MODE
-    P = n * (n - 1) // 2
-    flop_per_eval = (R * ((H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else FLOP_PER_TABLE_RADIUS) + FLOP_PER_RADIUS_RECORD)
-                     + M * (P * FLOP_PER_PAIR_TERM + n * FLOP_PER_ONEBODY_TERM) + M * FLOP_PER_LANE_GATHER)
+    kind, kname = eloc_kernel_name(n)
+    flop_per_eval = eloc_flop_per_eval(kind, n, H, radial)
     achieved = evals * flop_per_eval / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "ff_ode_fwd_kernel<%d,2,2,%s> (local-energy sensitivities)" % (n, "true" if radial == "table" else "false"), "bound": "mfma",
-                "note": "fp64 VALU-bound; on MI355X the fp64 vector and fp64 MFMA peaks coincide (78.6 TFLOP/s); "
-                        "MFMA is not used: the MLP is 1->50->1 (no dense GEMM)",
+    roofline = {"kernel": kname + " (local-energy sensitivities)",
+                "bound": "mfma" if kind == "mfma" else "fp64-valu",
+                "note": ("runs on v_mfma_f64_4x4x4 + fp64 VALU" if kind == "mfma" else
+                         "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
+                         "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
+                        "; peak = MI355X fp64 vector = fp64 matrix peak",
                 "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / args.walkers_per_gpu,
-                "flop_per_walker_eval": flop_per_eval, "radial_functions": radial}
-
-    # HBM bytes of the dominant kernel: not measurable live; taken from the committed rocprofv3 PMC pass
-    # (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), profiles/r01_k_hbm_traffic.json
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")))
-        key = [k for k in tj if "ff_ode_fwd_kernel<%d, 2, 2, true>" % n in k]
-        if key and radial == "table" and args.walkers_per_gpu == 65536:
-            roofline["traffic"] = tj[key[0]]["hbm_bytes_fetchx2_plus_write"]
-            roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_k_hbm_traffic.json), bytes per launch"
-            roofline["algorithmic_bytes"] = args.walkers_per_gpu * 8 * (M + M * M + 4 * M + 1)
-    except Exception:
-        pass
+                "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / wpg,
+                "flop_per_walker_eval": flop_per_eval, "radial_functions": radial,
+                "algorithmic_bytes": wpg * 8 * (M + M * M + 4 * M + 1)}
 
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",
            "value": B_glob * 100 * args.steps / dt, "unit": "walker-steps/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"GSVMC nup={args.nup} ndown={args.ndown} 2D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8, "
-                                  f"{args.walkers_per_gpu} walkers/GPU, 100 Metropolis steps/iter, seeded gaussian weights x(30,300)",
+           "config": {"workload": ("BetaVMC beta=10 boltzmann deltaE=2 " if wl == "beta" else "GSVMC ") +
+                                  f"nup={nup} ndown={ndown} 2D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8, "
+                                  f"{wpg} walkers/GPU, 100 Metropolis steps/iter, seeded gaussian weights x(30,300), Adam lr={args.lr}",
                       "global_walkers": B_glob, "parallelism": f"walker-dp{n_gpus}"},
            "E": model.E, "E_std": model.E_std, "stages_ms": stages, "roofline": roofline}
+    if wl == "beta":
+        out.update(F=model.F, F_std=model.F_std, S=model.S)
 
-    if rank == 0 and not args.no_extras:
-        # ---- the HBM-bound kernel of the path: parity-mode Metropolis sweep (noise streamed from HBM)
-        Bm, S = args.walkers_per_gpu, 100
-        g0, g, u = native.rng_fill(Bm, n, S, 7, dev)
-        tu, td = model._tables(dev)
-        native.mcmc_sample_noise(tu, td, args.nup, args.ndown, g0, g, u)
+    if rank == 0 and n_gpus == 1 and not args.no_extras:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            native.mcmc_sample_noise(tu, td, args.nup, args.ndown, g0, g, u)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        nbytes = Bm * S * (8 * M + 8 + 1) + Bm * (2 * 8 * M + 8)     # noise + uniforms + accept mask; init + final x, logp
-        del g0, g, u
-        # ---- the stand-alone pairwise kernels (potentials.py / equivariant_funs.py entry points; inside the sweep these
-        #      terms are fused into the ODE kernels): Coulomb + trap energy is HBM-bound, backflow v + div is fp64-bound
-        Bp = 16 * args.walkers_per_gpu
-        xp = torch.randn(Bp, n, 2, dtype=torch.float64, device=dev)
 
         def timed(fn, reps=5):
             fn(); e0.record()
@@ -211,40 +272,95 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
-        ms_p = timed(lambda: native.potential(xp, args.Z, True))
-        netp = model.cnf.v_wrapper.v.net(radial="exact")
-        xb = xp[: args.walkers_per_gpu]
-        ms_b = timed(lambda: native.backflow_v_div(netp, xb))
-        bytes_p = Bp * (8 * M + 8)
-        flop_b = args.walkers_per_gpu * R * (H * FLOP_PER_SIGMOID_UNIT + 20)
-        out["roofline_pairwise"] = {
-            "potential": {"kernel": "ff_potential_stream_kernel (HO + Coulomb pairs)", "bound": "hbm", "walkers": Bp, "avg_launch_ms": ms_p,
-                          "achieved": bytes_p / (ms_p * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": bytes_p / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            "backflow": {"kernel": "ff_backflow_kernel (v and div v, direct sigmoids)", "bound": "mfma", "walkers": args.walkers_per_gpu,
-                         "avg_launch_ms": ms_b, "achieved": flop_b / (ms_b * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flop_b / (ms_b * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
-                         "note": "fp64 VALU (exp/rcp chains); no MFMA: 1->H->1 layers"}}
-        del xp
-        out["roofline_hbm"] = {"kernel": (f"ff_mcmc_spin_kernel<{args.nup},noise>" if args.nup == args.ndown and 1 <= args.nup <= 6 else f"ff_mcmc_kernel<{args.nup},{args.ndown},noise>"), "bound": "hbm",
-                               "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
-                               "walker_steps_per_s": Bm * S / (ms * 1e-3)}
+        v = gs.cnf.v_wrapper.v
+        net = v.net()
+        tu, td = (model._state_tables(dev) if wl == "beta" else model._tables(dev))
+        ws = model._ws if wl == "beta" else None
+        # ---- the adjoint and the production Metropolis kernel stand-alone, on the last sweep's walkers
+        with torch.no_grad():
+            z0 = native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws)[0]
+            ms_mc = timed(lambda: native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws))
+            hg = torch.empty(wpg, dtype=torch.float64, device=dev); he = torch.empty_like(hg)
+            x = native.cnf_generate(net, z0, 0.0, 1.0, 1e-6, 1e-8, walker_h_out=hg)
+            r = native.eloc(tu, td, nup, ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, args.Z, True, walker_state=ws,
+                            walker_h_init=hg, walker_h_scale=model._h_scale_eloc, walker_h_out=he)
+            w = (r["eloc"] - r["eloc"].mean()) / wpg
+            az, ad = w[:, None, None] * r["glogp0"], -w
+            st = native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False, want_stats=True,
+                                    walker_h_init=he, walker_h_scale=1.25)[2]
+            adj_evals = int(st[0].item())
+            ms_adj = timed(lambda: native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False,
+                                                      walker_h_init=he, walker_h_scale=1.25))
+        flop_adj = R * FLOP_ADJ_RADIUS + M * FLOP_ADJ_LANE
+        a_adj = adj_evals * flop_adj / (ms_adj * 1e-3) / 1e12
+        out["roofline_adjoint"] = {
+            "kernel": f"ff_ode_adjtab_kernel<{n}, 2> + deposit reduce/contract (theta-gradient adjoint, whole ff_cnf_adjoint call)",
+            "bound": "fp64-valu", "achieved": a_adj, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_adj / PEAK_FP64_TFLOPS,
+            "avg_launch_ms": ms_adj, "rhs_evals_per_walker": adj_evals / wpg, "flop_per_walker_eval": flop_adj,
+            "note": "instruction-issue and LDS-atomic bound: per accepted step 5 records per radius go into the deposit table"}
+        flop_mc = n * FLOP_MCMC_STEP_PER_PARTICLE
+        a_mc = wpg * 100 * flop_mc / (ms_mc * 1e-3) / 1e12
+        out["roofline_mcmc"] = {
+            "kernel": (f"ff_mcmc_spin_kernel<{nup}, false>" if nup == ndown and 1 <= nup <= 6 and wl != "beta" else f"ff_mcmc_kernel<{nup}, {ndown}, false>") +
+                      " (Philox + Box-Muller on chip, the production sampler)",
+            "bound": "fp64-valu", "achieved": a_mc, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_mc / PEAK_FP64_TFLOPS,
+            "avg_launch_ms": ms_mc, "walker_steps_per_s": wpg * 100 / (ms_mc * 1e-3), "flop_per_walker_step": flop_mc,
+            "hbm_bytes_per_walker": 2 * (8 * M + 8),
+            "note": "instruction-issue bound (integer Philox rounds, log / sincos of Box-Muller, serial LU chain); HBM sees 208 B per "
+                    "walker per SWEEP, i.e. nothing"}
+        if wl == "gsvmc":
+            # ---- the HBM-bound kernel of the path: parity-mode Metropolis sweep (noise streamed from HBM)
+            S = 100
+            g0, g, u = native.rng_fill(wpg, n, S, 7, dev)
+            ms = timed(lambda: native.mcmc_sample_noise(tu, td, nup, ndown, g0, g, u))
+            nbytes = wpg * S * (8 * M + 8 + 1) + wpg * (2 * 8 * M + 8)     # noise + uniforms + accept mask; init + final x, logp
+            del g0, g, u
+            out["roofline_hbm"] = {"kernel": (f"ff_mcmc_spin_kernel<{nup}, true>" if nup == ndown and 1 <= nup <= 6 else f"ff_mcmc_kernel<{nup}, {ndown}, true>") + " (parity mode: explicit noise)",
+                                   "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
+                                   "walker_steps_per_s": wpg * S / (ms * 1e-3)}
+            # ---- the stand-alone pairwise kernels (potentials.py / equivariant_funs.py entry points; inside the sweep these
+            #      terms are fused into the ODE kernels): Coulomb + trap energy is HBM-bound, backflow v + div is fp64-bound
+            Bp = 16 * wpg
+            xp = torch.randn(Bp, n, 2, dtype=torch.float64, device=dev)
+            ms_p = timed(lambda: native.potential(xp, args.Z, True))
+            netp = v.net(radial="exact")
+            xb = xp[:wpg]
+            ms_b = timed(lambda: native.backflow_v_div(netp, xb))
+            bytes_p = Bp * (8 * M + 8)
+            flop_b = wpg * R * (H * FLOP_PER_SIGMOID_UNIT + 20)
+            out["roofline_pairwise"] = {
+                "potential": {"kernel": "ff_potential_stream_kernel (HO + Coulomb pairs)", "bound": "hbm", "walkers": Bp, "avg_launch_ms": ms_p,
+                              "achieved": bytes_p / (ms_p * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": bytes_p / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                "backflow": {"kernel": "ff_backflow_kernel (v and div v, direct sigmoids)", "bound": "fp64-valu", "walkers": wpg,
+                             "avg_launch_ms": ms_b, "achieved": flop_b / (ms_b * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flop_b / (ms_b * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                             "note": "fp64 VALU (exp/rcp chains); no MFMA: 1->H->1 layers"}}
+            del xp
+        # ---- HBM traffic of the dominant kernel, measured now: two rocprofv3 --pmc child passes of this script
+        if not args.no_pmc and os.environ.get("FF_BENCH_CHILD") != "1":
+            os.environ["FF_BENCH_CHILD"] = "1"
+            argv = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--lr", str(args.lr)]
+            nb, detail = pmc_traffic(kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0], argv)
+            roofline["traffic"] = nb
+            roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run, bytes per launch = "
+                                          "2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), " + json.dumps(detail)) if nb else f"unavailable: {detail}"
         # ---- CPU baseline: the oracle's full sweep on the host cores, bounded sample
-        if n_gpus == 1 and args.cpu_walkers > 0:
+        if args.cpu_walkers > 0 and wl != "beta":
             from oracle import oracle as O
-            v = model.cnf.v_wrapper.v
-            net = O.Net(tuple(t.detach().cpu().numpy() for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
-                        tuple(t.detach().cpu().numpy() for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
-            O.gsvmc_sweep(64, args.nup, args.ndown, net, args.Z, seed=1)      # thread-pool warm-up
+            onet = O.Net(tuple(t.detach().cpu().numpy() for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
+                         tuple(t.detach().cpu().numpy() for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+            ncpu = args.cpu_walkers if wl == "gsvmc" else max(256, args.cpu_walkers // 8)
+            O.gsvmc_sweep(64, nup, ndown, onet, args.Z, seed=1)      # thread-pool warm-up
             t1 = time.perf_counter()
-            r = O.gsvmc_sweep(args.cpu_walkers, args.nup, args.ndown, net, args.Z, seed=2)
+            rr = O.gsvmc_sweep(ncpu, nup, ndown, onet, args.Z, seed=2)
             ct = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": args.cpu_walkers * 100 / ct, "unit": "walker-steps/s", "cores": O.num_threads(),
+            out["cpu_baseline"] = {"value": ncpu * 100 / ct, "unit": "walker-steps/s", "cores": O.num_threads(),
                                    "kind": "port",
-                                   "sample": f"one full iteration (same stages, minus Adam) of {args.cpu_walkers} walkers, "
-                                             f"oracle/ff_oracle.c with OpenMP, {ct:.1f} s", "E": r["E"], "E_std": r["E_std"],
-                                   "stage_seconds": r["seconds"]}
+                                   "sample": f"one full iteration (same stages, minus Adam) of {ncpu} walkers, "
+                                             f"oracle/ff_oracle.c with OpenMP, {ct:.1f} s", "E": rr["E"], "E_std": rr["E_std"],
+                                   "stage_seconds": rr["seconds"]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
