@@ -398,9 +398,7 @@ class BetaVMC(_Sweep, torch.nn.Module):
             # one all-reduce: moments of E_loc and F_loc about the previous sweep's means + per-state (sum E_loc, count)
             shE, momE = self._moments(Eloc, "E", nglob)
             shF, momF = self._moments(Floc, "F", nglob)
-            stat = torch.zeros(2, Ns, dtype=torch.float64, device=device)
-            stat[0].index_add_(0, state_indices, Eloc)
-            stat[1].index_add_(0, state_indices, torch.ones_like(Eloc))
+            stat = native.state_sums(Eloc, ws, Ns)       # per-state (sum E_loc, count): segments of the sorted state list
             buf1 = torch.cat([momE, momF, stat.reshape(-1)])
             D.all_reduce_sum_(buf1)
             self._set_moments("E", shE, buf1[0:2], nglob)

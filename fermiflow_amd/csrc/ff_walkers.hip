@@ -560,6 +560,34 @@ ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, co
   if (t == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
+// Per-state sums of the finite-temperature estimator (src/VMC.py:164-169: the per-state baseline of gradF_theta, and the
+// state counts behind S and gradF_phi).  walker_state is sorted (src/VMC.py:94-96), so state s is one contiguous segment:
+// one workgroup per state finds its bounds by bisection and sums the segment with a fixed tree -- deterministic, and no
+// atomics (at beta = 10 every walker sits in state 0: 65536 atomic adds on one address took 6 ms).
+__global__ void __launch_bounds__(256)
+ff_state_sums_kernel(int64_t B, const int* __restrict__ ws, const double* __restrict__ e, double* __restrict__ sums,
+                     double* __restrict__ counts) {
+  __shared__ double sm[256];
+  const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  auto lower = [&](int key) -> int64_t {   // first index with ws[i] >= key
+    int64_t lo = 0, hi = B;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ws[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int64_t b0 = lower(s), b1 = lower(s + 1);
+  double a = 0.0;
+  for (int64_t i = b0 + t; i < b1; i += nt) a += e[i];
+  sm[t] = a;
+  __syncthreads();
+  int w = 1;
+  while (w * 2 < nt) w *= 2;
+  for (; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) sm[t] += sm[t + w];
+    __syncthreads();
+  }
+  if (t == 0) { sums[s] = sm[0]; counts[s] = (double)(b1 - b0); }
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -820,6 +848,13 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
                       double* out2) {
   FF_CHECK(B > 0 && e && out2, FF_EINVAL, "ff_reduce_moments: bad argument");
   FF_LAUNCH(ff_moments_kernel, 1, FF_RBLOCK(1024), stream, B, e, shift, shift_dev, shift_dev_scale, out2);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_state_sums(void* stream, int64_t B, int nstates, const int32_t* walker_state, const double* e, double* sums, double* counts) {
+  FF_CHECK(B >= 0 && nstates > 0 && sums && counts && (B == 0 || (walker_state && e)), FF_EINVAL, "ff_state_sums: bad argument");
+  FF_LAUNCH(ff_state_sums_kernel, (unsigned)nstates, FF_RBLOCK(256), stream, B, walker_state, e, sums, counts);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -225,3 +225,12 @@ def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0):
     L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(shift_dev),
                                       L.f64(shift_dev_scale), L.ptr(out)), "ff_reduce_moments")
     return out
+
+
+def state_sums(e, walker_state, nstates):
+    """ff_state_sums: tensor [2, nstates] = (per-state sums of e, per-state walker counts); walker_state sorted int32."""
+    e = L.dev(e, name="e"); ws = L.dev(walker_state, torch.int32, "walker_state")
+    out = torch.empty(2, nstates, dtype=torch.float64, device=e.device)
+    L.check(L.lib().ff_state_sums(L.stream(), L.i64(e.numel()), int(nstates), L.ptr(ws), L.ptr(e), L.ptr(out[0]), L.ptr(out[1])),
+            "ff_state_sums")
+    return out

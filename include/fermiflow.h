@@ -182,6 +182,11 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
 int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev,
                       double shift_dev_scale, double* out2);
 
+/* Per-state sums of the finite-temperature estimator (src/VMC.py:155-169): walker_state (int32 [B]) must be SORTED
+ * (src/VMC.py:94-96); sums[s] = sum of e[b] over the walkers in state s, counts[s] = their number (as doubles, ready for
+ * an all-reduce).  One workgroup per state, fixed summation tree: deterministic. */
+int ff_state_sums(void* stream, int64_t B, int nstates, const int32_t* walker_state, const double* e, double* sums, double* counts);
+
 #ifdef __cplusplus
 }
 #endif

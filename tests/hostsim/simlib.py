@@ -220,3 +220,9 @@ def moments(e, shift=0.0):
     e = _d(e); out = np.empty(2)
     _ck(lib().ff_reduce_moments(None, C.c_int64(len(e)), _p(e), C.c_double(shift), None, C.c_double(1.0), _p(out)))
     return out
+
+
+def state_sums(e, ws, nstates):
+    e = _d(e); ws = _i(ws); sums = np.empty(nstates); cnt = np.empty(nstates)
+    _ck(lib().ff_state_sums(None, C.c_int64(len(e)), int(nstates), _p(ws), _p(e), _p(sums), _p(cnt)))
+    return sums, cnt

@@ -355,3 +355,16 @@ def test_three_local_energy_kernels_agree(golden, kind, monkeypatch):
     assert st[3] == 0
     np.testing.assert_allclose(el, G["z2_nt_Eloc"][:7], rtol=1e-8)
     np.testing.assert_allclose(lap, G["z2_nt_lap"][:7], rtol=1e-7, atol=1e-6)
+
+
+def test_state_sums_of_the_finite_temperature_estimator():
+    """ff_state_sums: per-state sums over the sorted state list (src/VMC.py:164-169), including empty states and the
+    everything-in-state-0 case of beta = 10."""
+    rng = np.random.default_rng(0)
+    for ws in (np.sort(rng.integers(0, 21, 777)), np.zeros(300, dtype=int), np.full(5, 20)):
+        e = rng.normal(size=len(ws)) + 30
+        s, c = S.state_sums(e, ws, 21)
+        want_c = np.bincount(ws, minlength=21)
+        want_s = np.array([e[ws == k].sum() for k in range(21)])
+        assert (c == want_c).all()
+        np.testing.assert_allclose(s, want_s, rtol=1e-13, atol=1e-12)
