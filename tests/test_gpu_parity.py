@@ -807,3 +807,54 @@ def test_three_local_energy_kernels_agree_on_the_gpu(kind):
     assert st[3] == 0
     np.testing.assert_allclose(el, G["z2_nt_Eloc"], rtol=1e-8)
     np.testing.assert_allclose(lap, G["z2_nt_lap"], rtol=1e-7, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ configs 3 and 4 at BASELINE size
+def test_config3_betavmc_full_size_known_answer(dev):
+    """BASELINE.json configs[2] (beta = 10, nup = 3, boltzmann) at 65536 walkers with the driver's zero-initialised flow
+    and Z = 0: every walker's local energy is exactly the energy of the many-body state it was drawn in, so
+    E = sum_s p_s E_s up to the sampling of the states, F = E - S/beta, and S agrees with the analytic entropy."""
+    import fermiflow_amd as ff
+    eta, mu = ff.MLP(1, 50), ff.MLP(1, 50)
+    eta.init_zeros(); mu.init_zeros()
+    cnf = ff.CNF(ff.Backflow(eta, mu=mu), (0.0, 1.0))
+    model = ff.BetaVMC(1.0, 3, 0, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), cnf, ff.CoulombPairPotential(0.0), sp_potential=ff.HO())
+    model.to(dev)
+    torch.manual_seed(1)
+    B = 65536
+    gphi, gtheta = model(B)
+    (gphi + gtheta).backward()
+    Es = model.Es_original.to(dev)
+    ws = model._ws.long()
+    assert (model.Eloc - Es[ws]).abs().max().item() < 1e-8            # eigenfunction KAT, state by state
+    p = torch.softmax(model.log_state_weights.detach(), dim=0)
+    E_exact = (p * Es).sum().item()
+    assert abs(model.E - E_exact) < 6 * model.E_std / np.sqrt(B)
+    assert abs(model.S - model.S_analytical) < 0.02 and abs(model.F - (model.E - model.S / model.beta)) < 1e-9
+    counts = torch.bincount(ws, minlength=model.Nstates).double()
+    assert ((counts / B - p).abs() < 6 * (p * (1 - p) / B).sqrt() + 1e-12).all()       # the state list is a sample of softmax(logits)
+    assert torch.isfinite(model.log_state_weights.grad).all() and all(torch.isfinite(q.grad).all() for q in cnf.parameters())
+
+
+def test_config4_six_plus_six_full_size_known_answer(dev):
+    """BASELINE.json configs[3] per GPU: nup = ndown = 6, 32768 walkers; zero flow, Z = 0 -> E_loc = 2 (1+2+2+3+3+3) = 28
+    for every walker (row-layout local-energy kernel, split-determinant Metropolis kernel, 6 x 6 Slater finish)."""
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 6, 6, 0.0)
+    for p in model.parameters():
+        torch.nn.init.zeros_(p)
+    torch.manual_seed(2)
+    g = model(32768)
+    g.backward()
+    assert (model.Eloc - 28.0).abs().max().item() < 1e-7
+    assert abs(model.E - 28.0) < 1e-9 and model.E_std < 1e-7
+    # and with the benchmark's non-trivial flow: a sample of walkers against the oracle
+    model = Gm._model(dev, 6, 6, 2.0)
+    torch.manual_seed(3)
+    model(4096)
+    v = model.cnf.v_wrapper.v
+    net = O.Net(tuple(N(t) for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
+                tuple(N(t) for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+    ref = O.eloc(N(model.x[:24]), 6, 6, net, 2.0, rtol=1e-10, atol=1e-12)
+    rel = np.abs(N(model.Eloc[:24]) - ref["eloc"]) / np.abs(ref["eloc"])
+    assert rel.max() < ELOC_RTOL, rel.max()
