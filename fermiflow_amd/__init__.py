@@ -8,7 +8,7 @@ import torch
 
 torch.set_default_dtype(torch.float64)   # the reference does this at the top of every module (e.g. src/VMC.py:2)
 
-from .orbitals import HO2D, Orbitals, Orbital          # noqa: E402,F401
+from .orbitals import HO2D, HO3D, Orbitals, Orbital, Orbital3D          # noqa: E402,F401
 from .slater import LogAbsSlaterDet, LogAbsSlaterDetMultStates, logabsslaterdet, logabsslaterdetmultstates  # noqa: E402,F401
 from .base_dist import FreeFermion                      # noqa: E402,F401
 from .MLP import MLP                                    # noqa: E402,F401
@@ -18,3 +18,4 @@ from .potentials import HO, CoulombPairPotential        # noqa: E402,F401
 from .VMC import GSVMC, BetaVMC                         # noqa: E402,F401
 from .utils import y_grad_laplacian                     # noqa: E402,F401
 from .NeuralODE.nnModule import solve_ivp_nnmodule      # noqa: E402,F401
+from . import checkpoint                                # noqa: E402,F401

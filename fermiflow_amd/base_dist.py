@@ -2,7 +2,7 @@
 import torch
 
 from . import native
-from .orbitals import orbital_indices
+from .orbitals import orbital_indices, orbital_dim
 from .slater import LogAbsSlaterDet, LogAbsSlaterDetMultStates, _walker_states
 
 
@@ -28,6 +28,10 @@ class FreeFermion(BaseDist):
 
     def log_prob(self, orbitals_up, orbitals_down, x):
         nup, ndown = len(orbitals_up), len(orbitals_down)
+        if orbital_dim(tuple(orbitals_up) + tuple(orbitals_down)) == 3:      # HO3D: value only (ff_logprob3d)
+            tu, td = self._tables(orbitals_up, orbitals_down)
+            *batch, n, dim = x.shape
+            return native.logprob3d(tu, td, nup, ndown, x.detach().reshape(-1, n, 3).contiguous()).reshape(batch)
         logabspsi = (LogAbsSlaterDet.apply(orbitals_up, x[..., :nup, :]) if nup != 0 else 0) \
             + (LogAbsSlaterDet.apply(orbitals_down, x[..., nup:, :]) if ndown != 0 else 0)
         return 2 * logabspsi
@@ -45,6 +49,12 @@ class FreeFermion(BaseDist):
         for s in sample_shape:
             B *= int(s)
         tu, td = self._tables(orbitals_up, orbitals_down)
+        if orbital_dim(tuple(orbitals_up) + tuple(orbitals_down)) == 3:      # HO3D walkers (B, n, 3)
+            if x_init is not None:
+                raise NotImplementedError("persistent walkers in three dimensions")
+            x, _, _ = native.mcmc_sample3d(tu, td, nup, ndown, B, equilibrim_steps, tau, _draw_seed(), self.device,
+                                           walker_offset=self.walker_offset)
+            return x.reshape(*sample_shape, nup + ndown, 3)
         if x_init is not None:
             x, _, _ = native.mcmc_continue(tu, td, nup, ndown, x_init.reshape(B, nup + ndown, 2), equilibrim_steps, tau,
                                            _draw_seed(), walker_offset=self.walker_offset)
@@ -57,6 +67,8 @@ class FreeFermion(BaseDist):
         """Parity mode: consume explicit noise in the reference's draw order (randn(B,n,2); per step
         randn_like(x) then rand_like(p)).  Returns (x, logp, accept[S,B] uint8)."""
         tu, td = self._tables(orbitals_up, orbitals_down)
+        if orbital_dim(tuple(orbitals_up) + tuple(orbitals_down)) == 3:
+            return native.mcmc_sample_noise3d(tu, td, len(orbitals_up), len(orbitals_down), g0, g, u, tau)
         return native.mcmc_sample_noise(tu, td, len(orbitals_up), len(orbitals_down), g0, g, u, tau)
 
     # ---- finite temperature: one orbital set per walker ------------------------------------------

@@ -1,0 +1,315 @@
+// ff_ho3d.hip -- groundwork for BASELINE.json configs[4] (3-D harmonic trap, fp32 MLP path), SURVEY.md 8(f).4.
+//
+// The reference has no three-dimensional code (src/orbitals.py:56 and src/base_dist.py:62 hard-code d = 2), so there is no
+// upstream file to cite beyond the two-dimensional ones this generalises:
+//   HO3D orbitals        <- HO2D, src/orbitals.py:65-82          (one more Hermite factor, E = shell + 3/2)
+//   ff_logprob3d         <- FreeFermion.log_prob, src/base_dist.py:49-56, with the gradient / Laplacian y_grad_laplacian extracts
+//   ff_mcmc_sample*3d    <- FreeFermion.sample, src/base_dist.py:58-71 (walkers (B, n, 3))
+//   ff_backflow_v_div_f32<- Backflow.forward / .divergence, src/equivariant_funs.py:83-102, sigmoid sums in fp32
+// One lane per walker and runtime determinant sizes (private arrays): correct and simple, not yet tuned -- the fused ODE
+// kernels are templated on d but only instantiated for d = 2.
+// Known-answer test: E_loc == sum of orbital energies at every point (tests/test_basedist.py:5-60 one dimension up).
+#include "ff_common.h"
+#include "ff_slater.h"
+#include "ff_rng.h"
+
+#ifdef FF_HOSTSIM
+#define __expf expf
+#endif
+#define FF_HO3D_NORB 120        // shells 0..7 (Hermite degrees 0..7)
+#define FF_PI_M34 0.42377720812375763   // pi^(-3/4)
+
+FF_D void ff_ho3d_decode(int k, int& nx, int& ny, int& nz) {
+  int shell = 0;
+  while ((shell + 1) * (shell + 2) * (shell + 3) / 6 <= k) shell++;
+  int idx = k - shell * (shell + 1) * (shell + 2) / 6;
+  nx = ny = nz = 0;
+  for (int a = 0; a <= shell; a++) {
+    const int cnt = shell - a + 1;
+    if (idx < cnt) { nx = a; ny = idx; nz = shell - a - idx; return; }
+    idx -= cnt;
+  }
+}
+
+// phi_k at r and optionally its gradient (3) and Laplacian
+template <bool DERIV>
+FF_D void ff_orbital3d(int k, const double* r, double gauss /* pi^-3/4 exp(-r^2/2) */, double& v, double* g, double& lap) {
+  int n[3];
+  ff_ho3d_decode(k, n[0], n[1], n[2]);
+  double h[3], h1[3], h2[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) ff_herm<DERIV>(n[c], r[c], h[c], h1[c], h2[c]);
+  v = gauss * h[0] * h[1] * h[2];
+  if (DERIV) {
+    double p1[3], p2[3];   // (e^{-x^2/2} h)' / e^{-x^2/2}, (e^{-x^2/2} h)'' / e^{-x^2/2}
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      p1[c] = h1[c] - r[c] * h[c];
+      p2[c] = h2[c] - 2.0 * r[c] * h1[c] + (r[c] * r[c] - 1.0) * h[c];
+    }
+    g[0] = gauss * p1[0] * h[1] * h[2]; g[1] = gauss * h[0] * p1[1] * h[2]; g[2] = gauss * h[0] * h[1] * p1[2];
+    lap = gauss * (p2[0] * h[1] * h[2] + h[0] * p2[1] * h[2] + h[0] * h[1] * p2[2]);
+  }
+}
+
+FF_D double ff_gauss3d(const double* r) { return FF_PI_M34 * exp(-0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2])); }
+
+// log|det D| (D_ij = phi_j(r_i)) of ns particles; with grad: d/dr_i = sum_j grad phi_j(r_i) Dinv_ji (src/slater.py:51-61),
+// and the Laplacian sum_i [ sum_j lap phi_j(r_i) Dinv_ji - |grad_i|^2 ] (rank-one update of the determinant).
+// Value only: LU with partial pivoting, the operations of ff_slater_general; with derivatives: Gauss-Jordan inverse.
+FF_D double ff_ho3d_logabsdet(int ns, const int* __restrict__ orb, const double* x, double* grad, double* lap) {
+  double A[FF_MAX_NS * FF_MAX_NS], Inv[FF_MAX_NS * FF_MAX_NS];
+  const bool deriv = grad != nullptr;
+  for (int i = 0; i < ns; i++) {
+    const double gs = ff_gauss3d(x + 3 * i);
+    for (int j = 0; j < ns; j++) {
+      double v, lp;
+      ff_orbital3d<false>(orb[j], x + 3 * i, gs, v, nullptr, lp);
+      A[i * ns + j] = v;
+      if (deriv) Inv[i * ns + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  double acc = 0.0;
+  for (int c = 0; c < ns; c++) {
+    int p = c;
+    double best = fabs(A[c * ns + c]);
+    for (int r = c + 1; r < ns; r++) {
+      const double a = fabs(A[r * ns + c]);
+      if (a > best) { best = a; p = r; }
+    }
+    if (p != c)
+      for (int j = 0; j < ns; j++) {
+        double t = A[c * ns + j]; A[c * ns + j] = A[p * ns + j]; A[p * ns + j] = t;
+        if (deriv) { t = Inv[c * ns + j]; Inv[c * ns + j] = Inv[p * ns + j]; Inv[p * ns + j] = t; }
+      }
+    const double piv = A[c * ns + c];
+    acc += log(fabs(piv));
+    if (!deriv) {
+      for (int r = c + 1; r < ns; r++) {
+        const double f = A[r * ns + c] / piv;
+        for (int j = c + 1; j < ns; j++) A[r * ns + j] = A[r * ns + j] - f * A[c * ns + j];
+      }
+    } else {
+      const double ip = 1.0 / piv;
+      for (int j = 0; j < ns; j++) { A[c * ns + j] *= ip; Inv[c * ns + j] *= ip; }
+      for (int r = 0; r < ns; r++) {
+        if (r == c) continue;
+        const double f = A[r * ns + c];
+        for (int j = 0; j < ns; j++) {
+          A[r * ns + j] = fma(-f, A[c * ns + j], A[r * ns + j]);
+          Inv[r * ns + j] = fma(-f, Inv[c * ns + j], Inv[r * ns + j]);
+        }
+      }
+    }
+  }
+  if (deriv) {
+    double l = 0.0;
+    for (int a = 0; a < ns; a++) {
+      const double gs = ff_gauss3d(x + 3 * a);
+      double g[3] = {0.0, 0.0, 0.0}, s = 0.0;
+      for (int j = 0; j < ns; j++) {
+        double v, gj[3], lj;
+        ff_orbital3d<true>(orb[j], x + 3 * a, gs, v, gj, lj);
+        const double da = Inv[j * ns + a];
+        g[0] = fma(gj[0], da, g[0]); g[1] = fma(gj[1], da, g[1]); g[2] = fma(gj[2], da, g[2]);
+        s = fma(lj, da, s);
+      }
+      grad[3 * a] = g[0]; grad[3 * a + 1] = g[1]; grad[3 * a + 2] = g[2];
+      l += s - (g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    }
+    *lap = l;
+  }
+  return acc;
+}
+
+// logp = 2 (log|det up| + log|det dn|) and, optionally, its gradient and Laplacian wrt all coordinates
+__global__ void __launch_bounds__(64)
+ff_logprob3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                    const int* __restrict__ wstate, const double* __restrict__ x, double* __restrict__ logp,
+                    double* __restrict__ grad, double* __restrict__ lap) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = nup + ndn, st = wstate ? wstate[b] : 0;
+  double xl[3 * FF_MAX_NS], gl[3 * FF_MAX_NS];
+  double lp = 0.0, lsum = 0.0;
+  for (int sp = 0; sp < 2; sp++) {
+    const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+    if (!ns) continue;
+    for (int k = 0; k < 3 * ns; k++) xl[k] = x[b * 3 * n + 3 * off + k];
+    double l = 0.0;
+    lp += ff_ho3d_logabsdet(ns, (sp ? tab_dn : tab_up) + st * ns, xl, grad ? gl : nullptr, &l);
+    if (grad) {
+      for (int k = 0; k < 3 * ns; k++) grad[b * 3 * n + 3 * off + k] = 2.0 * gl[k];
+      lsum += 2.0 * l;
+    }
+  }
+  logp[b] = 2.0 * lp;
+  if (lap) lap[b] = lsum;
+}
+
+#ifdef FF_HOSTSIM
+static double ff3_mul_rn(double a, double b) { volatile double r = a * b; return r; }
+static double ff3_add_rn(double a, double b) { volatile double r = a + b; return r; }
+#else
+// two roundings, as torch evaluates x + tau * g (the backend must not contract them into one fma)
+FF_D double ff3_mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
+FF_D double ff3_add_rn(double a, double b) { double r = a + b; asm volatile("" : "+v"(r)); return r; }
+#endif
+
+// FreeFermion.sample in d = 3: N(0,1) start, `steps` Metropolis steps with proposal x + tau g, accept iff u < exp(dlogp).
+// NOISE: explicit g0 (B,n,3), g (S,B,n,3), u (S,B); otherwise Philox counters (seed, woff + b) as in the 2-D sampler.
+template <bool NOISE>
+__global__ void __launch_bounds__(64)
+ff_mcmc3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                 const int* __restrict__ wstate, int steps, double tau, const double* __restrict__ g0,
+                 const double* __restrict__ g, const double* __restrict__ u, uint64_t seed, int64_t woff,
+                 double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = nup + ndn, M = 3 * n, st = wstate ? wstate[b] : 0;
+  const int* ou = tab_up + (nup ? st * nup : 0);
+  const int* od = tab_dn + (ndn ? st * ndn : 0);
+  double x[3 * 2 * FF_MAX_NS], nx[3 * 2 * FF_MAX_NS];
+  const uint64_t wid = (uint64_t)(woff + b);
+  auto normals = [&](uint32_t step, double* dst) {   // M normals of (walker, step): quads of four per Philox block
+    for (int q = 0; 4 * q < M; q++) {
+      double z4[4];
+      ff_normal_quad(seed, wid, step, (uint32_t)q, z4);
+      for (int k = 0; k < 4 && 4 * q + k < M; k++) dst[4 * q + k] = z4[k];
+    }
+  };
+  auto logprob = [&](const double* r) -> double {
+    double lp = 0.0, dum;
+    if (nup) lp += ff_ho3d_logabsdet(nup, ou, r, nullptr, &dum);
+    if (ndn) lp += ff_ho3d_logabsdet(ndn, od, r + 3 * nup, nullptr, &dum);
+    return 2.0 * lp;
+  };
+  if (NOISE) { for (int i = 0; i < M; i++) x[i] = g0[b * M + i]; }
+  else normals(0u, x);
+  double logp = logprob(x);
+  int nacc = 0;
+  for (int s = 0; s < steps; s++) {
+    double gq[3 * 2 * FF_MAX_NS], uu;
+    if (NOISE) {
+      for (int i = 0; i < M; i++) gq[i] = g[((int64_t)s * B + b) * M + i];
+      uu = u[(int64_t)s * B + b];
+    } else {
+      normals((uint32_t)(s + 1), gq);
+      uu = ff_uniform(seed, wid, (uint32_t)(s + 1), 0xffffu);
+    }
+    for (int i = 0; i < M; i++) nx[i] = ff3_add_rn(x[i], ff3_mul_rn(tau, gq[i]));
+    const double nl = logprob(nx);
+    const double p = exp(nl - logp);
+    const bool acc = uu < p;          // IEEE comparison: NaN rejects, +inf accepts (src/base_dist.py:67-68)
+    if (acc) { for (int i = 0; i < M; i++) x[i] = nx[i]; logp = nl; nacc++; }
+    if (accept) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+  }
+  for (int i = 0; i < M; i++) x_out[b * M + i] = x[i];
+  if (logp_out) logp_out[b] = logp;
+  if (acc_count) acc_count[b] = nacc;
+}
+
+// ---- fp32: Backflow.forward / .divergence with the sigmoid sums, radii and accumulations in single precision
+// (walkers and results stay fp64 arrays at the boundary; the arithmetic in between is what an fp32 path would run)
+FF_D void ff_mlp_point_f32(int H, const double* __restrict__ w1, const double* __restrict__ b1, const double* __restrict__ w2,
+                           float r, float& val, float& dval) {
+  float s = 0.f, g = 0.f;
+  for (int h = 0; h < H; h++) {
+    const float a = fmaf((float)w1[h], r, (float)b1[h]);
+    const float sg = 1.0f / (1.0f + __expf(-a));
+    s = fmaf((float)w2[h], sg, s);
+    g = fmaf((float)w2[h] * (float)w1[h], sg * (1.0f - sg), g);
+  }
+  val = s; dval = g;
+}
+
+__global__ void __launch_bounds__(128)
+ff_backflow_f32_kernel(int64_t B, int n, int d, ff_net net, const double* __restrict__ x, double* __restrict__ v,
+                       double* __restrict__ div) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int M = n * d;
+  float xl[3 * 24], vl[3 * 24];
+  for (int i = 0; i < M; i++) { xl[i] = (float)x[b * M + i]; vl[i] = 0.f; }
+  float dv = 0.f;
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++) {
+      float rho[3], r2 = 0.f;
+      for (int c = 0; c < d; c++) { rho[c] = xl[i * d + c] - xl[j * d + c]; r2 = fmaf(rho[c], rho[c], r2); }
+      float r = sqrtf(r2), eta, deta;
+      ff_mlp_point_f32(net.He, net.ew1, net.eb1, net.ew2, r, eta, deta);
+      for (int c = 0; c < d; c++) { vl[i * d + c] = fmaf(eta, rho[c], vl[i * d + c]); vl[j * d + c] = fmaf(-eta, rho[c], vl[j * d + c]); }
+      dv += 2.0f * fmaf(deta, r, d * eta);
+    }
+  if (net.Hm > 0)
+    for (int i = 0; i < n; i++) {
+      float r2 = 0.f;
+      for (int c = 0; c < d; c++) r2 = fmaf(xl[i * d + c], xl[i * d + c], r2);
+      float r = sqrtf(r2), mu, dmu;
+      ff_mlp_point_f32(net.Hm, net.mw1, net.mb1, net.mw2, r, mu, dmu);
+      for (int c = 0; c < d; c++) vl[i * d + c] = fmaf(mu, xl[i * d + c], vl[i * d + c]);
+      dv += fmaf(dmu, r, d * mu);
+    }
+  if (v) for (int i = 0; i < M; i++) v[b * M + i] = (double)vl[i];
+  if (div) div[b] = (double)dv;
+}
+
+// =================================================================================================
+extern void ff_set_error(const char* msg);
+#define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
+#define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
+static unsigned ff3_grid(int64_t B, int block) { return (unsigned)((B + block - 1) / block); }
+
+extern "C" {
+
+int ff_logprob3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                 const int32_t* walker_state, const double* x, double* logp, double* grad, double* lap) {
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && nup + ndn > 0 && x && logp, FF_EINVAL, "ff_logprob3d: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn) && ((grad == nullptr) == (lap == nullptr)), FF_EINVAL, "ff_logprob3d: null pointer");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_logprob3d: determinant larger than FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_logprob3d_kernel, ff3_grid(B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, x, logp, grad, lap);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_mcmc_sample_noise3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                           const int32_t* walker_state, int steps, double tau, const double* g0, const double* g, const double* u,
+                           double* x_out, double* logp_out, uint8_t* accept) {
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && nup + ndn > 0 && steps >= 0 && x_out && g0 && (steps == 0 || (g && u)), FF_EINVAL,
+           "ff_mcmc_sample_noise3d: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_mcmc_sample_noise3d: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_mcmc_sample_noise3d: determinant larger than FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH((ff_mcmc3d_kernel<true>), ff3_grid(B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, g0, g, u,
+            (uint64_t)0, (int64_t)0, x_out, logp_out, accept, (int*)nullptr);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                     double* x_out, double* logp_out, int32_t* accept_count) {
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && nup + ndn > 0 && steps >= 0 && x_out, FF_EINVAL, "ff_mcmc_sample3d: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_mcmc_sample3d: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_mcmc_sample3d: determinant larger than FF_MAX_NS");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH((ff_mcmc3d_kernel<false>), ff3_grid(B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau,
+            (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, seed, walker_offset, x_out, logp_out,
+            (uint8_t*)nullptr, accept_count);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && net && x && (v || div), FF_EINVAL, "ff_backflow_v_div_f32: bad argument");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_backflow_v_div_f32: bad net");
+  FF_CHECK(n <= 24 && d <= 3, FF_EUNSUPPORTED, "ff_backflow_v_div_f32: n > 24 or d > 3");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_backflow_f32_kernel, ff3_grid(B, 128), 128, stream, B, n, d, *net, x, v, div);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+}  // extern "C"

@@ -234,3 +234,48 @@ def state_sums(e, walker_state, nstates):
     L.check(L.lib().ff_state_sums(L.stream(), L.i64(e.numel()), int(nstates), L.ptr(ws), L.ptr(e), L.ptr(out[0]), L.ptr(out[1])),
             "ff_state_sums")
     return out
+
+
+# ---- d = 3 groundwork (csrc/ff_ho3d.hip) ---------------------------------------------------------------------------
+def logprob3d(tab_up, tab_dn, nup, ndn, x, walker_state=None, derivs=False):
+    x = L.dev(x, name="x")
+    B = x.shape[0]
+    logp = torch.empty(B, dtype=torch.float64, device=x.device)
+    grad = torch.empty_like(x) if derivs else None
+    lap = torch.empty(B, dtype=torch.float64, device=x.device) if derivs else None
+    L.check(L.lib().ff_logprob3d(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                 L.ptr(x), L.ptr(logp), L.ptr(grad), L.ptr(lap)), "ff_logprob3d")
+    return (logp, grad, lap) if derivs else logp
+
+
+def mcmc_sample_noise3d(tab_up, tab_dn, nup, ndn, g0, g, u, tau=0.1, walker_state=None):
+    g0, g, u = L.dev(g0, name="g0"), L.dev(g, name="g"), L.dev(u, name="u")
+    B, steps = g0.shape[0], g.shape[0]
+    x = torch.empty_like(g0)
+    logp = torch.empty(B, dtype=torch.float64, device=g0.device)
+    acc = torch.empty(steps, B, dtype=torch.uint8, device=g0.device)
+    L.check(L.lib().ff_mcmc_sample_noise3d(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                           int(steps), L.f64(tau), L.ptr(g0), L.ptr(g), L.ptr(u), L.ptr(x), L.ptr(logp), L.ptr(acc)),
+            "ff_mcmc_sample_noise3d")
+    return x, logp, acc
+
+
+def mcmc_sample3d(tab_up, tab_dn, nup, ndn, B, steps, tau, seed, device, walker_offset=0, walker_state=None):
+    n = nup + ndn
+    x = torch.empty(B, n, 3, dtype=torch.float64, device=device)
+    logp = torch.empty(B, dtype=torch.float64, device=device)
+    cnt = torch.empty(B, dtype=torch.int32, device=device)
+    L.check(L.lib().ff_mcmc_sample3d(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                                     int(steps), L.f64(tau), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
+                                     L.ptr(x), L.ptr(logp), L.ptr(cnt)), "ff_mcmc_sample3d")
+    return x, logp, cnt
+
+
+def backflow_v_div_f32(net, x):
+    """Backflow v and div v with the arithmetic in fp32 (fp64 tensors at the boundary)."""
+    x = L.dev(x, name="x")
+    B, n, d = x.shape
+    v = torch.empty_like(x)
+    div = torch.empty(B, dtype=torch.float64, device=x.device)
+    L.check(L.lib().ff_backflow_v_div_f32(L.stream(), L.i64(B), n, d, net.ref(), L.ptr(x), L.ptr(v), L.ptr(div)), "ff_backflow_v_div_f32")
+    return v, div

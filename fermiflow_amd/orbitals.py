@@ -22,6 +22,7 @@ _HERM = [  # h_n(x) = norm * sum_k c_k x^k  (src/orbitals.py:66-73)
 
 
 class Orbital:
+    dim = 2
     """phi_{nx,ny}(r) = pi^-1/2 exp(-|r|^2/2) h_nx(x) h_ny(y)."""
 
     __slots__ = ("k", "nx", "ny", "E")
@@ -45,11 +46,36 @@ class Orbital:
         return f"Orbital(k={self.k}, nx={self.nx}, ny={self.ny})"
 
 
+class Orbital3D:
+    """phi_{nx,ny,nz}(r) = pi^-3/4 exp(-|r|^2/2) h_nx(x) h_ny(y) h_nz(z)  (HO3D: no upstream counterpart)."""
+
+    __slots__ = ("k", "nx", "ny", "nz", "E")
+    dim = 3
+
+    def __init__(self, k, nx, ny, nz):
+        self.k, self.nx, self.ny, self.nz, self.E = k, nx, ny, nz, nx + ny + nz + 1.5
+
+    def __call__(self, x):
+        return math.pi ** -0.75 * torch.exp(-0.5 * (x ** 2).sum(dim=-1)) \
+            * Orbital._h(self.nx, x[..., 0]) * Orbital._h(self.ny, x[..., 1]) * Orbital._h(self.nz, x[..., 2])
+
+    def __repr__(self):
+        return f"Orbital3D(k={self.k}, n=({self.nx}, {self.ny}, {self.nz}))"
+
+
+def orbital_dim(orbitals):
+    """2 for HO2D orbitals, 3 for HO3D orbitals (a mixed tuple is an error)."""
+    dims = {getattr(o, "dim", 2) for o in orbitals}
+    if len(dims) > 1:
+        raise TypeError("orbitals of different dimensions in one determinant")
+    return dims.pop() if dims else 2
+
+
 def orbital_indices(orbitals):
     """tuple of Orbital objects -> list of integer indices for the kernels."""
     out = []
     for o in orbitals:
-        if not isinstance(o, Orbital):
+        if not isinstance(o, (Orbital, Orbital3D)):
             raise TypeError("fermiflow_amd orbitals must come from fermiflow_amd.orbitals.HO2D().orbitals "
                             "(Python closures cannot be evaluated by the HIP kernels)")
         out.append(o.k)
@@ -118,3 +144,17 @@ class HO2D(Orbitals):
                 self.orbitals.append(Orbital(len(self.orbitals), nx, shell - nx))
                 self.Es.append(shell + 1)
         self.E_indices = lambda n: tuple(range(n * (n + 1) // 2, (n + 1) * (n + 2) // 2))
+
+
+class HO3D(Orbitals):
+    """Orbitals of h = -1/2 laplacian + 1/2 r^2 in 3-D: shells 0..7 (120 orbitals), E = shell + 3/2; list order
+    "for shell: for nx in 0..shell: for ny in 0..shell-nx: (nx, ny, shell-nx-ny)".  The reference stops at two dimensions
+    (src/orbitals.py:56); this is the set BASELINE.json configs[4] needs (nup = ndown = 10 fills shells 0..2)."""
+
+    def __init__(self):
+        self.orbitals, self.Es = [], []
+        for shell in range(8):
+            for nx in range(shell + 1):
+                for ny in range(shell + 1 - nx):
+                    self.orbitals.append(Orbital3D(len(self.orbitals), nx, ny, shell - nx - ny))
+                    self.Es.append(shell + 1.5)

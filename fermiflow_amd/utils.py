@@ -5,7 +5,7 @@ ODE solves.  Here they come out of one native pass; `f` must therefore be one of
 how to do that (GSVMC.logp / BetaVMC.logp bound methods, or a FreeFermion.log_prob closure made by
 `freefermion_logp`)."""
 from . import native
-from .orbitals import orbital_indices
+from .orbitals import orbital_indices, orbital_dim
 
 
 class freefermion_logp:
@@ -15,12 +15,13 @@ class freefermion_logp:
         self.nup, self.ndn = len(orbitals_up), len(orbitals_down)
         self.tu = native.orbital_table(orbital_indices(orbitals_up), basedist.device) if self.nup else None
         self.td = native.orbital_table(orbital_indices(orbitals_down), basedist.device) if self.ndn else None
+        self._f = native.logprob3d if orbital_dim(tuple(orbitals_up) + tuple(orbitals_down)) == 3 else native.logprob
 
     def __call__(self, x):
-        return native.logprob(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous())
+        return self._f(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous())
 
     def _native_grad_laplacian(self, x):
-        return native.logprob(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous(), derivs=True)
+        return self._f(self.tu, self.td, self.nup, self.ndn, x.detach().contiguous(), derivs=True)
 
 
 def y_grad_laplacian(f, x):

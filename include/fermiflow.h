@@ -182,6 +182,25 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
 int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev,
                       double shift_dev_scale, double* out2);
 
+/* ---- three dimensions (groundwork for a 3-D trap; no upstream counterpart: src/orbitals.py:56 and src/base_dist.py:62
+ * hard-code d = 2).  Orbital index k of HO3D: list order "for n in range(8) for nx in range(n+1) for ny in range(n+1-nx):
+ * (nx, ny, n-nx-ny)", phi = pi^-3/4 exp(-r^2/2) h_nx(x) h_ny(y) h_nz(z), E = n + 3/2.  Walkers are (B, n, 3). -------------- */
+/* FreeFermion.log_prob in d = 3 (src/base_dist.py:49-56 generalised) with, optionally (both or neither), the gradient (B,n,3)
+ * and the Laplacian (B) that y_grad_laplacian (src/utils.py:40-65) extracts. */
+int ff_logprob3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                 const int32_t* walker_state, const double* x, double* logp, double* grad, double* lap);
+/* FreeFermion.sample in d = 3 (src/base_dist.py:58-71 generalised): explicit noise g0 (B,n,3), g (S,B,n,3), u (S,B) ... */
+int ff_mcmc_sample_noise3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                           const int32_t* walker_state, int steps, double tau, const double* g0, const double* g, const double* u,
+                           double* x_out, double* logp_out, uint8_t* accept);
+/* ... or Philox counters (seed, walker_offset + b), as ff_mcmc_sample. */
+int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
+                     double* x_out, double* logp_out, int32_t* accept_count);
+/* Backflow.forward / .divergence (src/equivariant_funs.py:83-102) with radii, sigmoid sums and accumulations in fp32
+ * (fp64 arrays at the boundary): the single-precision instantiation whose error against ff_backflow_v_div the tests report. */
+int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div);
+
 /* Per-state sums of the finite-temperature estimator (src/VMC.py:155-169): walker_state (int32 [B]) must be SORTED
  * (src/VMC.py:94-96); sums[s] = sum of e[b] over the walkers in state s, counts[s] = their number (as doubles, ready for
  * an all-reduce).  One workgroup per state, fixed summation tree: deterministic. */

@@ -175,60 +175,92 @@ int ffo_orbitals(const int* k, int nk, const double* pts, int npts, double* out)
   return 0;
 }
 
+int ffo_orbitals3d(const int* k, int nk, const double* pts, int npts, double* out) {
+  for (int a = 0; a < nk; a++) {
+    if (k[a] < 0 || k[a] >= 120) return 1;
+    for (int p = 0; p < npts; p++)
+      out[a * npts + p] = orbital3d_o0(k[a], jc_o0(pts[3 * p]), jc_o0(pts[3 * p + 1]), jc_o0(pts[3 * p + 2])).v;
+  }
+  return 0;
+}
+
 static const int* row(const int* table, const int* wstate, int64_t b, int n) {
   return table + (size_t)(wstate ? wstate[b] : 0) * n;
 }
 
 /* value, gradient and Laplacian of logp0 = 2*(log|det up| + log|det dn|) at one point */
-static void logprob_glap(int nup, int ndn, const int* ou, const int* od, const double* x,
-                         double* logp, double* grad, double* lap) {
-  int n = nup + ndn, M = 2 * n;
+static void logprob_glap_d(int nup, int ndn, int d, const int* ou, const int* od, const double* x,
+                           double* logp, double* grad, double* lap) {
+  int n = nup + ndn, M = d * n;
   if (!grad && !lap) {
     jet_o0 xy[FFO_MAXM];
     for (int i = 0; i < M; i++) xy[i] = jc_o0(x[i]);
-    *logp = logprob_o0(nup, ndn, ou, od, xy).v;
+    *logp = logprob_d_o0(nup, ndn, d, ou, od, xy).v;
     return;
   }
   double l = 0.0;
   for (int i = 0; i < M; i++) {
     jet_o2 xy[FFO_MAXM];
     for (int k = 0; k < M; k++) xy[k] = jmk_o2(x[k], k == i ? 1.0 : 0.0, 0.0);
-    jet_o2 r = logprob_o2(nup, ndn, ou, od, xy);
+    jet_o2 r = logprob_d_o2(nup, ndn, d, ou, od, xy);
     if (logp) *logp = r.v;
     if (grad) grad[i] = r.d1;
     l += r.d2;
   }
   if (lap) *lap = l;
 }
+static void logprob_glap(int nup, int ndn, const int* ou, const int* od, const double* x,
+                         double* logp, double* grad, double* lap) { logprob_glap_d(nup, ndn, 2, ou, od, x, logp, grad, lap); }
 
-int ffo_logprob(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
-                const double* x, double* logp, double* grad, double* lap) {
+static int logprob_any(int64_t B, int nup, int ndn, int d, const int* tab_up, const int* tab_dn, const int* wstate,
+                       const double* x, double* logp, double* grad, double* lap) {
   int n = nup + ndn;
-  if (n <= 0 || nup > FFO_MAXN || ndn > FFO_MAXN) return 1;
+  if (n <= 0 || nup > FFO_MAXN || ndn > FFO_MAXN || d * n > FFO_MAXM) return 1;
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < B; b++)
-    logprob_glap(nup, ndn, nup ? row(tab_up, wstate, b, nup) : NULL, ndn ? row(tab_dn, wstate, b, ndn) : NULL,
-                 x + b * 2 * n, logp + b, grad ? grad + b * 2 * n : NULL, lap ? lap + b : NULL);
+    logprob_glap_d(nup, ndn, d, nup ? row(tab_up, wstate, b, nup) : NULL, ndn ? row(tab_dn, wstate, b, ndn) : NULL,
+                   x + b * d * n, logp + b, grad ? grad + b * d * n : NULL, lap ? lap + b : NULL);
   return 0;
+}
+int ffo_logprob(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                const double* x, double* logp, double* grad, double* lap) {
+  return logprob_any(B, nup, ndn, 2, tab_up, tab_dn, wstate, x, logp, grad, lap);
+}
+int ffo_logprob3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                  const double* x, double* logp, double* grad, double* lap) {
+  return logprob_any(B, nup, ndn, 3, tab_up, tab_dn, wstate, x, logp, grad, lap);
 }
 
 /* FreeFermion.sample loop body (src/base_dist.py:62-70) with explicit noise. */
+static int mcmc_noise_any(int64_t B, int nup, int ndn, int d, const int* tab_up, const int* tab_dn, const int* wstate,
+                          int steps, double tau, const double* g0, const double* g, const double* u,
+                          double* x_out, double* logp_out, uint8_t* accept_out);
 int ffo_mcmc_noise(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                    int steps, double tau, const double* g0, const double* g, const double* u,
                    double* x_out, double* logp_out, uint8_t* accept_out) {
-  int n = nup + ndn, M = 2 * n;
-  if (n <= 0) return 1;
+  return mcmc_noise_any(B, nup, ndn, 2, tab_up, tab_dn, wstate, steps, tau, g0, g, u, x_out, logp_out, accept_out);
+}
+int ffo_mcmc_noise3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                     int steps, double tau, const double* g0, const double* g, const double* u,
+                     double* x_out, double* logp_out, uint8_t* accept_out) {
+  return mcmc_noise_any(B, nup, ndn, 3, tab_up, tab_dn, wstate, steps, tau, g0, g, u, x_out, logp_out, accept_out);
+}
+static int mcmc_noise_any(int64_t B, int nup, int ndn, int d, const int* tab_up, const int* tab_dn, const int* wstate,
+                          int steps, double tau, const double* g0, const double* g, const double* u,
+                          double* x_out, double* logp_out, uint8_t* accept_out) {
+  int n = nup + ndn, M = d * n;
+  if (n <= 0 || M > FFO_MAXM) return 1;
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < B; b++) {
     const int* ou = nup ? row(tab_up, wstate, b, nup) : NULL;
     const int* od = ndn ? row(tab_dn, wstate, b, ndn) : NULL;
     double x[FFO_MAXM], nx[FFO_MAXM], logp, nl;
     for (int i = 0; i < M; i++) x[i] = g0[b * M + i];
-    logprob_glap(nup, ndn, ou, od, x, &logp, NULL, NULL);
+    logprob_glap_d(nup, ndn, d, ou, od, x, &logp, NULL, NULL);
     for (int s = 0; s < steps; s++) {
       const double* gs = g + ((size_t)s * B + b) * M;
       for (int i = 0; i < M; i++) { double t = tau * gs[i]; nx[i] = x[i] + t; }
-      logprob_glap(nup, ndn, ou, od, nx, &nl, NULL, NULL);
+      logprob_glap_d(nup, ndn, d, ou, od, nx, &nl, NULL, NULL);
       double p = exp(nl - logp);
       int acc = u[(size_t)s * B + b] < p;
       if (acc) { memcpy(x, nx, sizeof(double) * M); logp = nl; }

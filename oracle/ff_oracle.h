@@ -19,6 +19,13 @@ int ffo_logprob(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_d
 int ffo_mcmc_noise(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                    int steps, double tau, const double* g0, const double* g, const double* u,
                    double* x_out, double* logp_out, uint8_t* accept_out);
+/* HO3D counterparts (d = 3; no upstream code: SURVEY 8(f).4) */
+int ffo_orbitals3d(const int* k, int nk, const double* pts, int npts, double* out);
+int ffo_logprob3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                  const double* x, double* logp, double* grad, double* lap);
+int ffo_mcmc_noise3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                     int steps, double tau, const double* g0, const double* g, const double* u,
+                     double* x_out, double* logp_out, uint8_t* accept_out);
 int ffo_backflow(int64_t B, int n, int d, const ffo_net* net, const double* x, double* v, double* div);
 int ffo_potential(int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V);
 int ffo_cnf_generate(int64_t B, int n, int d, const ffo_net* net, double t0, double t1, double rtol, double atol,

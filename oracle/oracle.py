@@ -90,6 +90,34 @@ def logprob(x, nup, ndn, tab_up=None, tab_dn=None, wstate=None, derivs=True):
     return (logp, grad, lap) if derivs else logp
 
 
+def orbitals3d(k, pts):
+    k = _i(k); pts = _d(pts)
+    out = np.empty((len(k), len(pts)))
+    assert lib().ffo_orbitals3d(_p(k), len(k), _p(pts), len(pts), _p(out)) == 0
+    return out
+
+
+def logprob3d(x, nup, ndn, tab_up=None, tab_dn=None, wstate=None, derivs=True):
+    """HO3D (d = 3) log-density, gradient and Laplacian; x (B, n, 3)."""
+    x = _d(x); B = x.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    logp = np.empty(B); grad = np.empty_like(x) if derivs else None; lap = np.empty(B) if derivs else None
+    assert lib().ffo_logprob3d(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), _p(x), _p(logp), _p(grad), _p(lap)) == 0
+    return (logp, grad, lap) if derivs else logp
+
+
+def mcmc_noise3d(g0, g, u, nup, ndn, tau=0.1, tab_up=None, tab_dn=None, wstate=None):
+    g0, g, u = _d(g0), _d(g), _d(u)
+    B, steps = g0.shape[0], g.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    x = np.empty_like(g0); logp = np.empty(B); acc = np.empty((steps, B), dtype=np.uint8)
+    assert lib().ffo_mcmc_noise3d(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), steps, C.c_double(tau), _p(g0), _p(g), _p(u),
+                                  _p(x), _p(logp), acc.ctypes.data_as(C.c_void_p)) == 0
+    return x, logp, acc
+
+
 def mcmc_noise(g0, g, u, nup, ndn, tau=0.1, tab_up=None, tab_dn=None, wstate=None):
     g0, g, u = _d(g0), _d(g), _d(u)
     B = g0.shape[0]; steps = g.shape[0]

@@ -226,3 +226,36 @@ def state_sums(e, ws, nstates):
     e = _d(e); ws = _i(ws); sums = np.empty(nstates); cnt = np.empty(nstates)
     _ck(lib().ff_state_sums(None, C.c_int64(len(e)), int(nstates), _p(ws), _p(e), _p(sums), _p(cnt)))
     return sums, cnt
+
+
+# ---- d = 3 groundwork (csrc/ff_ho3d.hip)
+def logprob3d(x, nup, ndn, tab_up=None, tab_dn=None, wstate=None):
+    x = _d(x); B = x.shape[0]
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    lp = np.empty(B); g = np.empty_like(x); lap = np.empty(B)
+    _ck(lib().ff_logprob3d(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), _p(x), _p(lp), _p(g), _p(lap)))
+    return lp, g, lap
+
+
+def mcmc_noise3d(g0, g, u, nup, ndn, tau=0.1, tab_up=None, tab_dn=None, wstate=None):
+    g0, g, u = _d(g0), _d(g), _d(u); B, steps = g0.shape[0], g.shape[0]
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    x = np.empty_like(g0); lp = np.empty(B); acc = np.empty((steps, B), dtype=np.uint8)
+    _ck(lib().ff_mcmc_sample_noise3d(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), steps, C.c_double(tau), _p(g0), _p(g), _p(u),
+                                     _p(x), _p(lp), acc.ctypes.data_as(C.c_void_p)))
+    return x, lp, acc
+
+
+def mcmc3d(B, nup, ndn, steps, seed, offset=0, tau=0.1, tab_up=None, tab_dn=None):
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn)
+    x = np.empty((B, nup + ndn, 3)); lp = np.empty(B); cnt = np.empty(B, dtype=np.int32)
+    _ck(lib().ff_mcmc_sample3d(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), None, steps, C.c_double(tau), C.c_uint64(seed),
+                               C.c_int64(offset), _p(x), _p(lp), _p(cnt)))
+    return x, lp, cnt
+
+
+def backflow_f32(x, net):
+    x = _d(x); B, n, d = x.shape
+    v = np.empty_like(x); div = np.empty(B)
+    _ck(lib().ff_backflow_v_div_f32(None, C.c_int64(B), n, d, C.byref(net.c), _p(x), _p(v), _p(div)))
+    return v, div

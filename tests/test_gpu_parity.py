@@ -858,3 +858,54 @@ def test_config4_six_plus_six_full_size_known_answer(dev):
     ref = O.eloc(N(model.x[:24]), 6, 6, net, 2.0, rtol=1e-10, atol=1e-12)
     rel = np.abs(N(model.Eloc[:24]) - ref["eloc"]) / np.abs(ref["eloc"])
     assert rel.max() < ELOC_RTOL, rel.max()
+
+
+# ------------------------------------------------------------------------------------------------ three dimensions / fp32
+def test_ho3d_base_distribution(dev):
+    """HO3D orbitals, FreeFermion.log_prob / y_grad_laplacian / sample in d = 3: against the oracle, bit-exact Metropolis on
+    explicit noise, and the eigenfunction known-answer test at BASELINE size: nup = ndown = 10 (closed shells 0..2, the
+    occupation of configs[4]) on 65536 random points, E_loc == 2 (1.5 + 3*2.5 + 6*3.5) = 60."""
+    import fermiflow_amd as ff
+    from fermiflow_amd import native
+    h = ff.HO3D()
+    bd = ff.FreeFermion(device=dev)
+    rng = np.random.RandomState(5)
+    iu, idn = np.sort(rng.choice(20, 3, replace=False)), np.sort(rng.choice(20, 6, replace=False))
+    up, dn = tuple(h.orbitals[k] for k in iu), tuple(h.orbitals[k] for k in idn)
+    x = rng.randn(20, 9, 3)
+    lpo, go, lapo = O.logprob3d(x, 3, 6, tab_up=iu, tab_dn=idn)
+    np.testing.assert_allclose(N(bd.log_prob(up, dn, T(x, dev))), lpo, atol=1e-11)
+    lp, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, up, dn), T(x, dev))
+    np.testing.assert_allclose(N(g), go, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(N(lap), lapo, rtol=1e-8, atol=1e-6)
+    B, S = 64, 50
+    g0, g, u = rng.randn(B, 9, 3), rng.randn(S, B, 9, 3), rng.rand(S, B)
+    xs, lps, acc = bd.sample_with_noise(up, dn, T(g0, dev), T(g, dev), T(u, dev))
+    xo, lpo2, acco = O.mcmc_noise3d(g0, g, u, 3, 6, tab_up=iu, tab_dn=idn)
+    assert (N(acc) == acco).all() and (N(xs) == xo).all()
+    # full size: closed shells, every point an eigenfunction value
+    torch.manual_seed(0)
+    xb = torch.randn(65536, 20, 3, dtype=torch.float64, device=dev)
+    lp, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, tuple(h.orbitals[:10]), tuple(h.orbitals[:10])), xb)
+    eloc = -0.25 * lap - 0.125 * (g ** 2).sum(dim=(1, 2)) + 0.5 * (xb ** 2).sum(dim=(1, 2))
+    assert (eloc - 60.0).abs().max().item() < 1e-6 * 60
+    z = bd.sample(tuple(h.orbitals[:4]), tuple(h.orbitals[:4]), (4096,))          # Philox sampler, d = 3
+    assert z.shape == (4096, 8, 3) and torch.isfinite(z).all()
+    assert abs((z ** 2).mean().item() - (2 * (1.5 + 3 * 2.5) / 8) / 3) < 0.05     # <r^2>/particle = E/particle (virial), per coordinate
+
+
+def test_fp32_backflow_error_report(golden, dev, capsys):
+    """ff_backflow_v_div_f32 against the fp64 kernel on the benchmark's weights, 65536 walkers of six particles: the
+    single-precision error this path would carry (max over walkers, relative to the largest entry)."""
+    from fermiflow_amd import native
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 3, 3, 2.0)
+    net = model.cnf.v_wrapper.v.net(radial="exact")
+    torch.manual_seed(1)
+    x = torch.randn(65536, 6, 2, dtype=torch.float64, device=dev) * 1.3
+    v64, d64 = native.backflow_v_div(net, x)
+    v32, d32 = native.backflow_v_div_f32(net, x)
+    ev = ((v32 - v64).abs().max() / v64.abs().max()).item(); ed = ((d32 - d64).abs().max() / d64.abs().max()).item()
+    with capsys.disabled():
+        print(f"\n[fp32 backflow] max |v32 - v64| / max |v64| = {ev:.2e}, max |div32 - div64| / max |div64| = {ed:.2e}")
+    assert 1e-9 < ev < 5e-5 and ed < 5e-5

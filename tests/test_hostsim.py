@@ -368,3 +368,45 @@ def test_state_sums_of_the_finite_temperature_estimator():
         want_s = np.array([e[ws == k].sum() for k in range(21)])
         assert (c == want_c).all()
         np.testing.assert_allclose(s, want_s, rtol=1e-13, atol=1e-12)
+
+
+HO3D_E = np.array([s + 1.5 for s in range(8) for nx in range(s + 1) for ny in range(s + 1 - nx)])
+
+
+def test_ho3d_logprob_and_sampler(golden):
+    """Groundwork for the 3-D trap (no upstream code): ff_logprob3d against the oracle's jets, the known-answer
+    test of tests/test_basedist.py:5-60 one dimension up (E_loc == sum of orbital energies at random points), and the
+    d = 3 Metropolis chain bit for bit against the oracle on explicit noise."""
+    rng = np.random.RandomState(3)
+    for nup, ndn in ((1, 0), (4, 0), (3, 6), (10, 10)):
+        iu = np.sort(rng.choice(20, nup, replace=False)); idn = np.sort(rng.choice(20, ndn, replace=False)) if ndn else None
+        x = rng.randn(5, nup + ndn, 3)
+        lp, g, lap = S.logprob3d(x, nup, ndn, tab_up=iu, tab_dn=idn)
+        lpo, go, lapo = O.logprob3d(x, nup, ndn, tab_up=iu, tab_dn=idn)
+        np.testing.assert_allclose(lp, lpo, atol=1e-11)
+        np.testing.assert_allclose(g, go, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(lap, lapo, rtol=1e-8, atol=1e-6)
+        eloc = -0.25 * lap - 0.125 * (g ** 2).sum(axis=(1, 2)) + 0.5 * (x ** 2).sum(axis=(1, 2))
+        want = HO3D_E[iu].sum() + (HO3D_E[idn].sum() if ndn else 0.0)
+        np.testing.assert_allclose(eloc, want, rtol=1e-8)
+    B, Ssteps = 24, 30
+    g0, g, u = rng.randn(B, 5, 3), rng.randn(Ssteps, B, 5, 3), rng.rand(Ssteps, B)
+    x, lp, acc = S.mcmc_noise3d(g0, g, u, 3, 2)
+    xo, lpo, acco = O.mcmc_noise3d(g0, g, u, 3, 2)
+    assert (acc == acco).all() and (x == xo).all()
+    np.testing.assert_allclose(lp, lpo, atol=1e-12)
+    xs, lps, cnt = S.mcmc3d(64, 4, 4, 60, 99)          # Philox sampler: closed shells 0..1 for both spins
+    assert np.isfinite(xs).all() and 0.3 < cnt.mean() / 60 < 0.95
+    np.testing.assert_allclose(lps, O.logprob3d(xs, 4, 4, derivs=False), atol=1e-11)
+
+
+def test_fp32_backflow_error_against_fp64(golden):
+    """The fp32 instantiation (ff_backflow_v_div_f32) against the fp64 kernel on the benchmark's weights: relative error
+    of v and div v at the 1e-6 level expected of single precision (reported in DESIGN.md 7)."""
+    G = golden["g3_backflow"]
+    eta, mu = net_arrays(G, "c1_")
+    x = G["c1_x"]
+    v64, d64 = S.backflow(x, S.Net(eta, mu))
+    v32, d32 = S.backflow_f32(x, S.Net(eta, mu))
+    ev = np.abs(v32 - v64).max() / np.abs(v64).max(); ed = np.abs(d32 - d64).max() / np.abs(d64).max()
+    assert 1e-9 < ev < 2e-5 and ed < 2e-5, (ev, ed)

@@ -196,3 +196,21 @@ def test_gsvmc_estimator(golden):
         np.testing.assert_allclose(r["eloc"].mean(), float(G[name + "_E"]), rtol=1e-10)
         np.testing.assert_allclose(r["eloc"].std(ddof=1), float(G[name + "_E_std"]), rtol=1e-8)
         np.testing.assert_allclose((r["logp"] * (r["eloc"] - r["eloc"].mean())).mean(), float(G[name + "_gradE"]), rtol=1e-7, atol=1e-12)
+
+
+def test_ho3d_known_answer_eigenfunctions():
+    """The oracle's HO3D orbitals (no upstream code): orthonormal on a quadrature grid, and Slater determinants
+    of them are eigenfunctions -- E_loc == sum of orbital energies (shell + 3/2) at random points, the reference's
+    tests/test_basedist.py:5-60 one dimension up.  This is what pins the d = 3 oracle (there is no reference to import)."""
+    E3 = np.array([s + 1.5 for s in range(8) for nx in range(s + 1) for ny in range(s + 1 - nx)])
+    ax = np.linspace(-6, 6, 41)
+    pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    v = O.orbitals3d(np.arange(10), pts)
+    np.testing.assert_allclose((v @ v.T) * (12 / 40) ** 3, np.eye(10), atol=1e-12)
+    rng = np.random.RandomState(0)
+    for nup, ndn in ((1, 0), (4, 0), (3, 6), (10, 10)):
+        iu = np.sort(rng.choice(20, nup, replace=False)); idn = np.sort(rng.choice(20, ndn, replace=False)) if ndn else None
+        x = rng.randn(8, nup + ndn, 3)
+        lp, g, lap = O.logprob3d(x, nup, ndn, tab_up=iu, tab_dn=idn)
+        eloc = -0.25 * lap - 0.125 * (g ** 2).sum(axis=(1, 2)) + 0.5 * (x ** 2).sum(axis=(1, 2))
+        np.testing.assert_allclose(eloc, E3[iu].sum() + (E3[idn].sum() if ndn else 0.0), rtol=1e-10)
