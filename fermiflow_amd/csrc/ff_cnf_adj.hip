@@ -527,8 +527,11 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
   if (jB != jA) ff_row_add(sW, ovf, t, jB, accB);
 }
 
+#ifndef FF_ADJ_WPS
+#define FF_ADJ_WPS 1     // waves per SIMD the tabulated adjoint is compiled for (A/B knob: tools/probes/adj_ab.py)
+#endif
 template <int N, int D>
-__global__ void __launch_bounds__(FF_WAVE)
+__global__ void __launch_bounds__(FF_WAVE, FF_ADJ_WPS)
 ff_ode_adjtab_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;

@@ -1305,14 +1305,17 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
   FF_LAUNCH((ff_eloc_rows_kernel<N, D, SPLIT, false>), grid, FF_WAVE, stream, a);
 }
 
+#ifndef FF_MFMA_WPS
+#define FF_MFMA_WPS 1   // waves per SIMD the matrix-core kernel is compiled for (A/B knob)
+#endif
 // Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12
 template <int N, int D>
 static void launch_mfma(void* stream, const ff_fwd_args& a) {
   int64_t ngroups = (a.B + 3) / 4;
-  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
-  if (a.evt) FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true>), grid, FF_WAVE, stream, a);
-  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false>), grid, FF_WAVE, stream, a);
+  if (a.evt) FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, FF_MFMA_WPS>), grid, FF_WAVE, stream, a);
 }
 
 static std::atomic<uint64_t> g_evt_counter{1};

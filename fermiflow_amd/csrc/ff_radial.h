@@ -57,7 +57,9 @@ FF_D void ff_sigma_derivs(double s, double* out) {
 // so the kernel only accumulates Wacc (coefficients ca dr^k/k! + cb dr^(k-1)/(k-1)!) on a coarse grid, h_d = 1/16,
 // expansion order 11, and one small kernel contracts Wacc with dT/dtheta at the end.  Usable while max|w1| h_d <= 0.6.
 #define FF_DEP_INVH 16.0
+#ifndef FF_DEP_NLDS
 #define FF_DEP_NLDS 128                     // nodes kept in LDS (r < 8); the rest (r < 32) goes to a global table
+#endif
 #define FF_DEP_NTOT 512
 #define FF_DEP_ROW 12                       // T_0 .. T_11
 

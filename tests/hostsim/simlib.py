@@ -31,8 +31,10 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        build()
-        _LIB = C.CDLL(os.path.join(HERE, "libff_hostsim.so"))
+        alt = os.environ.get("FF_HOSTSIM_LIB")     # e.g. a build of the same sources under the address / UB sanitizers
+        if not alt:
+            build()
+        _LIB = C.CDLL(alt or os.path.join(HERE, "libff_hostsim.so"))
         _LIB.ff_last_error.restype = C.c_char_p
         _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
         _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
