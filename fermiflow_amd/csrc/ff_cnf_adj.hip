@@ -920,7 +920,7 @@ extern void ff_set_error(const char* msg);
 #include <stdlib.h>
 static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
-static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? FF_WAVE / M : 0; }
+static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? (FF_WAVE / M > 16 ? 16 : FF_WAVE / M) : 0; }   // = ff_geom<N,D>::G
 // Persistent grid: one wave per SIMD.  Every walker takes the same few steps here, so a static split is balanced, and
 // each workgroup flushes a private deposit table (25 KB) at its end -- the fewer workgroups the less HBM traffic
 // (measured, 65536 walkers: 4096 workgroups 1.09 ms, 1024 workgroups 0.92 ms).
