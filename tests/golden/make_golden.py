@@ -282,6 +282,7 @@ def g_gsvmc(R_unused):
         "z2_nt": (3, 3, 2.0, "nt", 32, 3, True),
         "u6_nt": (6, 0, 0.5, "nt", 8, 4, True),
         "z2_nomu": (3, 3, 2.0, "nt", 8, 5, False),
+        "u6d6_nt": (6, 6, 2.0, "nt", 4, 6, True),      # BASELINE.json configs[3] shape (n = 12): the reference's own numbers
     }
     only = os.environ.get("FF_GSVMC_CASES")
     for name, (nup, ndown, Z, w, B, seed, use_mu) in cases.items():

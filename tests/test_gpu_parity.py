@@ -194,7 +194,7 @@ def test_cnf_reversibility_full_size(golden, dev):
 
 
 # ------------------------------------------------------------------------------------------------ E_loc
-@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu"])
+@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu", "u6d6_nt"])
 def test_local_energy_vs_reference(golden, dev, name):
     import fermiflow_amd as ff
     G = golden["g5_gsvmc"]
@@ -263,7 +263,7 @@ def test_gsvmc_iteration_statistics_and_oracle(golden, dev):
 
 @pytest.mark.parametrize("name,rt,at,vtol,gtol", [("z2_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("z2_nt", 1e-6, 1e-8, 1e-5, 1e-5),
                                                   ("z05_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("u6_nt", 1e-10, 1e-12, 1e-7, 1e-6),
-                                                  ("z2_nomu", 1e-10, 1e-12, 1e-7, 1e-6)])
+                                                  ("z2_nomu", 1e-10, 1e-12, 1e-7, 1e-6), ("u6d6_nt", 1e-10, 1e-12, 1e-7, 1e-6)])
 def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gtol):
     """GSVMC.forward -> .backward() END TO END (src/VMC.py:40-59, src/FermionHO2D.py:69-72) on the reference's base
     walkers z, through the production sweep (flow with cost classes, cost-ordered local-energy pass, step-size warm

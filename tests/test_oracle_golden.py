@@ -86,7 +86,7 @@ def test_cnf_same_step_sequence_as_reference(golden, tag, rt, at):
     np.testing.assert_allclose(gp, ref, atol=1e-12 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu"])
+@pytest.mark.parametrize("name", ["z0_zero", "z2_zero", "z05_nt", "z2_nt", "u6_nt", "z2_nomu", "u6d6_nt"])
 def test_local_energy(golden, name):
     """E_loc, logp, grad logp, laplacian logp per walker vs the reference's nested-adjoint autograd."""
     G = golden["g5_gsvmc"]
