@@ -1008,10 +1008,10 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
   // (no table / weights too stiff for the deposit grid -> direct evaluation), so the host never has to look at it
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
   FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2) else FF_ND(5, 2) else FF_ND(8, 2) else FF_ND(10, 2)
-  else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2)
+  else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2) else FF_ND(2, 3) else FF_ND(3, 3) else FF_ND(4, 3)
 #undef FF_ND
   if (G == 0) {
-    ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2");
+    ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2 and n = 2..4 in d = 3");
     return FF_EUNSUPPORTED;
   }
   FF_LAUNCH_CHECK();

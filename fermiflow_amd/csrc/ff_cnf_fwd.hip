@@ -24,6 +24,7 @@
 #include "ff_common.h"
 #include "ff_ode.h"
 #include "ff_slater.h"
+#include "ff_eloc_ws.h"
 #define FF_RADIAL_BUILD_KERNELS
 #include "ff_radial.h"
 
@@ -1343,11 +1344,12 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)
 #undef FF_MF
   }
-  const bool no_columns = n == 1 || n == 7 || n == 9 || n == 11;
+  const bool no_columns = n == 1 || n == 7 || n == 9 || n == 11 || d == 3;
   if (MODE == 2 && (eloc_kind == 2 || no_columns || (eloc_kind == 0 && n >= 9))) {
 #define FF_RW(N_, D_, S_) if (n == N_ && d == D_) { launch_rows<N_, D_, S_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_RW(6, 2, 1) FF_RW(2, 2, 1) FF_RW(3, 2, 1) FF_RW(4, 2, 1) FF_RW(5, 2, 1) FF_RW(7, 2, 2) FF_RW(8, 2, 2) FF_RW(9, 2, 3)
     FF_RW(10, 2, 3) FF_RW(11, 2, 2) FF_RW(12, 2, 2) FF_RW(1, 2, 1)
+    FF_RW(2, 3, 1) FF_RW(3, 3, 1) FF_RW(4, 3, 1)      // three dimensions (small systems; finish: ff_eloc_finish3d)
 #undef FF_RW
   }
   if (MODE == 2 && d == 2 && !getenv("FF_NO_SPLIT")) {
@@ -1357,9 +1359,9 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   }
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
   FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
-  if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) }   // (their local-energy pass is the row-layout kernel above)
+  if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) FF_ND(2, 3) FF_ND(3, 3) FF_ND(4, 3) }   // (their local-energy pass is the row-layout kernel above)
 #undef FF_ND
-  ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2");
+  ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2 and n = 2..4 in d = 3");
   return FF_EUNSUPPORTED;
 }
 
@@ -1417,25 +1419,9 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   return dispatch_fwd<1>(stream, n, d, a);
 }
 
-// sensitivities (z0, Jt, kbar, dD, Lpart, Delta) + the Slater table of the finish (g0, S, T <= 2 n^2, logp0)
+// sensitivities (z0, Jt, kbar, dD, Lpart, Delta) + the Slater table of the finish: layout in ff_eloc_ws.h
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
-  size_t M = (size_t)n * d;
-  return sizeof(double) * ((size_t)B * (M * M + 4 * M + 1 + M + 3 * (size_t)n + 2 * (size_t)n * n + 2) + 2);   // + the work counters
-}
-
-struct ff_eloc_ws { double *z0, *Jt, *kbar, *dD, *Lp, *dl, *Q; unsigned long long* queue; };
-static ff_eloc_ws eloc_carve(void* workspace, int64_t B, size_t M) {
-  double* w = (double*)workspace;
-  ff_eloc_ws o;
-  o.z0 = w;   w += (size_t)B * M;
-  o.Jt = w;   w += (size_t)B * M * M;
-  o.kbar = w; w += (size_t)B * M;
-  o.dD = w;   w += (size_t)B * M;
-  o.Lp = w;   w += (size_t)B * M;
-  o.dl = w;   w += (size_t)B;
-  o.Q = w;
-  o.queue = (unsigned long long*)((double*)workspace + (size_t)B * (M * M + 4 * M + 1 + M + 3 * (M / 2) + 2 * (M / 2) * (M / 2) + 2));
-  return o;
+  return sizeof(double) * ff_eloc_ws_doubles(B, (size_t)n, (size_t)d);
 }
 
 /* pass 1 of ff_eloc: the fused sensitivity integration (results stay in `workspace`) */
@@ -1445,7 +1431,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   if (st) return st;
   FF_CHECK(x && workspace, FF_EINVAL, "ff_eloc_sensitivities: null pointer");
   if (B == 0) return FF_OK;
-  ff_eloc_ws w = eloc_carve(workspace, B, (size_t)n * d);
+  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, (size_t)d);
   ff_fwd_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
@@ -1471,7 +1457,7 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
   FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_eloc_finish: determinant larger than FF_MAX_NS");
   if (B == 0) return FF_OK;
   const size_t M = (size_t)n * 2;
-  ff_eloc_ws w = eloc_carve((void*)workspace, B, M);
+  ff_eloc_ws w = ff_eloc_carve((void*)workspace, B, (size_t)n, 2);
   FF_CHECK(2 * n <= FF_WAVE, FF_EUNSUPPORTED, "ff_eloc_finish: n*d > 64");
   {
     const int nsf = (nup == ndn || ndn == 0) ? nup : (nup == 0 ? ndn : 0);   // one determinant size for both spin species

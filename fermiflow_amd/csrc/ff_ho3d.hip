@@ -12,6 +12,7 @@
 #include "ff_common.h"
 #include "ff_slater.h"
 #include "ff_rng.h"
+#include "ff_eloc_ws.h"
 
 #ifdef FF_HOSTSIM
 #define __expf expf
@@ -254,6 +255,183 @@ ff_backflow_f32_kernel(int64_t B, int n, int d, ff_net net, const double* __rest
   if (div) div[b] = (double)dv;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Local-energy finish in d = 3 (the d = 2 one: ff_eloc_slater_kernel / ff_eloc_contract_kernel in ff_cnf_fwd.hip): the
+// sensitivities come from ff_eloc_sensitivities(..., d = 3) (row-layout kernel); here the Slater gradient / Hessian at z(t0):
+//   grad_i = g0 . u_i - dDelta_i,   lap = sum_i u_i^T H0 u_i + g0 . kbar - sum_i L_i,   E_loc = -lap/4 - |grad|^2/8 + V(x)
+// with H0 of 2 log|det|: same-particle block sum_j hess phi_j(r_a) Dinv_ja - g_a g_a^T, cross block -T_ac (x) T_ca
+// (T_ac = sum_j grad phi_j(r_a) Dinv_jc) -- SURVEY.md A.2 / A.6 with one more coordinate.
+// Q slots per walker: [0,M) g0 | [M, M+6n) S (xx,xy,xz,yy,yz,zz per particle) | T_up (3 nup^2, component-major) | T_dn | 2 log|det| per spin
+template <bool DERIV>
+FF_D void ff_orbital3d_hess(int k, const double* r, double gauss, double& v, double* g, double* hs) {
+  int n[3];
+  ff_ho3d_decode(k, n[0], n[1], n[2]);
+  double h[3], h1[3], h2[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) ff_herm<true>(n[c], r[c], h[c], h1[c], h2[c]);
+  double p1[3], p2[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { p1[c] = h1[c] - r[c] * h[c]; p2[c] = h2[c] - 2.0 * r[c] * h1[c] + (r[c] * r[c] - 1.0) * h[c]; }
+  v = gauss * h[0] * h[1] * h[2];
+  g[0] = gauss * p1[0] * h[1] * h[2]; g[1] = gauss * h[0] * p1[1] * h[2]; g[2] = gauss * h[0] * h[1] * p1[2];
+  hs[0] = gauss * p2[0] * h[1] * h[2]; hs[1] = gauss * p1[0] * p1[1] * h[2]; hs[2] = gauss * p1[0] * h[1] * p1[2];
+  hs[3] = gauss * h[0] * p2[1] * h[2]; hs[4] = gauss * h[0] * p1[1] * p1[2]; hs[5] = gauss * h[0] * h[1] * p2[2];
+}
+
+__global__ void __launch_bounds__(64)
+ff_eloc_slater3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                        const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1);
+  if (b >= B) return;
+  const int n = nup + ndn, M = 3 * n, st = wstate ? wstate[b] : 0;
+  const int64_t nq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + 2;
+  double* q = Q + b * nq;
+  const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+  const int lpq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + sp;
+  if (!ns) { q[lpq] = 0.0; return; }
+  const int* orb = (sp ? tab_dn : tab_up) + st * ns;
+  double x[3 * FF_MAX_NS], A[FF_MAX_NS * FF_MAX_NS], Inv[FF_MAX_NS * FF_MAX_NS];
+  for (int k = 0; k < 3 * ns; k++) x[k] = z0[b * M + 3 * off + k];
+  for (int i = 0; i < ns; i++) {
+    const double gs = ff_gauss3d(x + 3 * i);
+    for (int j = 0; j < ns; j++) {
+      double v, lp;
+      ff_orbital3d<false>(orb[j], x + 3 * i, gs, v, nullptr, lp);
+      A[i * ns + j] = v; Inv[i * ns + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  double acc = 0.0;
+  for (int c = 0; c < ns; c++) {
+    int p = c;
+    double best = fabs(A[c * ns + c]);
+    for (int r = c + 1; r < ns; r++) { const double a = fabs(A[r * ns + c]); if (a > best) { best = a; p = r; } }
+    if (p != c)
+      for (int j = 0; j < ns; j++) {
+        double t = A[c * ns + j]; A[c * ns + j] = A[p * ns + j]; A[p * ns + j] = t;
+        t = Inv[c * ns + j]; Inv[c * ns + j] = Inv[p * ns + j]; Inv[p * ns + j] = t;
+      }
+    const double piv = A[c * ns + c];
+    acc += log(fabs(piv));
+    const double ip = 1.0 / piv;
+    for (int j = 0; j < ns; j++) { A[c * ns + j] *= ip; Inv[c * ns + j] *= ip; }
+    for (int r = 0; r < ns; r++) {
+      if (r == c) continue;
+      const double f = A[r * ns + c];
+      for (int j = 0; j < ns; j++) { A[r * ns + j] = fma(-f, A[c * ns + j], A[r * ns + j]); Inv[r * ns + j] = fma(-f, Inv[c * ns + j], Inv[r * ns + j]); }
+    }
+  }
+  double* T = q + M + 6 * n + (sp ? 3 * nup * nup : 0);     // [comp][a][b]
+  for (int a = 0; a < ns; a++) {
+    const double gs = ff_gauss3d(x + 3 * a);
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int bb = 0; bb < ns; bb++) { T[a * ns + bb] = 0.0; T[ns * ns + a * ns + bb] = 0.0; T[2 * ns * ns + a * ns + bb] = 0.0; }
+    for (int j = 0; j < ns; j++) {
+      double v, gj[3], hj[6];
+      ff_orbital3d_hess<true>(orb[j], x + 3 * a, gs, v, gj, hj);
+      for (int bb = 0; bb < ns; bb++) {
+        const double di = Inv[j * ns + bb];
+        T[a * ns + bb] = fma(gj[0], di, T[a * ns + bb]);
+        T[ns * ns + a * ns + bb] = fma(gj[1], di, T[ns * ns + a * ns + bb]);
+        T[2 * ns * ns + a * ns + bb] = fma(gj[2], di, T[2 * ns * ns + a * ns + bb]);
+      }
+      const double da = Inv[j * ns + a];
+      for (int e = 0; e < 6; e++) S[e] = fma(hj[e], da, S[e]);
+    }
+    for (int c = 0; c < 3; c++) q[3 * (off + a) + c] = 2.0 * T[c * ns * ns + a * ns + a];     // g0 = 2 grad log|det|
+    for (int e = 0; e < 6; e++) q[M + 6 * (off + a) + e] = S[e];
+  }
+  q[lpq] = 2.0 * acc;
+}
+
+static size_t ff_contract3d_lds_bytes(int nup, int ndn) {
+  const int n = nup + ndn, M = 3 * n, G = FF_WAVE / M, nq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + 2;
+  return sizeof(double) * ((size_t)G * M * M + (size_t)G * nq + 4 * FF_WAVE);
+}
+__global__ void __launch_bounds__(FF_WAVE)
+ff_eloc_contract3d_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, const double* __restrict__ x,
+                          const double* __restrict__ Q, const double* __restrict__ Jt, const double* __restrict__ kbar,
+                          const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
+                          double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
+                          double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
+  FF_DYN_LDS(ff_fin3_lds);
+  const int n = nup + ndn, M = 3 * n, G = FF_WAVE / M;
+  const int lane = threadIdx.x, g = lane / M, i = lane - g * M;
+  const bool ingrp = g < G;
+  const int nq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + 2;
+  double* const s_u = ff_fin3_lds;                           // [g][i][k] = dz_k/dx_i
+  double* const s_q = s_u + G * M * M;
+  double* const s_x = s_q + G * nq;
+  double (*const s_red)[FF_WAVE] = (double (*)[FF_WAVE])(s_x + FF_WAVE);
+  const int64_t ngroups = (B + G - 1) / G;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t b0 = grp * G, b = b0 + g;
+    const bool valid = ingrp && b < B;
+    const int nw = (int)((B - b0) < G ? (B - b0) : G);
+    __syncthreads();
+    for (int e = lane; e < nw * M * M; e += FF_WAVE) s_u[e] = Jt[b0 * M * M + e];
+    for (int e = lane; e < nw * nq; e += FF_WAVE) s_q[e] = Q[b0 * nq + e];
+    if (valid) s_x[lane] = x[b * M + i];
+    __syncthreads();
+    double gi = 0.0, lap_i = 0.0, v_i = 0.0;
+    if (valid) {
+      const double* u = s_u + (g * M + i) * M;
+      const double* qw = s_q + g * nq;
+      const double* g0 = qw;
+      for (int k = 0; k < M; k++) gi = fma(g0[k], u[k], gi);
+      gi -= dD[b * M + i];
+      double hq = 0.0;
+      for (int sp = 0; sp < 2; sp++) {
+        const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+        if (!ns) continue;
+        const double* T = qw + M + 6 * n + (sp ? 3 * nup * nup : 0);
+        double q = 0.0;
+        for (int a = 0; a < ns; a++) {
+          const double* ua = u + 3 * (off + a);
+          const double* Sa = qw + M + 6 * (off + a);
+          q += ua[0] * ua[0] * Sa[0] + 2.0 * ua[0] * ua[1] * Sa[1] + 2.0 * ua[0] * ua[2] * Sa[2] + ua[1] * ua[1] * Sa[3]
+             + 2.0 * ua[1] * ua[2] * Sa[4] + ua[2] * ua[2] * Sa[5];
+          for (int c = 0; c < ns; c++) {
+            const double* uc = u + 3 * (off + c);
+            double Wac = 0.0, Wca = 0.0;
+            for (int cm = 0; cm < 3; cm++) {
+              Wac = fma(ua[cm], T[cm * ns * ns + a * ns + c], Wac);
+              Wca = fma(uc[cm], T[cm * ns * ns + c * ns + a], Wca);
+            }
+            q -= Wac * Wca;
+          }
+        }
+        hq += 2.0 * q;
+      }
+      lap_i = hq - Lpart[b * M + i] + g0[i] * kbar[b * M + i];
+      if (i % 3 == 0) {     // the lane of particle a's x-coordinate takes a's trap term and its pairs with the later particles
+        const int a = i / 3;
+        const double* xs = s_x + g * M;
+        double pair = 0.0;
+        for (int c = a + 1; c < n; c++) {
+          const double dx = xs[3 * a] - xs[3 * c], dy = xs[3 * a + 1] - xs[3 * c + 1], dz = xs[3 * a + 2] - xs[3 * c + 2];
+          pair += Zc / sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        v_i = pair + (use_ho ? 0.5 * (xs[3 * a] * xs[3 * a] + xs[3 * a + 1] * xs[3 * a + 1] + xs[3 * a + 2] * xs[3 * a + 2]) : 0.0);
+      }
+      if (grad) grad[b * M + i] = gi;
+      if (glogp0) glogp0[b * M + i] = g0[i];
+    }
+    s_red[0][lane] = gi * gi; s_red[1][lane] = lap_i; s_red[2][lane] = v_i;
+    __syncthreads();
+    if (valid && i == 0) {
+      double g2 = 0.0, lapv = 0.0, Vv = 0.0;
+      for (int k = 0; k < M; k++) { g2 += s_red[0][g * M + k]; lapv += s_red[1][g * M + k]; Vv += s_red[2][g * M + k]; }
+      if (logp) logp[b] = (s_q[g * nq + nq - 2] + s_q[g * nq + nq - 1]) - delta[b];
+      if (lap) lap[b] = lapv;
+      if (V) V[b] = Vv;
+      if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv;
+    }
+  }
+}
+
 // =================================================================================================
 extern void ff_set_error(const char* msg);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
@@ -309,6 +487,38 @@ int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* n
   if (B == 0) return FF_OK;
   FF_LAUNCH(ff_backflow_f32_kernel, ff3_grid(B, 128), 128, stream, B, n, d, *net, x, v, div);
   FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+
+int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                     double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                     double* glogp0_out) {
+  const int n = nup + ndn;
+  FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && n > 0 && x && workspace, FF_EINVAL, "ff_eloc_finish3d: bad argument");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc_finish3d: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS && 3 * n <= FF_WAVE, FF_EUNSUPPORTED, "ff_eloc_finish3d: walker too large");
+  if (B == 0) return FF_OK;
+  const size_t M = (size_t)n * 3;
+  ff_eloc_ws w = ff_eloc_carve((void*)workspace, B, (size_t)n, 3);
+  FF_LAUNCH(ff_eloc_slater3d_kernel, ff3_grid(2 * B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q);
+  FF_LAUNCH_CHECK();
+  {
+    const int Gf = FF_WAVE / (3 * n);
+    const int64_t ng = (B + Gf - 1) / Gf;
+    FF_LAUNCH_LDS(ff_eloc_contract3d_kernel, (unsigned)(ng < 32768 ? ng : 32768), FF_WAVE, ff_contract3d_lds_bytes(nup, ndn), stream, B, nup, ndn, Z,
+                  use_ho, x, (const double*)w.Q, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
+                  (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+  }
+  FF_LAUNCH_CHECK();
+#ifdef FF_HOSTSIM
+  if (z_out) memcpy(z_out, w.z0, sizeof(double) * (size_t)B * M);
+  if (dlogp_out) memcpy(dlogp_out, w.dl, sizeof(double) * (size_t)B);
+#else
+  if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+#endif
   return FF_OK;
 }
 

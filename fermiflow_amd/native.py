@@ -181,21 +181,22 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity kernel
     only (bench.py times the dominant kernel with it)."""
     x = L.dev(x, name="x")
-    B, n = x.shape[0], nup + ndn
+    B, n, d = x.shape[0], nup + ndn, x.shape[2]
     f = dict(dtype=torch.float64, device=x.device)
     out = dict(logp=torch.empty(B, **f), grad=torch.empty_like(x), lap=torch.empty(B, **f), V=torch.empty(B, **f),
                eloc=torch.empty(B, **f), z=torch.empty_like(x), dlogp=torch.empty(B, **f), glogp0=torch.empty_like(x))
-    nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, 2)
+    nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, d)
     ws = torch.empty(max(1, nbytes // 8), **f)
     st = _stats(x.device, want_stats)
     o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     if pass1_events is not None:
         pass1_events[0].record()
-    L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, 2, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),
+    L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),
             "ff_eloc_sensitivities")
     if pass1_events is not None:
         pass1_events[1].record()
-    L.check(L.lib().ff_eloc_finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+    finish = L.lib().ff_eloc_finish3d if d == 3 else L.lib().ff_eloc_finish      # d = 3: HO3D orbital tables (csrc/ff_ho3d.hip)
+    L.check(finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
                                    L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(ws), L.ptr(out["logp"]), L.ptr(out["grad"]),
                                    L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), L.ptr(out["z"]),
                                    L.ptr(out["dlogp"]), L.ptr(out["glogp0"])), "ff_eloc_finish")

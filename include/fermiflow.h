@@ -197,6 +197,12 @@ int ff_mcmc_sample_noise3d(void* stream, int64_t B, int nup, int ndn, const int3
 int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
                      const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
                      double* x_out, double* logp_out, int32_t* accept_count);
+/* Local-energy finish for d = 3 (pass 1: ff_eloc_sensitivities with d = 3, n = 2..4; workspace: ff_eloc_workspace_bytes(B, n, 3));
+ * arguments as ff_eloc_finish, walkers (B, n, 3), HO3D orbital tables. */
+int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                     const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                     double* logp, double* grad, double* lap, double* V, double* eloc,
+                     double* z_out, double* dlogp_out, double* glogp0_out);
 /* Backflow.forward / .divergence (src/equivariant_funs.py:83-102) with radii, sigmoid sums and accumulations in fp32
  * (fp64 arrays at the boundary): the single-precision instantiation whose error against ff_backflow_v_div the tests report. */
 int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div);

@@ -463,10 +463,24 @@ static void rhs_walker_o2(void* vctx, double t, const double* y, double* dy) {
   (void)t; walker_ctx* c = (walker_ctx*)vctx; rhs_xlogp_o2(c->net, c->n, c->d, y, dy);
 }
 
+static int eloc_any(int64_t B, int nup, int ndn, int d, const int* tab_up, const int* tab_dn, const int* wstate,
+                    const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
+                    const double* x, double* logp, double* grad, double* lap, double* V, double* eloc);
 int ffo_eloc(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
              const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
              const double* x, double* logp, double* grad, double* lap, double* V, double* eloc) {
-  int n = nup + ndn, d = 2, M = n * d, len = M + 1;
+  return eloc_any(B, nup, ndn, 2, tab_up, tab_dn, wstate, net, t0, t1, rtol, atol, Zc, use_ho, x, logp, grad, lap, V, eloc);
+}
+/* the same in three dimensions (HO3D orbitals; no upstream code) */
+int ffo_eloc3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+               const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
+               const double* x, double* logp, double* grad, double* lap, double* V, double* eloc) {
+  return eloc_any(B, nup, ndn, 3, tab_up, tab_dn, wstate, net, t0, t1, rtol, atol, Zc, use_ho, x, logp, grad, lap, V, eloc);
+}
+static int eloc_any(int64_t B, int nup, int ndn, int d, const int* tab_up, const int* tab_dn, const int* wstate,
+                    const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
+                    const double* x, double* logp, double* grad, double* lap, double* V, double* eloc) {
+  int n = nup + ndn, M = n * d, len = M + 1;
   if (M > FFO_MAXM) return 1;
   int fail = 0;
   double* Vloc = V ? V : (double*)malloc(sizeof(double) * B);
@@ -485,7 +499,7 @@ int ffo_eloc(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, 
       if (st) fail = 1;
       jet_o2 zj[FFO_MAXM + 1];
       unpack_o2(y, len, zj);
-      jet_o2 r = jsub_o2(logprob_o2(nup, ndn, ou, od, zj), zj[M]);
+      jet_o2 r = jsub_o2(logprob_d_o2(nup, ndn, d, ou, od, zj), zj[M]);
       lp = r.v; l += r.d2; g2 += r.d1 * r.d1;
       if (grad) grad[b * M + i] = r.d1;
     }

@@ -26,6 +26,9 @@ int ffo_logprob3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab
 int ffo_mcmc_noise3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                      int steps, double tau, const double* g0, const double* g, const double* u,
                      double* x_out, double* logp_out, uint8_t* accept_out);
+int ffo_eloc3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+               const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
+               const double* x, double* logp, double* grad, double* lap, double* V, double* eloc);
 int ffo_backflow(int64_t B, int n, int d, const ffo_net* net, const double* x, double* v, double* div);
 int ffo_potential(int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V);
 int ffo_cnf_generate(int64_t B, int n, int d, const ffo_net* net, double t0, double t1, double rtol, double atol,

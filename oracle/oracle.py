@@ -185,6 +185,19 @@ def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8,
     return dict(logp=logp, grad=grad, lap=lap, V=V, eloc=el)
 
 
+def eloc3d(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None):
+    """Local energy in three dimensions (HO3D orbitals); x (B, n, 3)."""
+    x = _d(x); B = x.shape[0]
+    tu, td = _tables(nup, ndn, tab_up, tab_dn)
+    ws = _i(wstate) if wstate is not None else None
+    logp = np.empty(B); grad = np.empty_like(x); lap = np.empty(B); V = np.empty(B); el = np.empty(B)
+    st = lib().ffo_eloc3d(C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), net.ref(), C.c_double(t0), C.c_double(t1),
+                          C.c_double(rtol), C.c_double(atol), C.c_double(Z), int(use_ho), _p(x),
+                          _p(logp), _p(grad), _p(lap), _p(V), _p(el))
+    assert st == 0, st
+    return dict(logp=logp, grad=grad, lap=lap, V=V, eloc=el)
+
+
 def gsvmc_sweep(B, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=100, tau=0.1, seed=0):
     E = C.c_double(); Es = C.c_double(); gE = C.c_double()
     gp = np.empty(net.nparams); tm = np.empty(5)

@@ -261,3 +261,19 @@ def backflow_f32(x, net):
     v = np.empty_like(x); div = np.empty(B)
     _ck(lib().ff_backflow_v_div_f32(None, C.c_int64(B), n, d, C.byref(net.c), _p(x), _p(v), _p(div)))
     return v, div
+
+
+def eloc3d(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None):
+    """ff_eloc_sensitivities (d = 3) + ff_eloc_finish3d."""
+    x = _d(x); B = x.shape[0]; n = nup + ndn
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    o = dict(logp=np.empty(B), grad=np.empty_like(x), lap=np.empty(B), V=np.empty(B), eloc=np.empty(B),
+             z=np.empty_like(x), dlogp=np.empty(B), glogp0=np.empty_like(x))
+    stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    wk = np.zeros(lib().ff_eloc_workspace_bytes(C.c_int64(B), n, 3) // 8)
+    _ck(lib().ff_eloc_sensitivities(None, C.c_int64(B), n, 3, C.byref(net.c), C.byref(ode), _p(x), _p(wk), _p(stats)))
+    _ck(lib().ff_eloc_finish3d(None, C.c_int64(B), nup, ndn, _p(tu), _p(td), _p(ws), C.c_double(Z), int(use_ho), _p(x), _p(wk),
+                               _p(o["logp"]), _p(o["grad"]), _p(o["lap"]), _p(o["V"]), _p(o["eloc"]), _p(o["z"]), _p(o["dlogp"]),
+                               _p(o["glogp0"])))
+    o["stats"] = stats
+    return o

@@ -913,3 +913,35 @@ def test_fp32_backflow_error_report(golden, dev, capsys):
     with capsys.disabled():
         print(f"\n[fp32 backflow] max |v32 - v64| / max |v64| = {ev:.2e}, max |div32 - div64| / max |div64| = {ed:.2e}")
     assert 1e-9 < ev < 5e-5 and ed < 5e-5
+
+
+def test_gsvmc_sweep_in_three_dimensions(dev):
+    """A whole VMC iteration with HO3D orbitals (nup = ndown = 2, walkers (B, 4, 3)): the d = 3 sampler, the fused flow /
+    sensitivity / adjoint kernels with D = 3 and the d = 3 finish.  Zero flow, Z = 0: E = 2 (1.5 + 2.5) = 8 for every walker;
+    with the benchmark's flow: per-walker E_loc against the oracle."""
+    import fermiflow_amd as ff
+    import __graft_entry__ as Gm
+
+    def build(Z, zero):
+        gs = Gm._model(dev, 2, 2, Z)
+        if zero:
+            for p in gs.parameters():
+                torch.nn.init.zeros_(p)
+        return ff.GSVMC(2, 2, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(Z), sp_potential=ff.HO())
+    model = build(0.0, True)
+    torch.manual_seed(4)
+    g = model(8192)
+    g.backward()
+    assert model.x.shape == (8192, 4, 3)
+    assert (model.Eloc - 8.0).abs().max().item() < 1e-7 and abs(model.E - 8.0) < 1e-9
+    model = build(2.0, False)
+    torch.manual_seed(5)
+    g = model(4096)
+    g.backward()
+    v = model.cnf.v_wrapper.v
+    net = O.Net(tuple(N(t) for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
+                tuple(N(t) for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+    ref = O.eloc3d(N(model.x[:48]), 2, 2, net, 2.0, rtol=1e-10, atol=1e-12)
+    rel = np.abs(N(model.Eloc[:48]) - ref["eloc"]) / np.abs(ref["eloc"])
+    assert rel.max() < ELOC_RTOL, rel.max()
+    assert np.isfinite(model.E) and all(torch.isfinite(p.grad).all() for p in model.parameters())
