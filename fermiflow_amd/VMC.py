@@ -64,6 +64,13 @@ class _Sweep:
         # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
         # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
         self._h_scale_eloc = 0.6 if n <= 8 else (0.45 if n <= 10 else 0.4)
+        # tolerance of the sensitivity components (ff_ode.walker_sens_tol): walkers whose flow-pass cost
+        # class is <= sens_tol_class integrate J, the Laplacian of z and the Delta derivatives at sens_tol x rtol/atol and
+        # open with _h_scale_loose x the flow's step; the others (close approaches) keep rtol/atol.  FERMIFLOW_SENS_TOL=1
+        # restores one tolerance for everything.
+        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "10"))
+        self.sens_tol_class = 8
+        self._h_scale_loose = 1.0
 
     def _mark(self, ev, name):
         if self.profile is not None:
@@ -105,12 +112,18 @@ class _Sweep:
             self._h_flow = hg if per_walker_h else hg.mean().reshape(1)
         he = torch.empty_like(hg) if warm else None
         order = native.walker_order(cost)
+        hin, hscale, sens = hg, self._h_scale_eloc, None
+        if self.sens_tol > 1.0:
+            loose = cost <= self.sens_tol_class
+            sens = torch.where(loose, self.sens_tol, 1.0).to(torch.float64)
+            if warm and self._h_scale_loose != self._h_scale_eloc:
+                hin, hscale = hg * torch.where(loose, self._h_scale_loose, self._h_scale_eloc).to(torch.float64), 1.0
         self._mark(ev, "generate")
         p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
         r = native.eloc(tu, td, nup, ndown, net, x, t0, t1, self.cnf.rtol, self.cnf.atol,
                         getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None, walker_state=walker_state,
                         want_stats=prof is not None, pass1_events=p1, walker_order=order,
-                        walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he)
+                        walker_h_init=hin, walker_h_scale=hscale, walker_h_out=he, walker_sens_tol=sens)
         self._mark(ev, "eloc")
         if prof is not None:
             prof.setdefault("pass1", []).append(p1)

@@ -30,7 +30,7 @@ class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
-                ("walker_h_uniform", C.c_int32)]
+                ("walker_sens_tol", C.c_void_p), ("walker_h_uniform", C.c_int32)]
 
 
 def lib():
@@ -124,14 +124,15 @@ class Net:
 
 
 def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, walker_h_init=None, walker_h_scale=1.0,
-        walker_h_out=None, walker_h_uniform=False):
+        walker_h_out=None, walker_h_uniform=False, walker_sens_tol=None):
     """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
     walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start);
     walker_h_uniform: walker_h_init is a 1-element tensor, the first step of every walker."""
     for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),
-                          ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64)):
+                          ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64),
+                          ("walker_sens_tol", walker_sens_tol, torch.float64)):
         if tns is not None and not (tns.dtype == dt and tns.is_contiguous() and tns.is_cuda):
             raise ValueError(f"{name} must be a contiguous {dt} device tensor")
     p = lambda t: t.data_ptr() if t is not None else None
     return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps), p(walker_cost), p(walker_order),
-                 p(walker_h_init), float(walker_h_scale), p(walker_h_out), int(bool(walker_h_uniform)))
+                 p(walker_h_init), float(walker_h_scale), p(walker_h_out), p(walker_sens_tol), int(bool(walker_h_uniform)))

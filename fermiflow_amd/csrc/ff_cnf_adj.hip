@@ -105,11 +105,14 @@ ff_ode_adj_kernel(ff_adj_args A) {
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
-    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
+    const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
     double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
-    y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
-    y[1] = valid ? A.az_in[b * M + i] : 0.0;
-    if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
+    y[0] = ff_opt_load(A.z_in, valid, b * M + i, A.z_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
+    y[1] = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0);
+    {
+      const double ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
+      if (ingrp && i == 0) s_ad[g] = ad0;
+    }
     // tent = B0*k0_theta + sum_{s=2..5} B_s*k_s_theta of the step under way (dropped if the step is rejected)
     double tent[2][MAXU][3];
 #pragma unroll
@@ -121,7 +124,7 @@ ff_ode_adj_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -588,17 +591,20 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
-    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
+    const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
     double y[NV], k0[NV] = {0.0, 0.0}, k1[NV] = {0.0, 0.0}, k2[NV] = {0.0, 0.0}, k3[NV] = {0.0, 0.0}, k4[NV] = {0.0, 0.0}, k5[NV] = {0.0, 0.0};
-    y[0] = valid ? A.z_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
-    y[1] = valid ? A.az_in[b * M + i] : 0.0;
-    if (ingrp && i == 0) s_ad[g] = valid ? A.ad_in[b] : 0.0;
+    y[0] = ff_opt_load(A.z_in, valid, b * M + i, A.z_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
+    y[1] = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0);
+    {
+      const double ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
+      if (ingrp && i == 0) s_ad[g] = ad0;
+    }
     // records of the step under way, per radius slot of this lane: stage 0 (= k0), 2, 3, 4, 5 and 6 (next k0)
     ff_rec r0[NSLOT], r2[NSLOT], r3[NSLOT], r4[NSLOT], r5[NSLOT], r6[NSLOT];
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;

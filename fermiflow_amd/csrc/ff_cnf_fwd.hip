@@ -64,6 +64,9 @@ struct ff_fwd_args {
   // same id returns at once unless it finds its id there.  ids are unique per process, so slots need no reset.
   double* evt;
   double evt_id;
+  // optional (B): per-walker factor (>= 1) by which the tolerance of the sensitivity components (J, kbar, the Delta
+  // derivatives) is looser than that of the walker's own coordinates in the error norm (ff_ode.walker_sens_tol)
+  const double* sens_tol;
   // Work queue (optional): with `queue` set the launch is a persistent grid and every workgroup takes its next walker
   // group from this counter (slot 0: table kernel, slot 1: direct kernel), zeroed by the host before the launch.
   unsigned long long* queue;
@@ -192,7 +195,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     if (grp >= ngroups) break;
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
-    const int64_t b = (valid && A.order) ? A.order[bq] : bq;   // the walker this lane group integrates
+    const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);   // the walker this lane group integrates
     // Stage storage, 5 vectors instead of the textbook 7 (y, k0..k5): c0..c2 hold k0..k2 up to stage 3; once k3 is
     // known the remaining stage inputs and the error accumulator are formed and overwrite them:
     //   c0 = input of stage 4, c1 = partial input of stage 5, c2 = partial y_new, c3 = partial error.
@@ -204,7 +207,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     double c0[NV], c1[NV], c2[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
-    y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);  // idle rows: finite, distinct
+    y[0] = ff_opt_load(A.y_in, valid, b * M + i, A.y_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));  // idle rows: finite, distinct
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int k = 0; k < M; k++) y[1 + k] = (k == i) ? 1.0 : 0.0;
@@ -212,7 +215,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -231,7 +234,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       __syncthreads();
       return t;
     };
-    auto wgt = [&](int v) -> double { return (MODE >= 1 && v == IDL && i != 0) ? 0.0 : 1.0; };  // Delta is replicated: count it once
+    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    auto wgt = [&](int v) -> double {   // Delta is replicated: count it once; sensitivity components: their own tolerance
+      if (MODE >= 1 && v == IDL && i != 0) return 0.0;
+      return (MODE == 2 && v >= 1) ? sens_w : 1.0;
+    };
 
 #pragma unroll 1
     for (;;) {
@@ -743,18 +750,21 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     if (grp >= ngroups) break;
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
-    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
+    const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);
     ff_lane_vec<NV, true> y(&s_yv[0][0], lane), c3(&s_cv[0][0], lane);
     double c0[NV], c1[NV], c2[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
-    if (owner) y[0] = valid ? A.y_in[b * M + i] : 0.25 * (i + 1) + 0.125 * ((i * 7) % 5);
+    {
+      const double y0 = ff_opt_load(A.y_in, valid && owner, b * M + i, A.y_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
+      y[0] = owner ? y0 : y[0];
+    }
 #pragma unroll
     for (int k = 0; k < MH; k++) y[1 + k] = (h * MH + k == i) ? 1.0 : 0.0;
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -769,8 +779,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       __syncthreads();
       return t;
     };
-    // slots 0 and MH+1 exist on owner lanes only
-    auto wgt = [&](int v) -> double { return ((v == 0 || v == MH + 1) && !owner) ? 0.0 : 1.0; };
+    // slots 0 and MH+1 exist on owner lanes only; sensitivity components: their own tolerance (ff_ode.walker_sens_tol)
+    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    auto wgt = [&](int v) -> double { return ((v == 0 || v == MH + 1) && !owner) ? 0.0 : (v >= 1 ? sens_w : 1.0); };
 
 #pragma unroll 1
     for (;;) {
@@ -1438,6 +1449,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
+  a.sens_tol = ode->walker_sens_tol;
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {
     if (hipMemsetAsync(w.queue, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;

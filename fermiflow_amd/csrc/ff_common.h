@@ -294,6 +294,19 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
   FF_SCHED_FENCE();
 }
 
+// Optional per-walker inputs (ff_ode.walker_order / walker_h_init / walker_sens_tol) are read WITHOUT a branch: a lane that
+// has no entry reads element 0 of `safe`, an array of the launch that always exists, and discards it.  This is not a
+// micro-optimisation: ROCm 7.2's register allocator was caught placing VGPR->AGPR copies in front of the exec restore at the
+// join of exactly these `if (p) v = p[b];` blocks (tools/check_agpr_spills.py) -- with a null pointer nobody
+// takes the branch, the copy executes with exec = 0 and the value it should have parked is garbage from then on.
+template <class T>
+FF_D T ff_opt_load(const T* p, bool cond, long long idx, const void* safe, T dflt) {
+  const bool use = cond && p != nullptr;
+  const T* q = use ? p + idx : reinterpret_cast<const T*>(safe);
+  const T v = *q;
+  return use ? v : dflt;
+}
+
 // --- log(x) for the Metropolis kernel (Box-Muller radius, log|det|): exponent split + atanh series
 //     log m = 2 s (1 + z/3 + ... + z^10/21), s = (m-1)/(m+1), z = s^2, m in [sqrt(1/2), sqrt(2)); ~1 ulp.
 //     Zero, denormal, negative and non-finite arguments take the library routine.

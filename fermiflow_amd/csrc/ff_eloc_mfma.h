@@ -118,19 +118,24 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     if (grp >= ngroups) break;
     const int64_t bq = grp * G + w;
     const bool valid = bq < A.B;
-    const int64_t b = (valid && A.order) ? A.order[bq] : bq;
+    const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);
     // Dormand-Prince storage as in ff_ode_fwd_kernel: y, c0..c2 (k0..k2, then the inputs of stages 4, 5 and y_new), c3 (error)
     double y[NV], c0[NV], c1[NV], c2[NV];
     ff_lane_vec<NV, true> c3(&s_cv[0][0], lane);
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
-    if (owner) y[0] = valid ? A.y_in[b * M + p] : 0.25 * (p + 1) + 0.125 * ((p * 7) % 5);   // idle walkers: finite, distinct
+    {
+      const double y0 = ff_opt_load(A.y_in, valid && owner, b * M + p, A.y_in, 0.25 * (p + 1) + 0.125 * ((p * 7) % 5));   // idle walkers: finite, distinct
+      y[0] = owner ? y0 : y[0];
+    }
 #pragma unroll
     for (int I = 0; I < MB; I++) y[1 + I * MB + I] = (r == c && 4 * I + r < M) ? 1.0 : 0.0;   // J = identity
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
-    const double hwarm = (valid && A.h_init) ? A.h_init[A.h_scale < 0.0 ? 0 : b] * fabs(A.h_scale) : 0.0;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
     const bool warm = hwarm > 0.0;
+    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.walker_sens_tol): weight in the error norm
+    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;
@@ -369,7 +374,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double isc = ff_rcp(fma(fabs(y[v]), rtol, atol));
+          const double isc = (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fabs(y[v]), rtol, atol));
           p0 = fma(y[v] * isc, y[v] * isc, p0);
           p1 = fma(c0[v] * isc, c0[v] * isc, p1);
         }
@@ -386,7 +391,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - c0[v]) * ff_rcp(fma(fabs(y[v]), rtol, atol));
+          const double t = (out[v] - c0[v]) * (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fabs(y[v]), rtol, atol));
           p2 = fma(t, t, p2);
         }
         const double d2 = sqrt(walker_sum(p2) * (1.0 / NT)) / h0v;
@@ -436,7 +441,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double e = fma(hs * FF_E6, out[v], c3[v]);
-          const double t = e * ff_rcp(fma(fmax(fabs(y[v]), fabs(c2[v])), rtol, atol));   // c2 = the candidate y_new
+          const double t = e * (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fmax(fabs(y[v]), fabs(c2[v])), rtol, atol));   // c2 = the candidate y_new
           pe = fma(t, t, pe);
         }
         const double err = sqrt(walker_sum(pe) * (1.0 / NT));

@@ -194,11 +194,12 @@ FF_D int ff_wave_or(int* s_any, int lane, int flags) {
 // per-walker step-size bookkeeping (identical on all lanes of a walker's group)
 struct ff_stepper {
   double t, tb, dir, interval, habs, h, tnew;
+  double hprev, eprev;   // size and error norm of the previous accepted step (0: none yet)
   int nacc, nrej, natt, rejected, fail;
   bool done;
   FF_D void begin(double ta_, double tb_, bool active) {
     t = ta_; tb = tb_; dir = tb_ > ta_ ? 1.0 : -1.0; interval = fabs(tb_ - ta_);
-    habs = 0.0; h = 0.0; tnew = ta_; nacc = nrej = natt = rejected = fail = 0;
+    habs = 0.0; h = 0.0; tnew = ta_; nacc = nrej = natt = rejected = fail = 0; hprev = eprev = 0.0;
     done = !active || interval == 0.0;
   }
   // Hairer initial step, part 1 (scipy select_initial_step)
@@ -222,8 +223,21 @@ struct ff_stepper {
     if (done) return false;
     natt++;
     bool acc = err < 1.0;
+#ifdef FF_HOSTSIM_TRACE
+    if (getenv("FF_TRACE_STEPS")) fprintf(stderr, "step t=%.6f h=%.3e err=%.3e %s\n", t, h, err, acc ? "acc" : "REJ");
+#endif
     if (acc) {
       double f = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * ff_pow02(err, -0.2f));
+#ifndef FF_NO_PREDICTIVE
+      // Predictive bound (Gustafsson; Hairer & Wanner II, IV.8): the elementary rule assumes the error coefficient
+      // C = err / h^5 of the next step equals this step's.  Where a trajectory runs towards a point at which the field is
+      // only C^1 (a particle passing the origin: mu(|x|) x), C grows by a constant factor per step, the elementary rule
+      // proposes a step that fails, and every accepted step is followed by a rejected one (7 wasted evaluations each).
+      // Extrapolating the trend, C_next = C_n^2 / C_(n-1), gives h_next = h_el * (h_n / h_(n-1)) * (err_(n-1) / err_n)^(1/5);
+      // taken only where it is the SMALLER of the two, so no step is ever larger than the elementary rule's.
+      if (eprev > 0.0 && err > 0.0) f = fmax(0.2, fmin(f, f * (habs / hprev) * ff_pow02(eprev / err, 0.2f)));
+      hprev = habs; eprev = err;
+#endif
       if (rejected) f = fmin(1.0, f);
       habs *= f; t = tnew; rejected = 0; nacc++;
       if (dir * (t - tb) >= 0.0) done = true;

@@ -21,7 +21,7 @@ class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
-                ("walker_h_uniform", C.c_int32)]
+                ("walker_sens_tol", C.c_void_p), ("walker_h_uniform", C.c_int32)]
 
 
 def build():
@@ -161,15 +161,15 @@ def mlp(r, w1, b1, w2):
 _WARM = {}     # set by warm(h_init=..., h_scale=..., h_out=...) for the next calls (keeps the wrappers' signatures short)
 
 
-def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0):
+def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, sens_tol=None):
     _WARM.clear()
-    _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps)
+    _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps, sens_tol=sens_tol)
 
 
 def _ode(t0, t1, rtol, atol, steps=None, order=None):
     q = lambda a: a.ctypes.data if a is not None else None
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
-                 q(_WARM.get("h_out")), int(bool(_WARM.get("uniform", False))))
+                 q(_WARM.get("h_out")), q(_WARM.get("sens_tol")), int(bool(_WARM.get("uniform", False))))
 
 
 def walker_order(cost):

@@ -576,6 +576,48 @@ def test_step_size_warm_start(dev):
     assert abs(Es[0][0] - Es[1][0]) < 1e-6 * abs(Es[1][0]) and abs(Es[0][1] - Es[1][1]) < 1e-5 * Es[1][1]
 
 
+@pytest.mark.parametrize("nup,ndn,B", [(3, 3, 65536), (6, 6, 8192)])
+def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
+    """ff_ode.walker_sens_tol as GSVMC/BetaVMC sweeps use it: walkers whose flow-pass cost class is <= 8
+    integrate the sensitivity components at 10x rtol/atol, the others (a particle passing a C^1 point) at rtol/atol.  On a
+    full batch: a third fewer RHS evaluations, and the per-walker E_loc error against a 1e-11 solve stays where the uniform
+    tolerance has it -- the LOOSE walkers alone stay below 1e-6 (bar: 1e-5), the maximum over all walkers is set by the
+    strict ones and does not move.  Switching the policy off (sens_tol = 1) changes the sweep's E at the 1e-8 level."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, nup, ndn, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    torch.manual_seed(13)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    f = dict(dtype=torch.float64, device=dev)
+    hg, cost = torch.zeros(B, **f), torch.zeros(B, dtype=torch.int32, device=dev)
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
+    loose = cost <= model.sens_tol_class
+    assert model.sens_tol == 10.0 and 0.85 < loose.double().mean().item() < 1.0
+    sens = torch.where(loose, model.sens_tol, 1.0).to(torch.float64)
+    hin = hg * torch.where(loose, model._h_scale_loose, model._h_scale_eloc).to(torch.float64)
+    tight = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+    a = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
+                    walker_h_scale=model._h_scale_eloc)
+    b = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hin,
+                    walker_h_scale=1.0, walker_sens_tol=sens)
+    assert int(a["stats"][3]) == 0 and int(b["stats"][3]) == 0
+    assert int(b["stats"][0]) < 0.8 * int(a["stats"][0]), (a["stats"][:3], b["stats"][:3])
+    ra, rb = (a["eloc"] / tight - 1).abs(), (b["eloc"] / tight - 1).abs()
+    assert rb[loose].max().item() < 1e-6 and rb.max().item() < ELOC_RTOL / 2, (rb[loose].max(), rb.max())
+    assert torch.equal(a["eloc"][~loose], b["eloc"][~loose]) or (rb[~loose].max() <= 2 * ra[~loose].max() + 1e-9)
+    assert abs(b["eloc"].mean().item() / a["eloc"].mean().item() - 1) < 1e-7
+    Es = []
+    for tol in (10.0, 1.0):
+        m = Gm._model(dev, nup, ndn, 2.0)
+        m.sens_tol = tol
+        torch.manual_seed(21)
+        m(4096); m(4096)
+        Es.append(m.E)
+    assert abs(Es[0] / Es[1] - 1) < 1e-7
+
+
 def test_persistent_walkers_opt_in(dev):
     """SURVEY 8(f).1, off by default: ff_mcmc_continue is the same chain as ff_mcmc_sample_noise fed the walkers and the
     materialised Philox stream; a GSVMC that keeps its walkers and advances them 10 steps per sweep samples the same

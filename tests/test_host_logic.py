@@ -128,3 +128,23 @@ def test_shard_partition():
                 assert o == off
                 off += c
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_no_agpr_copy_in_front_of_an_exec_restore():
+    """Static check of the BUILT library (tools/check_agpr_spills.py): ROCm 7.2's register allocator can place a VGPR->AGPR
+    copy in front of the `s_or_b64 exec` of a join block, where it runs under the mask of the branch that just ended --
+    with exec = 0 when no lane took it (an optional ff_ode array that is NULL).  That was an aperture violation at run time
+    for ff_ode_fwd_kernel<2,2,2>; the kernels read optional inputs without a branch since, and this test keeps
+    the pattern from coming back unnoticed with the next change of register pressure."""
+    import importlib.util, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "fermiflow_amd", "libfermiflow_hip.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library or llvm-objdump not present")
+    spec = importlib.util.spec_from_file_location("check_agpr_spills", os.path.join(root, "tools", "check_agpr_spills.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    funcs = mod.parse_library(lib)
+    assert len(funcs) > 100
+    wrong = {k: [h for h in mod.masked_prologue_writes(v) if not h[2].startswith("harmless")] for k, v in funcs.items()}
+    wrong = {k: v for k, v in wrong.items() if v}
+    assert not wrong, wrong

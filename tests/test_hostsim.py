@@ -447,3 +447,42 @@ def test_local_energy_in_three_dimensions(nup, ndn, B):
         gx, gp, st = S.cnf_adjoint(zo, az, ad, net, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(gx, gxo, atol=1e-7)
         np.testing.assert_allclose(gp, gpo, atol=2e-7 * max(1.0, np.abs(gpo).max()))
+
+
+def test_sensitivity_tolerance_and_predictive_step_bound(golden):
+    """ff_ode.walker_sens_tol in the kernels' host build: factor 1 (and anything below) is bit-identical to no array; a
+    factor of 10 on the sensitivity components takes fewer evaluations on ordinary walkers and leaves E_loc within 1e-6 of a
+    tight solve (bar: 1e-5).  Second half: a walker with a particle that ENDS next to the origin (where mu(|x|) x is only
+    C^1) -- the step sizes shrink geometrically towards t0; with the predictive bound of ff_stepper::decide (Gustafsson) the
+    controller follows the trend instead of failing every other step (11 rejected of 26 before, <= 5 now)."""
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    net = S.Net(eta, mu, table=True)
+    x = G["z2_nt_x"][:7]
+    B = len(x)
+    tight = S.eloc(x, 3, 3, net, 2.0, rtol=1e-10, atol=1e-12)["eloc"]
+    try:
+        r0 = S.eloc(x, 3, 3, net, 2.0)
+        S.warm(sens_tol=np.full(B, 1.0))
+        r1 = S.eloc(x, 3, 3, net, 2.0)
+        S.warm(sens_tol=np.full(B, 0.0))
+        r1b = S.eloc(x, 3, 3, net, 2.0)
+        S.warm(sens_tol=np.full(B, 10.0))
+        r2 = S.eloc(x, 3, 3, net, 2.0)
+        mixed = np.where(np.arange(B) % 2 == 0, 10.0, 1.0)
+        S.warm(sens_tol=mixed)
+        r3 = S.eloc(x, 3, 3, net, 2.0)
+    finally:
+        S.warm()
+    assert np.array_equal(r0["eloc"], r1["eloc"]) and np.array_equal(r0["eloc"], r1b["eloc"]) and r0["stats"][0] == r1["stats"][0]
+    assert r2["stats"][0] < r0["stats"][0] and r2["stats"][3] == 0
+    assert np.abs(r2["eloc"] / tight - 1).max() < 1e-6 and np.abs(r0["eloc"] / tight - 1).max() < 1e-6
+    assert np.array_equal(r3["eloc"][1::2], r0["eloc"][1::2]) and np.array_equal(r3["eloc"][0::2], r2["eloc"][0::2])   # per walker
+    # a particle that ends 2e-4 from the origin
+    z = G["z2_nt_x"][:1].copy()
+    z[0, 0] = 2e-4 * np.array([0.6, 0.8])
+    xh, _ = S.cnf_generate(z, net)
+    rh = S.eloc(xh, 3, 3, net, 2.0)
+    th = S.eloc(xh, 3, 3, net, 2.0, rtol=1e-10, atol=1e-12)["eloc"]
+    assert rh["stats"][3] == 0 and rh["stats"][2] <= 5 and rh["stats"][1] >= 10, rh["stats"]
+    assert abs(rh["eloc"][0] / th[0] - 1) < 1e-6
