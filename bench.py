@@ -192,7 +192,8 @@ def main():
         model.to(dev)
     else:
         model = gs
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    from fermiflow_amd.utils import make_adam
+    opt = make_adam(model.parameters(), lr=args.lr)
     B_glob = wpg * n_gpus
     torch.manual_seed(1234)      # same Philox key on every rank; streams are separated by the global walker index
 

@@ -11,6 +11,7 @@ import time
 import torch
 
 from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, BetaVMC, checkpoint
+from .utils import make_adam
 
 
 def main(argv=None):
@@ -53,7 +54,7 @@ def main(argv=None):
     model = BetaVMC(args.beta, args.nup, args.ndown, args.deltaE, args.boltzmann, HO2D(), FreeFermion(device=device), cnf,
                     CoulombPairPotential(args.Z), sp_potential=HO())
     model.to(device=device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    optimizer = make_adam(model.parameters(), lr=1e-2)
     start_iter = 1
     if args.resume:
         start_iter = checkpoint.load(args.resume, model, optimizer, device) + 1

@@ -13,6 +13,7 @@ import time
 import torch
 
 from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, GSVMC, checkpoint
+from .utils import make_adam
 
 
 def main(argv=None):
@@ -55,7 +56,7 @@ def main(argv=None):
     cnf = CNF(v, (args.t0, args.t1))
     model = GSVMC(args.nup, args.ndown, orbitals, basedist, cnf, CoulombPairPotential(args.Z), sp_potential=HO())
     model.to(device=device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    optimizer = make_adam(model.parameters(), lr=1e-2)
     start_iter = 1
     if args.resume:
         start_iter = checkpoint.load(args.resume, model, optimizer, device) + 1

@@ -64,7 +64,7 @@ class _Sweep:
         # sensitivities' first step / flow's largest step (measured, tools/probes/warm_start.py: the best factor is 0.6 up
         # to 8 particles, 0.4-0.5 at 10, 0.4 at 12; too large a factor costs a rejected step = 7 evaluations)
         self._h_scale_eloc = 0.6 if n <= 8 else (0.45 if n <= 10 else 0.4)
-        # tolerance of the sensitivity components (ff_ode.walker_sens_tol): walkers whose flow-pass cost
+        # tolerance of the sensitivity components (ff_ode.walker_class / sens_tol): walkers whose flow-pass cost
         # class is <= sens_tol_class integrate J, the Laplacian of z and the Delta derivatives at sens_tol x rtol/atol and
         # open with _h_scale_loose x the flow's step; the others (close approaches) keep rtol/atol.  FERMIFLOW_SENS_TOL=1
         # restores one tolerance for everything.
@@ -112,18 +112,14 @@ class _Sweep:
             self._h_flow = hg if per_walker_h else hg.mean().reshape(1)
         he = torch.empty_like(hg) if warm else None
         order = native.walker_order(cost)
-        hin, hscale, sens = hg, self._h_scale_eloc, None
-        if self.sens_tol > 1.0:
-            loose = cost <= self.sens_tol_class
-            sens = torch.where(loose, self.sens_tol, 1.0).to(torch.float64)
-            if warm and self._h_scale_loose != self._h_scale_eloc:
-                hin, hscale = hg * torch.where(loose, self._h_scale_loose, self._h_scale_eloc).to(torch.float64), 1.0
         self._mark(ev, "generate")
         p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
         r = native.eloc(tu, td, nup, ndown, net, x, t0, t1, self.cnf.rtol, self.cnf.atol,
                         getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None, walker_state=walker_state,
                         want_stats=prof is not None, pass1_events=p1, walker_order=order,
-                        walker_h_init=hin, walker_h_scale=hscale, walker_h_out=he, walker_sens_tol=sens)
+                        walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he,
+                        walker_class=cost if self.sens_tol > 1.0 else None, sens_tol=self.sens_tol,
+                        sens_tol_class=self.sens_tol_class, walker_h_scale_loose=self._h_scale_loose)
         self._mark(ev, "eloc")
         if prof is not None:
             prof.setdefault("pass1", []).append(p1)
@@ -255,21 +251,25 @@ class GSVMC(_Sweep, torch.nn.Module):
             x, r, he = self._flow_and_local_energy(net, z, tu, td, self.nup, self.ndown, None, ev,
                                                    per_walker_h=self.persistent_walkers)
             Eloc = r["eloc"]
-            shift, mom = self._moments(Eloc, "E", batch)          # [sum(e - c), sum((e - c)^2)]
-            D.all_reduce_sum_(mom)
-            self._set_moments("E", shift, mom, batch)
-            w = (Eloc - self._dev["E"]) / batch
+            # E, E_std and the surrogate's value (src/VMC.py:56-59) from ONE pass over (E_loc, logp) and one all-reduce of four
+            # sums, taken about the previous sweep's mean (no cancellation); the adjoint forms its seeds (E_loc - E) / batch
+            # from E on the device (ff_cnf_adjoint_energy) -- nothing here waits for the host
+            prev = self._dev.get("E")
+            shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
+            sums = native.reduce_energy(Eloc, r["logp"], shift)
+            D.all_reduce_sum_(sums)
+            est = native.energy_finish(sums, shift, batch)        # [E, sum (e - E)^2, mean(logp (e - E))]
+            self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
-            _, gp = native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
-                                       self.cnf.rtol, self.cnf.atol, need_gx=False,   # (uniform cost: no schedule)
+            _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
+                                       need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
                                        walker_h_init=he, walker_h_scale=1.25)
-            buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
-            D.all_reduce_sum_(buf)
+            D.all_reduce_sum_(gp)
             self._mark(ev, "adjoint")
         if prof is not None:
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
-        return _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
+        return _ScalarWithParamGrads.apply(est[2], gp, *params)
 
 
 class BetaVMC(_Sweep, torch.nn.Module):

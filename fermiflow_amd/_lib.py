@@ -15,7 +15,7 @@ _LIB = None
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
     "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_mcmc_continue", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
-    "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint",
+    "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint", "ff_cnf_adjoint_energy", "ff_reduce_energy", "ff_energy_finish",
     "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_state_sums", "ff_logprob3d", "ff_mcmc_sample_noise3d", "ff_mcmc_sample3d", "ff_eloc_finish3d", "ff_backflow_v_div_f32", "ff_walker_order_workspace_bytes", "ff_walker_order",
 ]
 
@@ -30,7 +30,8 @@ class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
-                ("walker_sens_tol", C.c_void_p), ("walker_h_uniform", C.c_int32)]
+                ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
+                ("walker_h_uniform", C.c_int32)]
 
 
 def lib():
@@ -124,15 +125,17 @@ class Net:
 
 
 def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, walker_h_init=None, walker_h_scale=1.0,
-        walker_h_out=None, walker_h_uniform=False, walker_sens_tol=None):
+        walker_h_out=None, walker_h_uniform=False, walker_class=None, sens_tol=1.0, sens_tol_class=0,
+        walker_h_scale_loose=0.0):
     """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
     walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start);
     walker_h_uniform: walker_h_init is a 1-element tensor, the first step of every walker."""
     for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),
                           ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64),
-                          ("walker_sens_tol", walker_sens_tol, torch.float64)):
+                          ("walker_class", walker_class, torch.int32)):
         if tns is not None and not (tns.dtype == dt and tns.is_contiguous() and tns.is_cuda):
             raise ValueError(f"{name} must be a contiguous {dt} device tensor")
     p = lambda t: t.data_ptr() if t is not None else None
     return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps), p(walker_cost), p(walker_order),
-                 p(walker_h_init), float(walker_h_scale), p(walker_h_out), p(walker_sens_tol), int(bool(walker_h_uniform)))
+                 p(walker_h_init), float(walker_h_scale), p(walker_h_out), p(walker_class), float(sens_tol), float(walker_h_scale_loose),
+                 int(sens_tol_class), int(bool(walker_h_uniform)))

@@ -32,6 +32,11 @@ struct ff_adj_args {
   const double* z_in;   // (B, M)  z(t0)
   const double* az_in;  // (B, M)  incoming gradient wrt z(t0)
   const double* ad_in;  // (B)     incoming gradient wrt Delta
+  // energy seeds (ff_cnf_adjoint_energy), optional: with w_b = (w_e[b] - w_mean[0]) * w_scale the seeds are
+  // a_z = w_b * az_in[b] and a_Delta = -w_b (ad_in unused) -- the estimator's weights are formed where they are consumed
+  const double* w_e;
+  const double* w_mean;
+  double w_scale;
   double* gx_out;       // (B, M)  gradient wrt x = z(t1); may be NULL
   double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials (direct kernel)
   double* trows;        // (gridDim.x, 2, FF_DEP_NLDS, FF_DEP_ROW) private coefficient tables, then Wtot (tabulated kernel)
@@ -108,10 +113,13 @@ ff_ode_adj_kernel(ff_adj_args A) {
     const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
     double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
     y[0] = ff_opt_load(A.z_in, valid, b * M + i, A.z_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
-    y[1] = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0);
     {
-      const double ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
-      if (ingrp && i == 0) s_ad[g] = ad0;
+      // seeds: given, or formed from the local energies (ff_cnf_adjoint_energy); all loads branch-free (ff_opt_load)
+      const bool ws = A.w_e != nullptr;
+      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, ws, 0, A.z_in, 0.0)) * A.w_scale;
+      const double az0 = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0), ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
+      y[1] = ws ? wb * az0 : az0;
+      if (ingrp && i == 0) s_ad[g] = ws ? -wb : ad0;
     }
     // tent = B0*k0_theta + sum_{s=2..5} B_s*k_s_theta of the step under way (dropped if the step is rejected)
     double tent[2][MAXU][3];
@@ -530,6 +538,17 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
   if (jB != jA) ff_row_add(sW, ovf, t, jB, accB);
 }
 
+// out-of-line variant (FF_ADJ_DEPOSIT_CALL: A/B knob): the deposit runs once per accepted step, its 12-term rows and two
+// accumulators need ~80 registers the six-evaluation stage loop should not have to make room for
+#ifdef FF_ADJ_DEPOSIT_CALL
+__attribute__((noinline)) static __device__ void ff_deposit5_call(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t,
+                                                                   ff_rec q0, ff_rec q2, ff_rec q3, ff_rec q4, ff_rec q5, double hw) {
+  ff_deposit5(sW, ovf, t, q0, q2, q3, q4, q5, hw);
+}
+#else
+#define ff_deposit5_call ff_deposit5
+#endif
+
 #ifndef FF_ADJ_WPS
 #define FF_ADJ_WPS 1     // waves per SIMD the tabulated adjoint is compiled for (A/B knob: tools/probes/adj_ab.py)
 #endif
@@ -549,6 +568,12 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   __shared__ double s_T[G][N][TROW];
   __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
   __shared__ int s_pa[R], s_pb[R], s_any;
+#ifndef FF_ADJ_ATAB_CONST
+  // the tableau rows in LDS: a wave-uniform ds_read (~100 ticks) where the scalar load from constant memory was measured at
+  // ~2 k ticks per stage (stamp 0 of the FF_STAMPS build: 2.4 k of 8.4 k ticks per evaluation before)
+  __shared__ double s_atab[10][6];
+  if (threadIdx.x < 60) (&s_atab[0][0])[threadIdx.x] = (&FF_ATAB[0][0])[threadIdx.x];
+#endif
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
@@ -594,10 +619,13 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
     double y[NV], k0[NV] = {0.0, 0.0}, k1[NV] = {0.0, 0.0}, k2[NV] = {0.0, 0.0}, k3[NV] = {0.0, 0.0}, k4[NV] = {0.0, 0.0}, k5[NV] = {0.0, 0.0};
     y[0] = ff_opt_load(A.z_in, valid, b * M + i, A.z_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
-    y[1] = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0);
     {
-      const double ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
-      if (ingrp && i == 0) s_ad[g] = ad0;
+      // seeds: given, or formed from the local energies (ff_cnf_adjoint_energy); all loads branch-free (ff_opt_load)
+      const bool ws = A.w_e != nullptr;
+      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, ws, 0, A.z_in, 0.0)) * A.w_scale;
+      const double az0 = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0), ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
+      y[1] = ws ? wb * az0 : az0;
+      if (ingrp && i == 0) s_ad[g] = ws ? -wb : ad0;
     }
     // records of the step under way, per radius slot of this lane: stage 0 (= k0), 2, 3, 4, 5 and 6 (next k0)
     ff_rec r0[NSLOT], r2[NSLOT], r3[NSLOT], r4[NSLOT], r5[NSLOT], r6[NSLOT];
@@ -627,7 +655,11 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       {
         // y + hsel * sum_k a_k k_k with the stage's tableau row (wave-uniform row: scalar loads, no literals)
         const double hsel = (s == -1) ? h0v * S.dir : h;
+#ifdef FF_ADJ_ATAB_CONST
         const double* __restrict__ arow = FF_ATAB[s + 2];
+#else
+        const double* arow = s_atab[s + 2];
+#endif
         const double a0 = hsel * arow[0], a1 = hsel * arow[1], a2 = hsel * arow[2], a3 = hsel * arow[3], a4 = hsel * arow[4],
                      a5 = hsel * arow[5];
 #pragma unroll
@@ -813,7 +845,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
             const int qg = rq_id[sl] & 15;
             const int t = ((rq_id[sl] >> 8) & 15) != 15 ? 0 : 1;
             const double hw = s_hw[qg];
-            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
+            ff_deposit5_call(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }
         }
@@ -982,9 +1014,27 @@ size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
   return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, G) + 1);
 }
 
+static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
+                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, double w_scale,
+                        double* grad_x, double* grad_params, void* workspace, int32_t* stats);
+
 int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
                    const double* a_z, const double* a_d, double* grad_x, double* grad_params, void* workspace,
                    int32_t* stats) {
+  FF_CHECK(B == 0 || a_d, FF_EINVAL, "ff_cnf_adjoint: null pointer");
+  return adjoint_impl(stream, B, n, d, net, ode, z_t0, a_z, a_d, nullptr, nullptr, 0.0, grad_x, grad_params, workspace, stats);
+}
+
+int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
+                          const double* glogp0, const double* eloc, const double* e_mean, double scale, double* grad_x,
+                          double* grad_params, void* workspace, int32_t* stats) {
+  FF_CHECK(B == 0 || (eloc && e_mean), FF_EINVAL, "ff_cnf_adjoint_energy: null pointer");
+  return adjoint_impl(stream, B, n, d, net, ode, z_t0, glogp0, nullptr, eloc, e_mean, scale, grad_x, grad_params, workspace, stats);
+}
+
+static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
+                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, double w_scale,
+                        double* grad_x, double* grad_params, void* workspace, int32_t* stats) {
   FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode && grad_params, FF_EINVAL, "ff_cnf_adjoint: bad argument");
   FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
            "ff_cnf_adjoint: bad net");
@@ -995,13 +1045,13 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
     if (hipMemsetAsync(grad_params, 0, sizeof(double) * P, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
     return FF_OK;
   }
-  FF_CHECK(z_t0 && a_z && a_d && workspace, FF_EINVAL, "ff_cnf_adjoint: null pointer");
+  FF_CHECK(z_t0 && a_z && workspace, FF_EINVAL, "ff_cnf_adjoint: null pointer");
   ff_adj_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
-  a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }

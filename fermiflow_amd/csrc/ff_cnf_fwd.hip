@@ -64,9 +64,12 @@ struct ff_fwd_args {
   // same id returns at once unless it finds its id there.  ids are unique per process, so slots need no reset.
   double* evt;
   double evt_id;
-  // optional (B): per-walker factor (>= 1) by which the tolerance of the sensitivity components (J, kbar, the Delta
-  // derivatives) is looser than that of the walker's own coordinates in the error norm (ff_ode.walker_sens_tol)
-  const double* sens_tol;
+  // local-energy pass, optional (B): a cost class per walker (ff_ode.walker_class).  Walkers with class <= sens_class weigh
+  // the sensitivity components (J, kbar, the Delta derivatives) with sens_w = 1 / ff_ode.sens_tol in the error norm and
+  // open with h_init * h_scale_loose
+  const int32_t* wclass;
+  int sens_class;
+  double sens_w, h_scale_loose;
   // Work queue (optional): with `queue` set the launch is a persistent grid and every workgroup takes its next walker
   // group from this counter (slot 0: table kernel, slot 1: direct kernel), zeroed by the host before the launch.
   unsigned long long* queue;
@@ -81,8 +84,12 @@ struct ff_fwd_args {
 #ifndef FF_FWD_WAVES_PER_SIMD
 #define FF_FWD_WAVES_PER_SIMD 1
 #endif
+// The tabulated flow kernel (MODE 0) carries one double per lane and hides its table fetches behind other waves: up to 6 particles it
+// is compiled for three waves per SIMD (<= 168 registers, no scratch; left alone hipcc drifted from 159 to 169 registers
+// with an unrelated change and the flow pass went from 112 to 143 us).  Larger walkers and delta_logp (MODE 1) would spill
+// under that bound; the local-energy kernel (MODE 2) needs the whole register file.
 template <int N, int D, int MODE, bool TAB>
-__global__ void __launch_bounds__(FF_WAVE, FF_FWD_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(FF_WAVE, (MODE == 0 && TAB && N * D <= 12) ? 3 : FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
@@ -215,7 +222,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    // (local-energy pass) walkers of a low cost class: looser tolerance for the sensitivity components, larger first step
+    const bool loose = MODE == 2 && ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -234,7 +243,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       __syncthreads();
       return t;
     };
-    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    const double sens_w = loose ? A.sens_w : 1.0;
     auto wgt = [&](int v) -> double {   // Delta is replicated: count it once; sensitivity components: their own tolerance
       if (MODE >= 1 && v == IDL && i != 0) return 0.0;
       return (MODE == 2 && v >= 1) ? sens_w : 1.0;
@@ -764,7 +773,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    // walkers of a low cost class: looser tolerance for the sensitivity components, larger first step (ff_ode.walker_class)
+    const bool loose = ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -779,8 +790,8 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       __syncthreads();
       return t;
     };
-    // slots 0 and MH+1 exist on owner lanes only; sensitivity components: their own tolerance (ff_ode.walker_sens_tol)
-    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    // slots 0 and MH+1 exist on owner lanes only; sensitivity components: their own tolerance (ff_ode.sens_tol)
+    const double sens_w = loose ? A.sens_w : 1.0;
     auto wgt = [&](int v) -> double { return ((v == 0 || v == MH + 1) && !owner) ? 0.0 : (v >= 1 ? sens_w : 1.0); };
 
 #pragma unroll 1
@@ -1449,7 +1460,9 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
-  a.sens_tol = ode->walker_sens_tol;
+  a.wclass = ode->walker_class; a.sens_class = ode->sens_tol_class;
+  a.sens_w = ode->sens_tol > 1.0 ? 1.0 / ode->sens_tol : 1.0;
+  a.h_scale_loose = ode->walker_h_scale_loose > 0.0 ? ode->walker_h_scale_loose : fabs(ode->walker_h_scale);
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {
     if (hipMemsetAsync(w.queue, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;

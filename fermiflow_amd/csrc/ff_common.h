@@ -294,7 +294,7 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
   FF_SCHED_FENCE();
 }
 
-// Optional per-walker inputs (ff_ode.walker_order / walker_h_init / walker_sens_tol) are read WITHOUT a branch: a lane that
+// Optional per-walker inputs (ff_ode.walker_order / walker_h_init / walker_class) are read WITHOUT a branch: a lane that
 // has no entry reads element 0 of `safe`, an array of the launch that always exists, and discards it.  This is not a
 // micro-optimisation: ROCm 7.2's register allocator was caught placing VGPR->AGPR copies in front of the exec restore at the
 // join of exactly these `if (p) v = p[b];` blocks (tools/check_agpr_spills.py) -- with a null pointer nobody

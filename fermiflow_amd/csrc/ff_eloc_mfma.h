@@ -132,10 +132,12 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     for (int I = 0; I < MB; I++) y[1 + I * MB + I] = (r == c && 4 * I + r < M) ? 1.0 : 0.0;   // J = identity
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    // walkers of a low cost class: looser tolerance for the sensitivity components, larger first step (ff_ode.walker_class)
+    const bool loose = ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
     const bool warm = hwarm > 0.0;
-    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.walker_sens_tol): weight in the error norm
-    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.sens_tol): weight in the error norm
+    const double sens_w = loose ? A.sens_w : 1.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;

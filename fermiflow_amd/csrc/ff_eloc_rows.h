@@ -155,10 +155,12 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
     for (int k = 0; k < MC; k++) y[1 + k] = (col0 + k == p) ? 1.0 : 0.0;
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    // walkers of a low cost class: looser tolerance for the sensitivity components, larger first step (ff_ode.walker_class)
+    const bool loose = ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
     const bool warm = hwarm > 0.0;
-    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.walker_sens_tol): weight in the error norm
-    const double sens_w = ff_rcp(fmax(ff_opt_load(A.sens_tol, valid, b, A.y_in, 1.0), 1.0));
+    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.sens_tol): weight in the error norm
+    const double sens_w = loose ? A.sens_w : 1.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
     double h0v = 0.0, d1v = 0.0;

@@ -560,6 +560,50 @@ ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, co
   if (t == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
+// Ground-state estimator sums in one pass (src/VMC.py:56-59): with c = shift[0] (any number every rank agrees on, e.g. the
+// previous sweep's mean: no cancellation)  out = [sum (e - c), sum (e - c)^2, sum logp, sum logp (e - c)].  One workgroup,
+// fixed tree: deterministic.  The sums of all ranks add up; ff_energy_finish turns the totals into E, the centred sum of
+// squares and the surrogate mean(logp (e - E)).
+__global__ void __launch_bounds__(1024)
+ff_energy_sums_kernel(int64_t B, const double* __restrict__ e, const double* __restrict__ logp, const double* __restrict__ shift_dev,
+                      double* __restrict__ out) {
+  __shared__ double sm[4][1024];
+  const double shift = shift_dev[0];
+  const int nt = blockDim.x, t = threadIdx.x;
+  double a[2] = {0.0, 0.0}, q[2] = {0.0, 0.0}, l[2] = {0.0, 0.0}, m[2] = {0.0, 0.0};
+  int64_t i = t;
+  for (; i + (int64_t)nt < B; i += 2 * (int64_t)nt) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const double v = e[i + k * (int64_t)nt] - shift, lp = logp[i + k * (int64_t)nt];
+      a[k] += v; q[k] = fma(v, v, q[k]); l[k] += lp; m[k] = fma(lp, v, m[k]);
+    }
+  }
+  if (i < B) { const double v = e[i] - shift, lp = logp[i]; a[0] += v; q[0] = fma(v, v, q[0]); l[0] += lp; m[0] = fma(lp, v, m[0]); }
+  sm[0][t] = a[0] + a[1]; sm[1][t] = q[0] + q[1]; sm[2][t] = l[0] + l[1]; sm[3][t] = m[0] + m[1];
+  __syncthreads();
+  int w = 1;
+  while (w * 2 < nt) w *= 2;
+  for (; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) sm[k][t] += sm[k][t + w];
+    }
+    __syncthreads();
+  }
+  if (t < 4) out[t] = sm[t][0];
+}
+
+// est = [E, sum (e - E)^2, sum logp (e - E) / n] from the (all-reduced) sums of ff_energy_sums_kernel over n walkers
+__global__ void ff_energy_finish_kernel(const double* __restrict__ sums, const double* __restrict__ shift_dev, double n,
+                                        double* __restrict__ est) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double d = sums[0] / n;                 // E - c
+  est[0] = shift_dev[0] + d;
+  est[1] = sums[1] - sums[0] * d;
+  est[2] = (sums[3] - d * sums[2]) / n;
+}
+
 // Per-state sums of the finite-temperature estimator (src/VMC.py:164-169: the per-state baseline of gradF_theta, and the
 // state counts behind S and gradF_phi).  walker_state is sorted (src/VMC.py:94-96), so state s is one contiguous segment:
 // one workgroup per state finds its bounds by bisection and sums the segment with a fixed tree -- deterministic, and no
@@ -848,6 +892,20 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
                       double* out2) {
   FF_CHECK(B > 0 && e && out2, FF_EINVAL, "ff_reduce_moments: bad argument");
   FF_LAUNCH(ff_moments_kernel, 1, FF_RBLOCK(1024), stream, B, e, shift, shift_dev, shift_dev_scale, out2);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4) {
+  FF_CHECK(B > 0 && e && logp && shift_dev && sums4, FF_EINVAL, "ff_reduce_energy: bad argument");
+  FF_LAUNCH(ff_energy_sums_kernel, 1, FF_RBLOCK(1024), stream, B, e, logp, shift_dev, sums4);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3) {
+  FF_CHECK(sums4 && shift_dev && est3 && n_global > 0, FF_EINVAL, "ff_energy_finish: bad argument");
+  FF_LAUNCH(ff_energy_finish_kernel, 1, FF_RBLOCK(64), stream, sums4, shift_dev, (double)n_global, est3);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -161,9 +161,13 @@ def cnf_delta_logp(net, x, t0, t1, rtol, atol, want_stats=False, walker_cost=Non
 
 
 def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, want_stats=False, walker_cost=None,
-                walker_order=None, **warm):
-    """Adjoint sweep from t_from (where y_start, a_z, a_d are given) to t_to."""
-    y = L.dev(y_start, name="y_start"); a_z = L.dev(a_z, name="a_z"); a_d = L.dev(a_d, name="a_d")
+                walker_order=None, energy=None, **warm):
+    """Adjoint sweep from t_from (where y_start, a_z, a_d are given) to t_to.
+    energy = (eloc (B,), e_mean 1-element device tensor, scale): ff_cnf_adjoint_energy -- a_z is glogp0 (B,n,d) and the
+    kernel forms the seeds w_b * glogp0[b], -w_b with w_b = (eloc[b] - e_mean) * scale itself (a_d is ignored)."""
+    y = L.dev(y_start, name="y_start"); a_z = L.dev(a_z, name="a_z")
+    if energy is None:
+        a_d = L.dev(a_d, name="a_d")
     B, n, d = y.shape
     gx = torch.empty_like(y) if need_gx else None
     gp = torch.empty(net.nparams, dtype=torch.float64, device=y.device)
@@ -171,8 +175,13 @@ def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, 
     ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=y.device)
     st = _stats(y.device, want_stats)
     o = L.ode(t_from, t_to, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
-    L.check(L.lib().ff_cnf_adjoint(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(a_d),
-                                   L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint")
+    if energy is not None:
+        e = L.dev(energy[0], name="eloc"); em = L.dev(energy[1].reshape(-1)[:1], name="e_mean")
+        L.check(L.lib().ff_cnf_adjoint_energy(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(e), L.ptr(em),
+                                              L.f64(energy[2]), L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint_energy")
+    else:
+        L.check(L.lib().ff_cnf_adjoint(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(a_d),
+                                       L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint")
     return (gx, gp, st) if want_stats else (gx, gp)
 
 
@@ -225,6 +234,22 @@ def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0):
         shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
     L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(shift_dev),
                                       L.f64(shift_dev_scale), L.ptr(out)), "ff_reduce_moments")
+    return out
+
+
+def reduce_energy(e, logp, shift_dev):
+    """ff_reduce_energy: tensor [sum(e - c), sum((e - c)^2), sum(logp), sum(logp (e - c))], c = shift_dev[0] (device)."""
+    e = L.dev(e, name="e"); logp = L.dev(logp, name="logp"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
+    out = torch.empty(4, dtype=torch.float64, device=e.device)
+    L.check(L.lib().ff_reduce_energy(L.stream(), L.i64(e.numel()), L.ptr(e), L.ptr(logp), L.ptr(shift_dev), L.ptr(out)), "ff_reduce_energy")
+    return out
+
+
+def energy_finish(sums4, shift_dev, n_global):
+    """ff_energy_finish: tensor [E, sum((e - E)^2), mean(logp (e - E))] from the (all-reduced) sums of reduce_energy."""
+    sums4 = L.dev(sums4, name="sums4"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
+    out = torch.empty(3, dtype=torch.float64, device=sums4.device)
+    L.check(L.lib().ff_energy_finish(L.stream(), L.ptr(sums4), L.ptr(shift_dev), L.i64(n_global), L.ptr(out)), "ff_energy_finish")
     return out
 
 

@@ -59,13 +59,17 @@ typedef struct ff_ode {
   const double* walker_h_init;
   double walker_h_scale;
   double* walker_h_out;
-  /* Local-energy pass only, optional (NULL): walker_sens_tol (in, B) -- per-walker factor (>= 1) by which the tolerance of the
-   * SENSITIVITY components of the integrated state (J = dz/dx, the x-Laplacian of z, the derivatives of Delta) is looser than
-   * rtol/atol in the error norm; the walker's own coordinates keep rtol/atol.  The second-order sensitivities are what needs
-   * the small steps, and only where a trajectory passes near a vanishing radius (the field is C^1 there): walkers whose
-   * cost class (walker_cost of the flow pass) is low can take the flow's own steps for them (GSVMC.forward passes 10 for
-   * classes <= 8, 1 otherwise; measured on 65 536 walkers: 19.6 -> 13.4 evaluations, E_loc error unchanged). */
-  const double* walker_sens_tol;
+  /* Local-energy pass only, optional (walker_class NULL or sens_tol <= 1: off).  The SENSITIVITY components of the integrated
+   * state (J = dz/dx, the x-Laplacian of z, the derivatives of Delta) are what needs small steps, and only where a trajectory
+   * passes a point at which the field is merely C^1 (a vanishing radius).  walker_class (in, B): a cost class per walker --
+   * walker_cost of the flow pass along the same trajectory.  Walkers with class <= sens_tol_class control those components at
+   * sens_tol x (rtol, atol) -- their own coordinates keep rtol/atol -- and open with walker_h_init x walker_h_scale_loose
+   * (0: walker_h_scale); the others keep one tolerance for everything.  The sweeps pass sens_tol = 10, class 8, scale 1.0:
+   * 19.5 -> 13.6 evaluations per walker at 6 particles, 25.1 -> 14.1 at 12; E_loc error of the loose walkers <= 2e-7. */
+  const int32_t* walker_class;
+  double sens_tol;
+  double walker_h_scale_loose;
+  int32_t sens_tol_class;
   int32_t walker_h_uniform;   /* nonzero: walker_h_init holds ONE entry, the first step size of every walker (a statistic of an
                                  earlier call on other walkers of the same distribution, e.g. the mean of its walker_h_out) */
 } ff_ode;
@@ -157,6 +161,13 @@ size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm);
 int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
                    const double* z_t0, const double* a_z, const double* a_d,
                    double* grad_x, double* grad_params, void* workspace, int32_t* stats);
+/* The same adjoint with the seeds of the energy gradient (src/VMC.py:58-59, gradE = mean(logp (E_loc - E))) formed inside
+ * the kernel: with w_b = (eloc[b] - e_mean[0]) * scale  (e_mean: DEVICE pointer, e.g. est3 of ff_energy_finish; scale =
+ * 1 / global batch)  it is ff_cnf_adjoint(a_z = w_b * glogp0[b], a_d = -w_b) -- no (B,n,d) seed array and no host round
+ * trip for the mean. */
+int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
+                          const double* z_t0, const double* glogp0, const double* eloc, const double* e_mean, double scale,
+                          double* grad_x, double* grad_params, void* workspace, int32_t* stats);
 
 /* ---- local energy (src/VMC.py:46-55 via src/utils.py:40-65) --------------------------------- */
 /* Two launches: (1) a fused per-walker Dormand-Prince pass integrating z, J = dz/dx, the x-Laplacian of z,
@@ -188,6 +199,14 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
  * the mean of the first call (a sum on the device, all-reduced there) feeds the second without a host round trip. */
 int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev,
                       double shift_dev_scale, double* out2);
+/* GSVMC.forward's estimator (src/VMC.py:56-59) in two small launches around the one all-reduce a multi-GPU run needs:
+ * ff_reduce_energy: sums4 = [sum (e - c), sum (e - c)^2, sum logp, sum logp (e - c)] over this rank's B walkers,
+ *   c = shift_dev[0] (device; any value all ranks share -- the previous sweep's mean keeps the sums free of cancellation);
+ * (the caller adds the sums4 of all ranks;)
+ * ff_energy_finish: est3 = [E = mean e, sum (e - E)^2 (E_std^2 = est3[1] / (n - 1)), mean(logp (e - E)) -- the value of
+ *   the reference's surrogate gradE] for n_global walkers.  One workgroup, fixed summation tree: deterministic. */
+int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4);
+int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3);
 
 /* ---- three dimensions (groundwork for a 3-D trap; no upstream counterpart: src/orbitals.py:56 and src/base_dist.py:62
  * hard-code d = 2).  Orbital index k of HO3D: list order "for n in range(8) for nx in range(n+1) for ny in range(n+1-nx):

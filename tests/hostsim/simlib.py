@@ -21,7 +21,8 @@ class FFOde(C.Structure):
     _fields_ = [("t0", C.c_double), ("t1", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
-                ("walker_sens_tol", C.c_void_p), ("walker_h_uniform", C.c_int32)]
+                ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
+                ("walker_h_uniform", C.c_int32)]
 
 
 def build():
@@ -161,15 +162,18 @@ def mlp(r, w1, b1, w2):
 _WARM = {}     # set by warm(h_init=..., h_scale=..., h_out=...) for the next calls (keeps the wrappers' signatures short)
 
 
-def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, sens_tol=None):
+def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, wclass=None, sens_tol=1.0, sens_class=0, h_scale_loose=0.0):
     _WARM.clear()
-    _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps, sens_tol=sens_tol)
+    _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps, wclass=wclass, sens_tol=sens_tol, sens_class=sens_class,
+                 h_scale_loose=h_scale_loose)
 
 
 def _ode(t0, t1, rtol, atol, steps=None, order=None):
     q = lambda a: a.ctypes.data if a is not None else None
+    qi = q
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
-                 q(_WARM.get("h_out")), q(_WARM.get("sens_tol")), int(bool(_WARM.get("uniform", False))))
+                 q(_WARM.get("h_out")), qi(_WARM.get("wclass")), float(_WARM.get("sens_tol", 1.0)), float(_WARM.get("h_scale_loose", 0.0)),
+                 int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))))
 
 
 def walker_order(cost):
@@ -216,6 +220,29 @@ def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8,
                       _p(o["z"]), _p(o["dlogp"]), _p(o["glogp0"]), _p(wk), _p(stats)))
     o["stats"] = stats
     return o
+
+
+def reduce_energy(e, logp, shift):
+    e = _d(e); logp = _d(logp); sh = np.array([shift], dtype=np.float64); out = np.empty(4)
+    _ck(lib().ff_reduce_energy(None, C.c_int64(len(e)), _p(e), _p(logp), _p(sh), _p(out)))
+    return out
+
+
+def energy_finish(sums4, shift, n):
+    sums4 = _d(sums4); sh = np.array([shift], dtype=np.float64); out = np.empty(3)
+    _ck(lib().ff_energy_finish(None, _p(sums4), _p(sh), C.c_int64(n), _p(out)))
+    return out
+
+
+def cnf_adjoint_energy(z0, glogp0, eloc, e_mean, scale, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+    z0 = _d(z0); glogp0 = _d(glogp0); eloc = _d(eloc); B, n, d = z0.shape
+    em = np.array([e_mean], dtype=np.float64)
+    gx = np.empty_like(z0); gp = np.empty(3 * net.c.He + 3 * net.c.Hm); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
+    lib().ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
+    ws = np.zeros(max(1, lib().ff_cnf_adjoint_workspace_bytes(C.c_int64(B), n, d, net.c.He, net.c.Hm) // 8))
+    _ck(lib().ff_cnf_adjoint_energy(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z0), _p(glogp0), _p(eloc), _p(em),
+                                    C.c_double(scale), _p(gx), _p(gp), _p(ws), _p(stats)))
+    return gx, gp, stats
 
 
 def moments(e, shift=0.0):

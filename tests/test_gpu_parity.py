@@ -578,7 +578,7 @@ def test_step_size_warm_start(dev):
 
 @pytest.mark.parametrize("nup,ndn,B", [(3, 3, 65536), (6, 6, 8192)])
 def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
-    """ff_ode.walker_sens_tol as GSVMC/BetaVMC sweeps use it: walkers whose flow-pass cost class is <= 8
+    """ff_ode.walker_class / sens_tol as GSVMC/BetaVMC sweeps use it: walkers whose flow-pass cost class is <= 8
     integrate the sensitivity components at 10x rtol/atol, the others (a particle passing a C^1 point) at rtol/atol.  On a
     full batch: a third fewer RHS evaluations, and the per-walker E_loc error against a 1e-11 solve stays where the uniform
     tolerance has it -- the LOOSE walkers alone stay below 1e-6 (bar: 1e-5), the maximum over all walkers is set by the
@@ -595,13 +595,12 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
     loose = cost <= model.sens_tol_class
     assert model.sens_tol == 10.0 and 0.85 < loose.double().mean().item() < 1.0
-    sens = torch.where(loose, model.sens_tol, 1.0).to(torch.float64)
-    hin = hg * torch.where(loose, model._h_scale_loose, model._h_scale_eloc).to(torch.float64)
     tight = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
     a = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
                     walker_h_scale=model._h_scale_eloc)
-    b = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hin,
-                    walker_h_scale=1.0, walker_sens_tol=sens)
+    b = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
+                    walker_h_scale=model._h_scale_eloc, walker_class=cost, sens_tol=model.sens_tol,
+                    sens_tol_class=model.sens_tol_class, walker_h_scale_loose=model._h_scale_loose)
     assert int(a["stats"][3]) == 0 and int(b["stats"][3]) == 0
     assert int(b["stats"][0]) < 0.8 * int(a["stats"][0]), (a["stats"][:3], b["stats"][:3])
     ra, rb = (a["eloc"] / tight - 1).abs(), (b["eloc"] / tight - 1).abs()

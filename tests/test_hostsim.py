@@ -450,9 +450,9 @@ def test_local_energy_in_three_dimensions(nup, ndn, B):
 
 
 def test_sensitivity_tolerance_and_predictive_step_bound(golden):
-    """ff_ode.walker_sens_tol in the kernels' host build: factor 1 (and anything below) is bit-identical to no array; a
-    factor of 10 on the sensitivity components takes fewer evaluations on ordinary walkers and leaves E_loc within 1e-6 of a
-    tight solve (bar: 1e-5).  Second half: a walker with a particle that ENDS next to the origin (where mu(|x|) x is only
+    """ff_ode.walker_class / sens_tol in the kernels' host build: factor 1 (and anything below), or no walker at or below
+    the class threshold, is bit-identical to no policy; a factor of 10 on the sensitivity components takes fewer evaluations
+    on ordinary walkers and leaves E_loc within 1e-6 of a tight solve (bar: 1e-5); the choice is per walker.  Second half: a walker with a particle that ENDS next to the origin (where mu(|x|) x is only
     C^1) -- the step sizes shrink geometrically towards t0; with the predictive bound of ff_stepper::decide (Gustafsson) the
     controller follows the trend instead of failing every other step (11 rejected of 26 before, <= 5 now)."""
     G = golden["g5_gsvmc"]
@@ -463,14 +463,15 @@ def test_sensitivity_tolerance_and_predictive_step_bound(golden):
     tight = S.eloc(x, 3, 3, net, 2.0, rtol=1e-10, atol=1e-12)["eloc"]
     try:
         r0 = S.eloc(x, 3, 3, net, 2.0)
-        S.warm(sens_tol=np.full(B, 1.0))
+        cls = np.full(B, 3, dtype=np.int32)
+        S.warm(wclass=cls, sens_tol=1.0, sens_class=8)
         r1 = S.eloc(x, 3, 3, net, 2.0)
-        S.warm(sens_tol=np.full(B, 0.0))
+        S.warm(wclass=cls, sens_tol=10.0, sens_class=2)        # nobody is at or below class 2
         r1b = S.eloc(x, 3, 3, net, 2.0)
-        S.warm(sens_tol=np.full(B, 10.0))
+        S.warm(wclass=cls, sens_tol=10.0, sens_class=8)
         r2 = S.eloc(x, 3, 3, net, 2.0)
-        mixed = np.where(np.arange(B) % 2 == 0, 10.0, 1.0)
-        S.warm(sens_tol=mixed)
+        mixed = np.where(np.arange(B) % 2 == 0, 3, 9).astype(np.int32)
+        S.warm(wclass=mixed, sens_tol=10.0, sens_class=8)
         r3 = S.eloc(x, 3, 3, net, 2.0)
     finally:
         S.warm()
@@ -486,3 +487,31 @@ def test_sensitivity_tolerance_and_predictive_step_bound(golden):
     th = S.eloc(xh, 3, 3, net, 2.0, rtol=1e-10, atol=1e-12)["eloc"]
     assert rh["stats"][3] == 0 and rh["stats"][2] <= 5 and rh["stats"][1] >= 10, rh["stats"]
     assert abs(rh["eloc"][0] / th[0] - 1) < 1e-6
+
+
+def test_energy_estimator_and_energy_seeded_adjoint(golden):
+    """ff_reduce_energy + ff_energy_finish == mean / centred sum of squares / mean(logp (e - E)) (src/VMC.py:56-59), for any
+    shift; ff_cnf_adjoint_energy == ff_cnf_adjoint on the seeds w * glogp0, -w with w = (e - E) / n formed by the caller."""
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    net = S.Net(eta, mu, table=True)
+    x = G["z2_nt_x"][:9]
+    r = S.eloc(x, 3, 3, net, 2.0)
+    e, lp = r["eloc"], r["logp"]
+    n = len(e)
+    for shift in (0.0, float(e.mean()) + 0.3, 1e3):
+        sums = S.reduce_energy(e, lp, shift)
+        est = S.energy_finish(sums, shift, n)
+        np.testing.assert_allclose(est[0], e.mean(), rtol=1e-13)
+        np.testing.assert_allclose(est[1], ((e - e.mean()) ** 2).sum(), rtol=1e-9 if shift < 100 else 1e-6)
+        np.testing.assert_allclose(est[2], (lp * (e - e.mean())).mean(), rtol=1e-9 if shift < 100 else 1e-6, atol=1e-12)
+    # two "ranks": the sums add up
+    sa, sb = S.reduce_energy(e[:4], lp[:4], 2.0), S.reduce_energy(e[4:], lp[4:], 2.0)
+    np.testing.assert_allclose(S.energy_finish(sa + sb, 2.0, n), S.energy_finish(S.reduce_energy(e, lp, 2.0), 2.0, n), rtol=1e-12)
+    E = float(e.mean())
+    w = (e - E) / n
+    gx0, gp0, st0 = S.cnf_adjoint(r["z"], w[:, None, None] * r["glogp0"], -w, net)
+    gx1, gp1, st1 = S.cnf_adjoint_energy(r["z"], r["glogp0"], e, E, 1.0 / n, net)
+    assert st0[3] == 0 and st1[3] == 0
+    np.testing.assert_allclose(gx1, gx0, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(gp1, gp0, rtol=1e-12, atol=1e-15)

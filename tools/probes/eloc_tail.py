@@ -23,7 +23,7 @@ def run(sel, sens, tag, sc):
     for rep in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r = native.eloc(tu, td, nup, ndn, net, xs, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=(e0, e1), walker_order=order,
-                        walker_cost=c2, walker_h_init=hs, walker_h_scale=sc, walker_sens_tol=None if sens is None else torch.full((n,), sens, dtype=torch.float64, device=dev))
+                        walker_cost=c2, walker_h_init=hs, walker_h_scale=sc, **({} if sens is None else dict(walker_class=torch.zeros(n, dtype=torch.int32, device=dev), sens_tol=sens, sens_tol_class=0)))
         torch.cuda.synchronize()
         if rep: ts.append(e0.elapsed_time(e1))
     st = r["stats"]

@@ -1,5 +1,5 @@
-"""Probe: per-walker tolerance of the sensitivity components in the local-energy pass (ff_ode.walker_sens_tol = f for the
-walkers whose flow-pass cost class is <= thr, 1 for the others).  Evaluations, time and E_loc error against a 1e-11 solve.
+"""Probe: tolerance of the sensitivity components in the local-energy pass (ff_ode.sens_tol = f for the walkers whose
+flow-pass cost class, ff_ode.walker_class, is <= thr; 1 for the others).  Evaluations, time and E_loc error against a 1e-11 solve.
 usage: sens_tol.py [nup ndown B]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -25,13 +25,12 @@ base = model._h_scale_eloc
 print("cost classes (warm flow pass): " + " ".join("%d:%d" % (c, int((cost2 == c).sum())) for c in range(int(cost2.min()), int(cost2.max()) + 1)))
 for fac, thr, sc in [(1, 0, base), (10, 7, 0.9), (10, 8, 0.9), (10, 9, 0.9), (10, 8, 0.8), (10, 8, 1.0), (10, 8, 1.1), (30, 8, 0.9), (30, 8, 1.0), (10, 99, 0.9)]:
     loose = cost2 <= thr
-    sens = torch.where(loose, float(fac), 1.0).to(torch.float64)
-    hin = hg2 * torch.where(loose, sc, base).to(torch.float64)
     ts = []
     for rep in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=(e0, e1), walker_order=order,
-                        walker_h_init=hin, walker_h_scale=1.0, walker_sens_tol=sens if fac > 1 else None)
+                        walker_h_init=hg2, walker_h_scale=base, walker_class=cost2, sens_tol=float(fac), sens_tol_class=thr,
+                        walker_h_scale_loose=sc)
         torch.cuda.synchronize()
         if rep: ts.append(e0.elapsed_time(e1))
     rel = (r["eloc"] - ref).abs() / ref.abs()
