@@ -151,6 +151,11 @@ class _Sweep:
         st = {"h_flow": self._h_flow, "dev": dict(self._dev), "n_global": getattr(self, "_n_global", 0)}
         if getattr(self, "_z_prev", None) is not None:
             st["z_prev"] = self._z_prev
+        if getattr(self, "_z_next", None) is not None:      # prefetched walkers of the next iteration (GSVMC)
+            zn, done, nloc = self._z_next
+            if done is not None:
+                done.synchronize()
+            st["z_next"] = zn
         return st
 
     def set_extra_state(self, st):
@@ -159,6 +164,8 @@ class _Sweep:
         self._n_global = st.get("n_global", 0)
         if "z_prev" in st:
             self._z_prev = st["z_prev"]
+        if "z_next" in st and hasattr(self, "_z_next"):
+            self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]))
 
 
 class GSVMC(_Sweep, torch.nn.Module):
@@ -176,6 +183,14 @@ class GSVMC(_Sweep, torch.nn.Module):
         self.persistent_walkers = False
         self.persistent_steps = 10
         self._z_prev = None
+        # Walker prefetch (FERMIFLOW_PREFETCH=0 or model.prefetch_walkers = False: off).  The base distribution |psi_0|^2 has no
+        # trainable parameter, so the NEXT iteration's Metropolis kernel does not have to wait for this iteration's update: it is
+        # started on a side stream a moment after the adjoint kernel and runs beside it on the same SIMDs (292 + 164 registers;
+        # DESIGN.md 6).  Same seeds in the same order, hence the same walkers as without it; the prefetched walkers travel in
+        # checkpoints.
+        self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1") != "0"
+        self._z_next = None          # (walkers, event on the side stream, nloc)
+        self._side = None
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
     @property
@@ -226,11 +241,31 @@ class GSVMC(_Sweep, torch.nn.Module):
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
                                          equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
+            elif self._z_next is not None and self._z_next[2] == nloc and not self.persistent_walkers:
+                z, done, _ = self._z_next          # sampled beside the previous iteration's adjoint
+                if done is not None:
+                    torch.cuda.current_stream().wait_event(done)
+                    z.record_stream(torch.cuda.current_stream())
             else:
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
+            self._z_next = None
             self._z_prev = z if self.persistent_walkers else None
         self._mark(ev, "mcmc")
-        return self._sweep(z, batch, ev)
+        return self._sweep(z, batch, ev, prefetch=nloc if (self.prefetch_walkers and not self.persistent_walkers and z.is_cuda) else 0)
+
+    def _prefetch(self, nloc, go):
+        """Next iteration's walkers on the side stream: starts when `go` (recorded on the main stream in front of the adjoint)
+        has fired plus a short delay, so that the adjoint's waves are placed first (tools/probes/overlap.py: the other order
+        serialises the two kernels)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(go)
+            native.stream_delay(40.0)
+            z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
+            done = torch.cuda.Event()
+            done.record()
+        self._z_next = (z, done, nloc)
 
     def forward_from(self, z, batch=None):
         """forward() on GIVEN base walkers z (nloc, n, 2) -- this rank's shard of a global batch of `batch` walkers
@@ -240,7 +275,7 @@ class GSVMC(_Sweep, torch.nn.Module):
         self._mark(ev, "mcmc")
         return self._sweep(z.detach().contiguous(), int(batch if batch is not None else z.shape[0]), ev)
 
-    def _sweep(self, z, batch, ev):
+    def _sweep(self, z, batch, ev, prefetch=0):
         self._first_sweep_sync()
         prof = self.profile
         with torch.no_grad():
@@ -261,9 +296,15 @@ class GSVMC(_Sweep, torch.nn.Module):
             est = native.energy_finish(sums, shift, batch)        # [E, sum (e - E)^2, mean(logp (e - E))]
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
+            go = None
+            if prefetch:
+                go = torch.cuda.Event()
+                go.record()
             _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
                                        need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
                                        walker_h_init=he, walker_h_scale=1.25)
+            if prefetch:
+                self._prefetch(prefetch, go)
             D.all_reduce_sum_(gp)
             self._mark(ev, "adjoint")
         if prof is not None:

@@ -538,25 +538,26 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
   if (jB != jA) ff_row_add(sW, ovf, t, jB, accB);
 }
 
-// out-of-line variant (FF_ADJ_DEPOSIT_CALL: A/B knob): the deposit runs once per accepted step, its 12-term rows and two
-// accumulators need ~80 registers the six-evaluation stage loop should not have to make room for
-#ifdef FF_ADJ_DEPOSIT_CALL
-__attribute__((noinline)) static __device__ void ff_deposit5_call(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t,
-                                                                   ff_rec q0, ff_rec q2, ff_rec q3, ff_rec q4, ff_rec q5, double hw) {
-  ff_deposit5(sW, ovf, t, q0, q2, q3, q4, q5, hw);
-}
-#else
-#define ff_deposit5_call ff_deposit5
-#endif
-
 #ifndef FF_ADJ_WPS
 #define FF_ADJ_WPS 1     // waves per SIMD the tabulated adjoint is compiled for (A/B knob: tools/probes/adj_ab.py)
 #endif
+// Walkers per wave of the tabulated adjoint.  The forward kernels pack 64 / M walkers into a wave; here every lane also
+// carries the six stage records of its radii, and at 6 particles (5 walkers x 21 radii = 105 radii: two per lane) that
+// put the kernel at 360 registers.  With THREE walkers (63 radii: one per lane) it takes 292 and is exactly as fast
+// (0.67 ms per 65 536 walkers either way: the radius phase is what a wave-evaluation waits for) -- and 292 + 164 <= 512:
+// a wave of the Metropolis kernel now fits the same SIMD, so the next sweep's walkers are sampled BESIDE the adjoint
+// (GSVMC prefetch, DESIGN.md 6: 1.11 -> 0.78 ms for the two together; tools/probes/overlap.py).
+#ifndef FF_ADJ_G12
+#define FF_ADJ_G12 3
+#endif
+template <int N, int D> struct ff_adjtab_geom { static constexpr int G = (N * D == 12) ? FF_ADJ_G12 : ff_geom<N, D>::G; };
+static int adj_tab_G(int n, int d) { return n * d == 12 ? FF_ADJ_G12 : (n * d > 0 && n * d <= FF_WAVE ? (FF_WAVE / (n * d) > 16 ? 16 : FF_WAVE / (n * d)) : 0); }
+
 template <int N, int D>
 __global__ void __launch_bounds__(FF_WAVE, FF_ADJ_WPS)
 ff_ode_adjtab_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
-  constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
+  constexpr int M = Gm::M, G = ff_adjtab_geom<N, D>::G, P = Gm::P, R = Gm::RA;
   constexpr int NV = 2, NSLOT = (G * R + FF_WAVE - 1) / FF_WAVE;
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
@@ -568,12 +569,6 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   __shared__ double s_T[G][N][TROW];
   __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
   __shared__ int s_pa[R], s_pb[R], s_any;
-#ifndef FF_ADJ_ATAB_CONST
-  // the tableau rows in LDS: a wave-uniform ds_read (~100 ticks) where the scalar load from constant memory was measured at
-  // ~2 k ticks per stage (stamp 0 of the FF_STAMPS build: 2.4 k of 8.4 k ticks per evaluation before)
-  __shared__ double s_atab[10][6];
-  if (threadIdx.x < 60) (&s_atab[0][0])[threadIdx.x] = (&FF_ATAB[0][0])[threadIdx.x];
-#endif
 
   const int lane = threadIdx.x;
   const int g = lane / M, i = lane % M;
@@ -655,11 +650,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       {
         // y + hsel * sum_k a_k k_k with the stage's tableau row (wave-uniform row: scalar loads, no literals)
         const double hsel = (s == -1) ? h0v * S.dir : h;
-#ifdef FF_ADJ_ATAB_CONST
         const double* __restrict__ arow = FF_ATAB[s + 2];
-#else
-        const double* arow = s_atab[s + 2];
-#endif
         const double a0 = hsel * arow[0], a1 = hsel * arow[1], a2 = hsel * arow[2], a3 = hsel * arow[3], a4 = hsel * arow[4],
                      a5 = hsel * arow[5];
 #pragma unroll
@@ -845,7 +836,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
             const int qg = rq_id[sl] & 15;
             const int t = ((rq_id[sl] >> 8) & 15) != 15 ? 0 : 1;
             const double hw = s_hw[qg];
-            ff_deposit5_call(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
+            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }
         }
@@ -1001,8 +992,8 @@ static void launch_adj(void* stream, const ff_adj_args& a_in) {
 
 extern "C" {
 
-static size_t adj_table_doubles(int64_t B, int G) {
-  return (size_t)adj_grid(B, G) * 2 * FF_DEP_NLDS * FF_DEP_ROW + (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW;
+static size_t adj_table_doubles(int64_t B, int Gtab) {   // one private table per workgroup of the tabulated kernel + Wtot
+  return (size_t)adj_grid(B, Gtab) * 2 * FF_DEP_NLDS * FF_DEP_ROW + (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW;
 }
 
 // workspace = [direct rows | private tables + Wtot | off-table flag]
@@ -1011,7 +1002,7 @@ static size_t adj_direct_doubles(int64_t B, int G, int He, int Hm) { return (siz
 size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
   int G = adj_G(n, d);
   if (G == 0 || B <= 0) return 0;
-  return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, G) + 1);
+  return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d)) + 1);
 }
 
 static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
@@ -1056,13 +1047,13 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     const int Gq = adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
-    a.off_table = a.trows + adj_table_doubles(B, Gq);
+    a.off_table = a.trows + adj_table_doubles(B, adj_tab_G(n, d));
   }
   if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
   // both variants are enqueued; on the device exactly one of them runs, chosen by the radial-table header
   // (no table / weights too stiff for the deposit grid -> direct evaluation), so the host never has to look at it
-#define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
+#define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_adjtab_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
   FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2) else FF_ND(5, 2) else FF_ND(8, 2) else FF_ND(10, 2)
   else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2) else FF_ND(2, 3) else FF_ND(3, 3) else FF_ND(4, 3)
 #undef FF_ND
@@ -1075,8 +1066,9 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk * G, P, (const double*)a.rows, grad_params);
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
-    double* wtot = a.trows + (size_t)nblk * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, (const double*)a.off_table, nblk,
+    const int ntab = (int)adj_grid(B, adj_tab_G(n, d));     // workgroups (= private tables) of the tabulated kernel
+    double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
+    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)(2 * FF_DEP_NLDS * FF_DEP_ROW), FF_RBLOCK(128), stream, *net, (const double*)a.off_table, ntab,
               (const double*)a.trows, wtot);
     FF_LAUNCH_CHECK();
     FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)a.off_table,

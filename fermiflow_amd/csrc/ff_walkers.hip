@@ -560,6 +560,15 @@ ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, co
   if (t == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
+// One idle wave that returns after `ticks` of the 100 MHz constant clock: holds a side stream back for a few microseconds
+// so that the kernel the main stream launches at the same moment gets its waves placed first (ff_stream_delay)
+__global__ void ff_delay_kernel(unsigned long long ticks) {
+#ifndef FF_HOSTSIM
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+#endif
+}
+
 // Ground-state estimator sums in one pass (src/VMC.py:56-59): with c = shift[0] (any number every rank agrees on, e.g. the
 // previous sweep's mean: no cancellation)  out = [sum (e - c), sum (e - c)^2, sum logp, sum logp (e - c)].  One workgroup,
 // fixed tree: deterministic.  The sums of all ranks add up; ff_energy_finish turns the totals into E, the centred sum of
@@ -892,6 +901,13 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
                       double* out2) {
   FF_CHECK(B > 0 && e && out2, FF_EINVAL, "ff_reduce_moments: bad argument");
   FF_LAUNCH(ff_moments_kernel, 1, FF_RBLOCK(1024), stream, B, e, shift, shift_dev, shift_dev_scale, out2);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_stream_delay(void* stream, double microseconds) {
+  FF_CHECK(microseconds >= 0.0 && microseconds <= 1e5, FF_EINVAL, "ff_stream_delay: 0 .. 1e5 microseconds");
+  FF_LAUNCH(ff_delay_kernel, 1, FF_RBLOCK(64), stream, (unsigned long long)(microseconds * 100.0));   // 100 MHz constant clock
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

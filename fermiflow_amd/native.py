@@ -237,6 +237,11 @@ def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0):
     return out
 
 
+def stream_delay(microseconds):
+    """ff_stream_delay on the current stream."""
+    L.check(L.lib().ff_stream_delay(L.stream(), L.f64(microseconds)), "ff_stream_delay")
+
+
 def reduce_energy(e, logp, shift_dev):
     """ff_reduce_energy: tensor [sum(e - c), sum((e - c)^2), sum(logp), sum(logp (e - c))], c = shift_dev[0] (device)."""
     e = L.dev(e, name="e"); logp = L.dev(logp, name="logp"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")

@@ -205,6 +205,10 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
  * (the caller adds the sums4 of all ranks;)
  * ff_energy_finish: est3 = [E = mean e, sum (e - E)^2 (E_std^2 = est3[1] / (n - 1)), mean(logp (e - E)) -- the value of
  *   the reference's surrogate gradE] for n_global walkers.  One workgroup, fixed summation tree: deterministic. */
+/* Enqueues one idle wave that ends after `microseconds` (0 .. 1e5): the sweep uses it to start the next iteration's
+ * ff_mcmc_sample on a side stream a moment AFTER the adjoint kernel of the main stream -- launched the other way round
+ * the Metropolis waves fill every SIMD first and the two kernels run one after the other instead of side by side. */
+int ff_stream_delay(void* stream, double microseconds);
 int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4);
 int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3);
 

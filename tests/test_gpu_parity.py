@@ -617,6 +617,33 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     assert abs(Es[0] / Es[1] - 1) < 1e-7
 
 
+def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
+    """GSVMC.prefetch_walkers (default on): the next iteration's Metropolis kernel is started on a side stream beside this
+    iteration's adjoint.  Same seeds in the same order -> the same walkers: three training iterations with and without it
+    end in bit-identical energies and parameters; the prefetched walkers are part of the checkpoint state."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd.utils import make_adam
+    out = []
+    for flag in (True, False):
+        m = Gm._model(dev, 3, 3, 2.0)
+        m.prefetch_walkers = flag
+        opt = make_adam(m.parameters(), lr=1e-3)
+        torch.manual_seed(31)
+        Es = []
+        for it in range(3):
+            opt.zero_grad()
+            m(4096).backward()
+            opt.step()
+            Es.append((m.E, m.E_std))
+        torch.cuda.synchronize()
+        out.append((Es, [p.detach().clone() for p in m.parameters()], m))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+    st_on, st_off = out[0][2].get_extra_state(), out[1][2].get_extra_state()
+    assert "z_next" in st_on and st_on["z_next"].shape == (4096, 6, 2) and "z_next" not in st_off
+
+
 def test_persistent_walkers_opt_in(dev):
     """SURVEY 8(f).1, off by default: ff_mcmc_continue is the same chain as ff_mcmc_sample_noise fed the walkers and the
     materialised Philox stream; a GSVMC that keeps its walkers and advances them 10 steps per sweep samples the same
