@@ -223,7 +223,7 @@ struct ff_stepper {
     if (done) return false;
     natt++;
     bool acc = err < 1.0;
-#ifdef FF_HOSTSIM_TRACE
+#ifdef FF_HOSTSIM_TRACE   // host-simulator builds with -DFF_HOSTSIM_TRACE: FF_TRACE_STEPS=1 prints every step decision
     if (getenv("FF_TRACE_STEPS")) fprintf(stderr, "step t=%.6f h=%.3e err=%.3e %s\n", t, h, err, acc ? "acc" : "REJ");
 #endif
     if (acc) {
