@@ -1,5 +1,6 @@
 // ff_eloc_ws.h -- layout of the ff_eloc workspace between its launches (shared by ff_cnf_fwd.hip and ff_ho3d.hip):
 //   z(t0) (B,M) | Jt (B,M,M) | kbar (B,M) | dDelta (B,M) | lap parts (B,M) | Delta (B) | Slater table Q (B, nq) | 2 work counters
+// (the positions of z(t0) and Delta are documented in include/fermiflow.h: callers may read them in place)
 // nq = M + d(d+1)/2 n + d n^2 + 2: g0, the same-particle Hessian sums S, the gradient-times-inverse tables T of both spins
 // (at most d n^2 entries), 2 log|det| per spin.
 #pragma once

@@ -192,10 +192,14 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     x = L.dev(x, name="x")
     B, n, d = x.shape[0], nup + ndn, x.shape[2]
     f = dict(dtype=torch.float64, device=x.device)
-    out = dict(logp=torch.empty(B, **f), grad=torch.empty_like(x), lap=torch.empty(B, **f), V=torch.empty(B, **f),
-               eloc=torch.empty(B, **f), z=torch.empty_like(x), dlogp=torch.empty(B, **f), glogp0=torch.empty_like(x))
     nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, d)
     ws = torch.empty(max(1, nbytes // 8), **f)
+    # z(t0) and Delta stay where the sensitivity pass leaves them: views of the workspace (its documented head, include/fermiflow.h)
+    # instead of two device-to-device copies per sweep
+    M = n * d
+    out = dict(logp=torch.empty(B, **f), grad=torch.empty_like(x), lap=torch.empty(B, **f), V=torch.empty(B, **f),
+               eloc=torch.empty(B, **f), z=ws[:B * M].view(B, n, d), dlogp=ws[B * (M * M + 4 * M):B * (M * M + 4 * M) + B],
+               glogp0=torch.empty_like(x))
     st = _stats(x.device, want_stats)
     o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     if pass1_events is not None:
@@ -207,8 +211,8 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     finish = L.lib().ff_eloc_finish3d if d == 3 else L.lib().ff_eloc_finish      # d = 3: HO3D orbital tables (csrc/ff_ho3d.hip)
     L.check(finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
                                    L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(ws), L.ptr(out["logp"]), L.ptr(out["grad"]),
-                                   L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), L.ptr(out["z"]),
-                                   L.ptr(out["dlogp"]), L.ptr(out["glogp0"])), "ff_eloc_finish")
+                                   L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None,
+                                   None, L.ptr(out["glogp0"])), "ff_eloc_finish")
     if want_stats:
         out["stats"] = st
     return out

@@ -177,7 +177,10 @@ int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* n
  *   V = Coulomb + trap,  eloc = -lap/4 - |grad|^2/8 + V.
  * Any of logp, grad, lap, V, eloc may be NULL.  Optional extra outputs (may be NULL): z_out (B,n,2) = z(t0),
  * dlogp_out (B) = delta, glogp0_out (B,n,2) = grad_z logp0(z(t0)).
- * workspace: ff_eloc_workspace_bytes(B, n, 2) bytes of device memory (the sensitivities between the launches). */
+ * workspace: ff_eloc_workspace_bytes(B, n, 2) bytes of device memory (the sensitivities between the launches).
+ * Its head is part of the contract, for callers that want z(t0) and delta without a copy (z_out = dlogp_out = NULL): with
+ * M = n d, doubles [0, B M) hold z(t0) (B,n,d) and doubles [B (M^2 + 4 M), B (M^2 + 4 M) + B) hold delta (B) once pass 1 has
+ * run; both stay valid until the workspace is reused. */
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d);
 int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
             const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho,
