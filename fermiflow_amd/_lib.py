@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
+ABI_VERSION = 102      # ff_version() of the library this binding was written against (include/fermiflow.h)
+
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
     "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_mcmc_continue", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
@@ -43,6 +45,10 @@ def lib():
                 f"{LIB_PATH} not found: build the HIP kernels first (python -c 'import __graft_entry__ as g; g.build()' "
                 "or make -C fermiflow_amd/csrc). fermiflow_amd has no CPU fallback.")
         _LIB = C.CDLL(LIB_PATH)
+        if _LIB.ff_version() != ABI_VERSION:      # a stale build would read FFOde with the wrong layout
+            v, _LIB = _LIB.ff_version(), None
+            raise RuntimeError(f"{LIB_PATH} has ABI version {v}, this binding expects {ABI_VERSION}: rebuild "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
         _LIB.ff_last_error.restype = C.c_char_p
         _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
         _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t

@@ -74,7 +74,7 @@ typedef struct ff_ode {
                                  earlier call on other walkers of the same distribution, e.g. the mean of its walker_h_out) */
 } ff_ode;
 
-int ff_version(void);
+int ff_version(void);   /* 102; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* order (B) = walker indices sorted by descending cost (ties in a fixed order; classes above 31 count as 31); cost (B) >= 0, e.g. ff_ode.walker_cost. */
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);

@@ -18,7 +18,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_lib.SYMBOLS)
-    assert lib.ff_version() >= 100
+    from fermiflow_amd import _lib as L
+    assert lib.ff_version() == L.ABI_VERSION
 
 
 def test_header_is_plain_c_and_matches_the_ctypes_structs():
