@@ -54,6 +54,15 @@ def test_abi_argument_errors_without_gpu():
     assert lib.ff_cnf_generate(None, C.c_int64(4), 6, 2, C.byref(wide), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
     bad = _lib.FFOde(0.0, 1.0, -1.0, 1e-8, 0)
     assert lib.ff_cnf_generate(None, C.c_int64(4), 6, 2, C.byref(net), C.byref(bad), C.c_void_p(8), C.c_void_p(8), None) == 1
+    # round-2 entry points: empty batches, null pointers and out-of-range arguments
+    p8 = C.c_void_p(8)
+    assert lib.ff_reduce_energy(None, C.c_int64(0), p8, p8, p8, p8) == 1
+    assert lib.ff_reduce_energy(None, C.c_int64(4), p8, None, p8, p8) == 1
+    assert lib.ff_energy_finish(None, p8, p8, C.c_int64(0), p8) == 1
+    assert lib.ff_stream_delay(None, C.c_double(-1.0)) == 1 and lib.ff_stream_delay(None, C.c_double(1e9)) == 1
+    assert lib.ff_cnf_adjoint_energy(None, C.c_int64(4), 6, 2, C.byref(net), C.byref(ode), p8, p8, None, p8, C.c_double(0.25),
+                                     None, p8, p8, None) == 1                       # eloc missing
+    assert lib.ff_cnf_adjoint(None, C.c_int64(4), 6, 2, C.byref(net), C.byref(ode), p8, p8, None, None, p8, p8, None) == 1   # a_d missing
 
 
 def test_no_cpu_fallback():
