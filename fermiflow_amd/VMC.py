@@ -445,39 +445,31 @@ class BetaVMC(_Sweep, torch.nn.Module):
             tu, td = self._state_tables(device)
             x, r, he = self._flow_and_local_energy(net, z, tu, td, self.nup, self.ndown, ws, ev)
             Eloc = r["eloc"]
-            state_indices = ws.to(torch.int64)
-            logp_all = torch.log_softmax(self.log_state_weights.detach().to(device), dim=0)
-            logp_states = logp_all[state_indices]
-            Floc = Eloc + logp_states / self.beta
-            # one all-reduce: moments of E_loc and F_loc about the previous sweep's means + per-state (sum E_loc, count)
-            shE, momE = self._moments(Eloc, "E", nglob)
-            shF, momF = self._moments(Floc, "F", nglob)
-            stat = native.state_sums(Eloc, ws, Ns)       # per-state (sum E_loc, count): segments of the sorted state list
-            buf1 = torch.cat([momE, momF, stat.reshape(-1)])
+            # Estimator (src/VMC.py:146-171) in two launches around ONE all-reduce: moments of E_loc about the previous sweep's
+            # mean + partial per-state sums of (E_loc, 1, logp, logp E_loc); ff_beta_finish turns the totals into E, F, S, both
+            # surrogates' values, the logits gradient (closed form) and the per-state baseline, which the adjoint reads by
+            # state index when it forms its seeds (ff_cnf_adjoint_energy) -- no per-walker torch arithmetic, no host round trip
+            prev = self._dev.get("E")
+            shE = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=Eloc.dtype, device=device)
+            buf1 = native.beta_buffer(Ns, device)
+            native.reduce_moments(Eloc, shift_dev=shE, out=buf1[:2])
+            native.beta_state_partials(Eloc, r["logp"], ws, Ns, buf1)
             D.all_reduce_sum_(buf1)
-            self._set_moments("E", shE, buf1[0:2], nglob)
-            self._set_moments("F", shF, buf1[2:4], nglob)
-            sums, cnts = buf1[4:4 + Ns], buf1[4 + Ns:4 + 2 * Ns]
-            self._dev["S"] = -(cnts * logp_all).sum() / nglob                      # -mean log p(state), src/VMC.py:155
-            self._dev["S_analytical"] = -(logp_all * logp_all.exp()).sum()
+            logits = self.log_state_weights.detach().to(device)
+            est, g_phi, mean_e, logp_all = native.beta_finish(buf1, shE, logits, self.beta, nglob)
+            for k, key in enumerate(("E", "E_ss", "F", "F_ss", "S", "S_analytical")):
+                self._dev[key] = est[k]
+            self._n_global = nglob
             self.logp_states_all = logp_all.to(self.log_state_weights.device)
-            # gradF_phi = mean(logp_states (Floc - F)) (src/VMC.py:162) and its gradient wrt the logits, from the per-state
-            # sums alone:  sum_b cF_b log_softmax(logits)[s_b],  cF_s = sum_{b in s} (Floc_b - F)/n
-            cF_state = (sums + cnts * logp_all / self.beta - cnts * self._dev["F"]) / nglob
-            gphi_val = (logp_all * cF_state).sum()
-            g_phi = (cF_state - logp_all.exp() * cF_state.sum()).to(self.log_state_weights.device)
-            Eloc_x_mean = (sums / cnts.clamp(min=1.0))[state_indices]       # per-state baseline (src/VMC.py:164-169)
-            w = (Eloc - Eloc_x_mean) / nglob
             self._mark(ev, "estimator")
-            _, gp = native.cnf_adjoint(net, r["z"], w[:, None, None] * r["glogp0"], -w, t0, t1,
-                                       self.cnf.rtol, self.cnf.atol, need_gx=False,
-                                       walker_h_init=he, walker_h_scale=1.25)
-            buf = torch.cat([(r["logp"] * w).sum().reshape(1), gp])
-            D.all_reduce_sum_(buf)
+            _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol, need_gx=False,
+                                       energy=(Eloc, mean_e, 1.0 / nglob, ws), walker_h_init=he, walker_h_scale=1.25)
+            D.all_reduce_sum_(gp)
             self._mark(ev, "adjoint")
         if prof is not None:
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
-        gradF_phi = _ScalarWithParamGrads.apply(gphi_val.to(self.log_state_weights.device), g_phi.reshape(-1), self.log_state_weights)
-        gradF_theta = _ScalarWithParamGrads.apply(buf[0], buf[1:], *params)
+        pdev = self.log_state_weights.device
+        gradF_phi = _ScalarWithParamGrads.apply(est[6].to(pdev), g_phi.to(pdev), self.log_state_weights)
+        gradF_theta = _ScalarWithParamGrads.apply(est[7], gp, *params)
         return gradF_phi, gradF_theta

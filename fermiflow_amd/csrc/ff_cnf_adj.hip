@@ -36,6 +36,7 @@ struct ff_adj_args {
   // a_z = w_b * az_in[b] and a_Delta = -w_b (ad_in unused) -- the estimator's weights are formed where they are consumed
   const double* w_e;
   const double* w_mean;
+  const int32_t* w_index;   // optional (B): which entry of w_mean is walker b's baseline (BetaVMC: its many-body state); NULL: entry 0
   double w_scale;
   double* gx_out;       // (B, M)  gradient wrt x = z(t1); may be NULL
   double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials (direct kernel)
@@ -116,7 +117,8 @@ ff_ode_adj_kernel(ff_adj_args A) {
     {
       // seeds: given, or formed from the local energies (ff_cnf_adjoint_energy); all loads branch-free (ff_opt_load)
       const bool ws = A.w_e != nullptr;
-      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, ws, 0, A.z_in, 0.0)) * A.w_scale;
+      const int wi = ff_opt_load(A.w_index, valid && ws, b, A.z_in, (int32_t)0);
+      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, valid && ws, wi, A.z_in, 0.0)) * A.w_scale;
       const double az0 = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0), ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
       y[1] = ws ? wb * az0 : az0;
       if (ingrp && i == 0) s_ad[g] = ws ? -wb : ad0;
@@ -617,7 +619,8 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     {
       // seeds: given, or formed from the local energies (ff_cnf_adjoint_energy); all loads branch-free (ff_opt_load)
       const bool ws = A.w_e != nullptr;
-      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, ws, 0, A.z_in, 0.0)) * A.w_scale;
+      const int wi = ff_opt_load(A.w_index, valid && ws, b, A.z_in, (int32_t)0);
+      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, valid && ws, wi, A.z_in, 0.0)) * A.w_scale;
       const double az0 = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0), ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
       y[1] = ws ? wb * az0 : az0;
       if (ingrp && i == 0) s_ad[g] = ws ? -wb : ad0;
@@ -1024,26 +1027,27 @@ size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
 }
 
 static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
-                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, double w_scale,
-                        double* grad_x, double* grad_params, void* workspace, int32_t* stats);
+                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, const int32_t* w_index,
+                        double w_scale, double* grad_x, double* grad_params, void* workspace, int32_t* stats);
 
 int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
                    const double* a_z, const double* a_d, double* grad_x, double* grad_params, void* workspace,
                    int32_t* stats) {
   FF_CHECK(B == 0 || a_d, FF_EINVAL, "ff_cnf_adjoint: null pointer");
-  return adjoint_impl(stream, B, n, d, net, ode, z_t0, a_z, a_d, nullptr, nullptr, 0.0, grad_x, grad_params, workspace, stats);
+  return adjoint_impl(stream, B, n, d, net, ode, z_t0, a_z, a_d, nullptr, nullptr, nullptr, 0.0, grad_x, grad_params, workspace, stats);
 }
 
 int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
-                          const double* glogp0, const double* eloc, const double* e_mean, double scale, double* grad_x,
-                          double* grad_params, void* workspace, int32_t* stats) {
+                          const double* glogp0, const double* eloc, const double* e_mean, const int32_t* mean_index, double scale,
+                          double* grad_x, double* grad_params, void* workspace, int32_t* stats) {
   FF_CHECK(B == 0 || (eloc && e_mean), FF_EINVAL, "ff_cnf_adjoint_energy: null pointer");
-  return adjoint_impl(stream, B, n, d, net, ode, z_t0, glogp0, nullptr, eloc, e_mean, scale, grad_x, grad_params, workspace, stats);
+  return adjoint_impl(stream, B, n, d, net, ode, z_t0, glogp0, nullptr, eloc, e_mean, mean_index, scale, grad_x, grad_params, workspace,
+                      stats);
 }
 
 static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
-                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, double w_scale,
-                        double* grad_x, double* grad_params, void* workspace, int32_t* stats) {
+                        const double* a_z, const double* a_d, const double* w_e, const double* w_mean, const int32_t* w_index,
+                        double w_scale, double* grad_x, double* grad_params, void* workspace, int32_t* stats) {
   FF_CHECK(B >= 0 && n > 0 && d > 0 && net && ode && grad_params, FF_EINVAL, "ff_cnf_adjoint: bad argument");
   FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
            "ff_cnf_adjoint: bad net");
@@ -1060,7 +1064,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
-  a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_index = w_index; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   {
     const int Gq = adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }

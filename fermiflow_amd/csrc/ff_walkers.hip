@@ -641,6 +641,117 @@ ff_state_sums_kernel(int64_t B, const int* __restrict__ ws, const double* __rest
   if (t == 0) { sums[s] = sm[0]; counts[s] = (double)(b1 - b0); }
 }
 
+// Finite-temperature estimator in two launches around the all-reduce (src/VMC.py:146-171).
+// (1) ff_state_part_kernel: the sorted state list cut into FF_SS_K slices per state -- partial sums
+//     part[s][k] = (sum e, count, sum logp, sum logp e) over slice k of state s, one workgroup each, fixed tree (at beta = 10
+//     every walker sits in state 0: one workgroup per state took 31 us for 65 536 walkers).  Partial sums of all ranks add up.
+#define FF_SS_K 16
+__global__ void __launch_bounds__(256)
+ff_state_part_kernel(int64_t B, const int* __restrict__ ws, const double* __restrict__ e, const double* __restrict__ logp,
+                     double* __restrict__ part) {
+  __shared__ double sm[3][256];
+  const int s = blockIdx.x / FF_SS_K, k = blockIdx.x % FF_SS_K, t = threadIdx.x, nt = blockDim.x;
+  auto lower = [&](int key) -> int64_t {   // first index with ws[i] >= key
+    int64_t lo = 0, hi = B;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ws[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int64_t b0 = lower(s), b1 = lower(s + 1), len = b1 - b0;
+  const int64_t c0 = b0 + len * k / FF_SS_K, c1 = b0 + len * (k + 1) / FF_SS_K;
+  double a = 0.0, l = 0.0, m = 0.0;
+  for (int64_t i = c0 + t; i < c1; i += nt) { const double ei = e[i], li = logp[i]; a += ei; l += li; m = fma(li, ei, m); }
+  sm[0][t] = a; sm[1][t] = l; sm[2][t] = m;
+  __syncthreads();
+  int w = 1;
+  while (w * 2 < nt) w *= 2;
+  for (; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) { sm[0][t] += sm[0][t + w]; sm[1][t] += sm[1][t + w]; sm[2][t] += sm[2][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double* o = part + ((size_t)s * FF_SS_K + k) * 4;
+    o[0] = sm[0][0]; o[1] = (double)(c1 - c0); o[2] = sm[1][0]; o[3] = sm[2][0];
+  }
+}
+
+// (2) ff_beta_finish_kernel, one workgroup: from buf = [sum (e - c), sum (e - c)^2 | part (all ranks added)], the logits and
+//     beta it forms everything BetaVMC.forward reports and both surrogates' ingredients:
+//     est = [E, sum (e - E)^2, F, sum (f - F)^2, S, S_analytical, gradF_phi value, gradF_theta value]
+//     (f_b = e_b + log p(s_b) / beta; S = -mean log p(s_b); gradF_phi = mean(log p(s_b) (f_b - F)), src/VMC.py:162;
+//      gradF_theta = mean(logp_b (e_b - mean_e[s_b])), src/VMC.py:164-169),
+//     gphi[s] = d gradF_phi / d logits[s],  mean_e[s] = the per-state baseline,  logp_all = log_softmax(logits).
+__global__ void __launch_bounds__(256)
+ff_beta_finish_kernel(const double* __restrict__ buf, const double* __restrict__ shift_dev, const double* __restrict__ logits, int Ns,
+                      double beta, double n, double* __restrict__ est, double* __restrict__ gphi, double* __restrict__ mean_e,
+                      double* __restrict__ logp_all) {
+  __shared__ double sm[256];
+  const int t = threadIdx.x, nt = blockDim.x;
+  auto block_sum = [&](double v) -> double {     // fixed tree; every thread gets the total
+    sm[t] = v;
+    __syncthreads();
+    int w = 1;
+    while (w * 2 < nt) w *= 2;
+    for (; w > 0; w >>= 1) {
+      if (t < w && t + w < nt) sm[t] += sm[t + w];
+      __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+  };
+  auto block_max = [&](double v) -> double {
+    sm[t] = v;
+    __syncthreads();
+    int w = 1;
+    while (w * 2 < nt) w *= 2;
+    for (; w > 0; w >>= 1) {
+      if (t < w && t + w < nt) sm[t] = fmax(sm[t], sm[t + w]);
+      __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+  };
+  const double* part = buf + 2;
+  double mx = -1e300;
+  for (int s = t; s < Ns; s += nt) mx = fmax(mx, logits[s]);
+  mx = block_max(mx);
+  double z = 0.0;
+  for (int s = t; s < Ns; s += nt) z += exp(logits[s] - mx);
+  const double lz = mx + log(block_sum(z));
+  // per state: sums over the slices in a fixed order
+  double sF = 0.0, sCE = 0.0, sCC = 0.0, sS = 0.0, sSa = 0.0;
+  for (int s = t; s < Ns; s += nt) {
+    double se = 0.0, cnt = 0.0;
+    for (int k = 0; k < FF_SS_K; k++) { const double* o = part + ((size_t)s * FF_SS_K + k) * 4; se += o[0]; cnt += o[1]; }
+    const double lp = logits[s] - lz, c = lp / beta;
+    logp_all[s] = lp;
+    mean_e[s] = se / fmax(cnt, 1.0);
+    sF += se + cnt * c; sCE += c * se; sCC += cnt * c * c; sS += cnt * lp; sSa += lp * exp(lp);
+  }
+  sF = block_sum(sF); sCE = block_sum(sCE); sCC = block_sum(sCC); sS = block_sum(sS); sSa = block_sum(sSa);
+  const double c0 = shift_dev[0], d = buf[0] / n;            // E - c
+  const double E = c0 + d, Ess = buf[1] - buf[0] * d, F = sF / n;
+  // sum f^2 = sum e^2 + 2 sum_s c_s sum_e(s) + sum_s cnt_s c_s^2,  sum e^2 = sum (e - c)^2 + 2 c sum (e - c) + n c^2
+  const double se2 = buf[1] + 2.0 * c0 * buf[0] + n * c0 * c0;
+  const double Fss = se2 + 2.0 * sCE + sCC - n * F * F;
+  double sG = 0.0, sC = 0.0, sT = 0.0;
+  for (int s = t; s < Ns; s += nt) {
+    double se = 0.0, cnt = 0.0, sl = 0.0, sle = 0.0;
+    for (int k = 0; k < FF_SS_K; k++) { const double* o = part + ((size_t)s * FF_SS_K + k) * 4; se += o[0]; cnt += o[1]; sl += o[2]; sle += o[3]; }
+    const double lp = logits[s] - lz;
+    const double cF = (se + cnt * lp / beta - cnt * F) / n;
+    gphi[s] = cF;                      // completed below
+    sG += lp * cF; sC += cF;
+    sT += sle - (se / fmax(cnt, 1.0)) * sl;
+  }
+  sG = block_sum(sG); sC = block_sum(sC); sT = block_sum(sT);
+  for (int s = t; s < Ns; s += nt) gphi[s] -= exp(logits[s] - lz) * sC;
+  if (t == 0) {
+    est[0] = E; est[1] = Ess; est[2] = F; est[3] = Fss; est[4] = -sS / n; est[5] = -sSa; est[6] = sG; est[7] = sT / n;
+  }
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -922,6 +1033,26 @@ int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* log
 int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3) {
   FF_CHECK(sums4 && shift_dev && est3 && n_global > 0, FF_EINVAL, "ff_energy_finish: bad argument");
   FF_LAUNCH(ff_energy_finish_kernel, 1, FF_RBLOCK(64), stream, sums4, shift_dev, (double)n_global, est3);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+size_t ff_beta_buffer_doubles(int nstates) { return nstates > 0 ? 2 + (size_t)nstates * FF_SS_K * 4 : 0; }
+
+int ff_beta_state_partials(void* stream, int64_t B, int nstates, const int32_t* walker_state, const double* e, const double* logp,
+                           double* buf) {
+  FF_CHECK(B >= 0 && nstates > 0 && buf && (B == 0 || (walker_state && e && logp)), FF_EINVAL, "ff_beta_state_partials: bad argument");
+  FF_LAUNCH(ff_state_part_kernel, (unsigned)(nstates * FF_SS_K), FF_RBLOCK(256), stream, B, walker_state, e, logp, buf + 2);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_beta_finish(void* stream, const double* buf, const double* shift_dev, const double* logits, int nstates, double beta,
+                   int64_t n_global, double* est8, double* gphi, double* mean_e, double* logp_all) {
+  FF_CHECK(buf && shift_dev && logits && nstates > 0 && beta > 0.0 && n_global > 0 && est8 && gphi && mean_e && logp_all, FF_EINVAL,
+           "ff_beta_finish: bad argument");
+  FF_LAUNCH(ff_beta_finish_kernel, 1, FF_RBLOCK(256), stream, buf, shift_dev, logits, nstates, beta, (double)n_global, est8, gphi, mean_e,
+            logp_all);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -163,8 +163,9 @@ def cnf_delta_logp(net, x, t0, t1, rtol, atol, want_stats=False, walker_cost=Non
 def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, want_stats=False, walker_cost=None,
                 walker_order=None, energy=None, **warm):
     """Adjoint sweep from t_from (where y_start, a_z, a_d are given) to t_to.
-    energy = (eloc (B,), e_mean 1-element device tensor, scale): ff_cnf_adjoint_energy -- a_z is glogp0 (B,n,d) and the
-    kernel forms the seeds w_b * glogp0[b], -w_b with w_b = (eloc[b] - e_mean) * scale itself (a_d is ignored)."""
+    energy = (eloc (B,), e_mean device tensor, scale[, mean_index int32 (B,)]): ff_cnf_adjoint_energy -- a_z is glogp0
+    (B,n,d) and the kernel forms the seeds w_b * glogp0[b], -w_b with w_b = (eloc[b] - e_mean[mean_index[b] or 0]) * scale
+    itself (a_d is ignored)."""
     y = L.dev(y_start, name="y_start"); a_z = L.dev(a_z, name="a_z")
     if energy is None:
         a_d = L.dev(a_d, name="a_d")
@@ -176,9 +177,11 @@ def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, 
     st = _stats(y.device, want_stats)
     o = L.ode(t_from, t_to, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     if energy is not None:
-        e = L.dev(energy[0], name="eloc"); em = L.dev(energy[1].reshape(-1)[:1], name="e_mean")
+        e = L.dev(energy[0], name="eloc")
+        mi = L.dev(energy[3], torch.int32, "mean_index") if len(energy) > 3 and energy[3] is not None else None
+        em = L.dev(energy[1].reshape(-1) if mi is not None else energy[1].reshape(-1)[:1], name="e_mean")
         L.check(L.lib().ff_cnf_adjoint_energy(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(e), L.ptr(em),
-                                              L.f64(energy[2]), L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint_energy")
+                                              L.ptr(mi), L.f64(energy[2]), L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint_energy")
     else:
         L.check(L.lib().ff_cnf_adjoint(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(y), L.ptr(a_z), L.ptr(a_d),
                                        L.ptr(gx), L.ptr(gp), L.ptr(ws), L.ptr(st)), "ff_cnf_adjoint")
@@ -229,11 +232,11 @@ def walker_order(cost):
     return order
 
 
-def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0):
+def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0, out=None):
     """tensor [sum(e - shift), sum((e - shift)^2)] on the device; shift_dev: optional 1-element device tensor, then
-    shift = shift_dev[0] * shift_dev_scale (no host round trip for the mean)."""
+    shift = shift_dev[0] * shift_dev_scale (no host round trip for the mean); out: where to write the two sums."""
     e = L.dev(e, name="e")
-    out = torch.empty(2, dtype=torch.float64, device=e.device)
+    out = torch.empty(2, dtype=torch.float64, device=e.device) if out is None else out
     if shift_dev is not None:
         shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
     L.check(L.lib().ff_reduce_moments(L.stream(), L.i64(e.numel()), L.ptr(e), L.f64(shift), L.ptr(shift_dev),
@@ -260,6 +263,28 @@ def energy_finish(sums4, shift_dev, n_global):
     out = torch.empty(3, dtype=torch.float64, device=sums4.device)
     L.check(L.lib().ff_energy_finish(L.stream(), L.ptr(sums4), L.ptr(shift_dev), L.i64(n_global), L.ptr(out)), "ff_energy_finish")
     return out
+
+
+def beta_buffer(nstates, device):
+    """buffer of ff_beta_state_partials / ff_beta_finish: [0:2] moments of E_loc, [2:] partial per-state sums."""
+    return torch.empty(L.lib().ff_beta_buffer_doubles(int(nstates)), dtype=torch.float64, device=device)
+
+
+def beta_state_partials(e, logp, walker_state, nstates, buf):
+    e = L.dev(e, name="e"); logp = L.dev(logp, name="logp"); ws = L.dev(walker_state, torch.int32, "walker_state")
+    L.check(L.lib().ff_beta_state_partials(L.stream(), L.i64(e.numel()), int(nstates), L.ptr(ws), L.ptr(e), L.ptr(logp), L.ptr(buf)),
+            "ff_beta_state_partials")
+
+
+def beta_finish(buf, shift_dev, logits, beta, n_global):
+    """ff_beta_finish: (est8, gphi, mean_e, logp_all) from the all-reduced buffer."""
+    logits = L.dev(logits, name="logits"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
+    ns = logits.numel()
+    f = dict(dtype=torch.float64, device=buf.device)
+    est, gphi, mean_e, lpa = torch.empty(8, **f), torch.empty(ns, **f), torch.empty(ns, **f), torch.empty(ns, **f)
+    L.check(L.lib().ff_beta_finish(L.stream(), L.ptr(buf), L.ptr(shift_dev), L.ptr(logits), ns, L.f64(beta), L.i64(n_global),
+                                   L.ptr(est), L.ptr(gphi), L.ptr(mean_e), L.ptr(lpa)), "ff_beta_finish")
+    return est, gphi, mean_e, lpa
 
 
 def state_sums(e, walker_state, nstates):

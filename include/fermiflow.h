@@ -162,11 +162,13 @@ int ff_cnf_adjoint(void* stream, int64_t B, int n, int d, const ff_net* net, con
                    const double* z_t0, const double* a_z, const double* a_d,
                    double* grad_x, double* grad_params, void* workspace, int32_t* stats);
 /* The same adjoint with the seeds of the energy gradient (src/VMC.py:58-59, gradE = mean(logp (E_loc - E))) formed inside
- * the kernel: with w_b = (eloc[b] - e_mean[0]) * scale  (e_mean: DEVICE pointer, e.g. est3 of ff_energy_finish; scale =
- * 1 / global batch)  it is ff_cnf_adjoint(a_z = w_b * glogp0[b], a_d = -w_b) -- no (B,n,d) seed array and no host round
- * trip for the mean. */
+ * the kernel: with w_b = (eloc[b] - e_mean[k_b]) * scale  (e_mean: DEVICE array, e.g. est of ff_energy_finish; k_b =
+ * mean_index[b], or 0 for all walkers if mean_index is NULL; scale = 1 / global batch)  it is
+ * ff_cnf_adjoint(a_z = w_b * glogp0[b], a_d = -w_b) -- no (B,n,d) seed array and no host round trip for the mean.
+ * mean_index = the walkers' many-body states gives BetaVMC's per-state baseline (src/VMC.py:164-169). */
 int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
-                          const double* z_t0, const double* glogp0, const double* eloc, const double* e_mean, double scale,
+                          const double* z_t0, const double* glogp0, const double* eloc, const double* e_mean,
+                          const int32_t* mean_index, double scale,
                           double* grad_x, double* grad_params, void* workspace, int32_t* stats);
 
 /* ---- local energy (src/VMC.py:46-55 via src/utils.py:40-65) --------------------------------- */
@@ -244,6 +246,19 @@ int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* n
  * (src/VMC.py:94-96); sums[s] = sum of e[b] over the walkers in state s, counts[s] = their number (as doubles, ready for
  * an all-reduce).  One workgroup per state, fixed summation tree: deterministic. */
 int ff_state_sums(void* stream, int64_t B, int nstates, const int32_t* walker_state, const double* e, double* sums, double* counts);
+/* BetaVMC.forward's estimator (src/VMC.py:146-171) in two launches around its one all-reduce.  buf holds
+ * ff_beta_buffer_doubles(nstates) doubles: [0, 2) the caller's moments of E_loc about shift_dev[0] (ff_reduce_moments),
+ * from 2 on the partial per-state sums (sum e, count, sum logp, sum logp e; 16 slices per state) that
+ * ff_beta_state_partials writes (walker_state sorted, as for ff_state_sums).  The caller adds the buffers of all ranks;
+ * ff_beta_finish then gives est8 = [E, sum (e - E)^2, F, sum (f - F)^2, S, S_analytical, value of gradF_phi, value of
+ * gradF_theta], gphi [nstates] = d gradF_phi / d logits, mean_e [nstates] = the per-state baseline of gradF_theta (feed it
+ * to ff_cnf_adjoint_energy with mean_index = walker_state) and logp_all [nstates] = log_softmax(logits).
+ * One workgroup, fixed summation trees: deterministic. */
+size_t ff_beta_buffer_doubles(int nstates);
+int ff_beta_state_partials(void* stream, int64_t B, int nstates, const int32_t* walker_state, const double* e, const double* logp,
+                           double* buf);
+int ff_beta_finish(void* stream, const double* buf, const double* shift_dev, const double* logits, int nstates, double beta,
+                   int64_t n_global, double* est8, double* gphi, double* mean_e, double* logp_all);
 
 #ifdef __cplusplus
 }

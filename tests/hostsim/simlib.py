@@ -234,15 +234,32 @@ def energy_finish(sums4, shift, n):
     return out
 
 
-def cnf_adjoint_energy(z0, glogp0, eloc, e_mean, scale, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8):
+def cnf_adjoint_energy(z0, glogp0, eloc, e_mean, scale, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, mean_index=None):
     z0 = _d(z0); glogp0 = _d(glogp0); eloc = _d(eloc); B, n, d = z0.shape
-    em = np.array([e_mean], dtype=np.float64)
+    em = np.atleast_1d(np.asarray(e_mean, dtype=np.float64)).copy()
+    mi = _i(mean_index) if mean_index is not None else None
     gx = np.empty_like(z0); gp = np.empty(3 * net.c.He + 3 * net.c.Hm); stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol)
     lib().ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
     ws = np.zeros(max(1, lib().ff_cnf_adjoint_workspace_bytes(C.c_int64(B), n, d, net.c.He, net.c.Hm) // 8))
     _ck(lib().ff_cnf_adjoint_energy(None, C.c_int64(B), n, d, C.byref(net.c), C.byref(ode), _p(z0), _p(glogp0), _p(eloc), _p(em),
-                                    C.c_double(scale), _p(gx), _p(gp), _p(ws), _p(stats)))
+                                    _p(mi), C.c_double(scale), _p(gx), _p(gp), _p(ws), _p(stats)))
     return gx, gp, stats
+
+
+def beta_estimator(e, logp, ws, logits, beta, shift, n_global=None):
+    """ff_reduce_moments + ff_beta_state_partials + ff_beta_finish on one rank: (est8, gphi, mean_e, logp_all)."""
+    e = _d(e); logp = _d(logp); ws = _i(ws); logits = _d(logits); ns = len(logits)
+    lib().ff_beta_buffer_doubles.restype = C.c_size_t
+    buf = np.zeros(lib().ff_beta_buffer_doubles(ns))
+    sh = np.array([shift], dtype=np.float64)
+    mom = np.empty(2)
+    _ck(lib().ff_reduce_moments(None, C.c_int64(len(e)), _p(e), C.c_double(0.0), _p(sh), C.c_double(1.0), _p(mom)))
+    _ck(lib().ff_beta_state_partials(None, C.c_int64(len(e)), ns, _p(ws), _p(e), _p(logp), _p(buf)))
+    buf[:2] = mom
+    est, gphi, mean_e, lpa = np.empty(8), np.empty(ns), np.empty(ns), np.empty(ns)
+    _ck(lib().ff_beta_finish(None, _p(buf), _p(sh), _p(logits), ns, C.c_double(beta), C.c_int64(n_global or len(e)), _p(est), _p(gphi),
+                             _p(mean_e), _p(lpa)))
+    return est, gphi, mean_e, lpa
 
 
 def moments(e, shift=0.0):

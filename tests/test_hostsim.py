@@ -515,3 +515,41 @@ def test_energy_estimator_and_energy_seeded_adjoint(golden):
     assert st0[3] == 0 and st1[3] == 0
     np.testing.assert_allclose(gx1, gx0, rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(gp1, gp0, rtol=1e-12, atol=1e-15)
+
+
+def test_finite_temperature_estimator_kernels(golden):
+    """ff_beta_state_partials + ff_beta_finish == the formulas of BetaVMC.forward (src/VMC.py:146-171) evaluated with numpy;
+    ff_cnf_adjoint_energy with a per-state baseline == ff_cnf_adjoint on the seeds (e - mean_e[state]) / n."""
+    rng = np.random.default_rng(11)
+    ns, B, beta = 7, 403, 3.0
+    logits = rng.normal(size=ns)
+    ws = np.sort(rng.choice(ns, size=B, p=[0.5, 0.2, 0.1, 0.1, 0.05, 0.05, 0.0])).astype(np.int32)     # state 6 is empty
+    e = 30.0 + rng.normal(size=B) * 3.0
+    lp = -20.0 + rng.normal(size=B)
+    est, gphi, mean_e, lpa = S.beta_estimator(e, lp, ws, logits, beta, shift=29.0)
+    lsm = logits - (np.log(np.exp(logits - logits.max()).sum()) + logits.max())
+    np.testing.assert_allclose(lpa, lsm, rtol=1e-13, atol=1e-14)
+    f = e + lsm[ws] / beta
+    cnt = np.bincount(ws, minlength=ns).astype(float)
+    sums = np.bincount(ws, weights=e, minlength=ns)
+    me = sums / np.maximum(cnt, 1.0)
+    np.testing.assert_allclose(mean_e, me, rtol=1e-13)
+    F = f.mean()
+    want = [e.mean(), ((e - e.mean()) ** 2).sum(), F, ((f - F) ** 2).sum(), -(lsm[ws]).mean(), -(lsm * np.exp(lsm)).sum(),
+            (lsm[ws] * (f - F)).mean(), (lp * (e - me[ws])).mean()]
+    np.testing.assert_allclose(est, want, rtol=1e-9, atol=1e-10)
+    cF = (sums + cnt * lsm / beta - cnt * F) / B
+    np.testing.assert_allclose(gphi, cF - np.exp(lsm) * cF.sum(), rtol=1e-10, atol=1e-13)
+    # per-state baseline inside the adjoint
+    G = golden["g5_gsvmc"]
+    eta, mu = net_arrays(G, "z2_nt_")
+    net = S.Net(eta, mu, table=True)
+    x = G["z2_nt_x"][:6]
+    r = S.eloc(x, 3, 3, net, 2.0)
+    st = np.array([0, 0, 1, 1, 1, 2], dtype=np.int32)
+    m3 = np.array([r["eloc"][:2].mean(), r["eloc"][2:5].mean(), r["eloc"][5]])
+    w = (r["eloc"] - m3[st]) / 6
+    gx0, gp0, _ = S.cnf_adjoint(r["z"], w[:, None, None] * r["glogp0"], -w, net)
+    gx1, gp1, _ = S.cnf_adjoint_energy(r["z"], r["glogp0"], r["eloc"], m3, 1.0 / 6, net, mean_index=st)
+    np.testing.assert_allclose(gx1, gx0, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(gp1, gp0, rtol=1e-12, atol=1e-15)
