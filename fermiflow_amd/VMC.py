@@ -126,18 +126,6 @@ class _Sweep:
             prof.setdefault("eloc_stats", []).append(r["stats"])
         return x, r, he
 
-    def _moments(self, e, key, n_global):
-        """[sum(e - c), sum((e - c)^2)] about a shift c every rank knows -- the previous sweep's mean (0 on the first sweep)
-        -- so that mean and variance come out of ONE pass and ONE all-reduce without cancellation (|mean - c| << std)."""
-        prev = self._dev.get(key)
-        shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=e.dtype, device=e.device)
-        return shift, native.reduce_moments(e, shift_dev=shift)
-
-    def _set_moments(self, key, shift, mom, n_global):
-        self._dev[key] = shift[0] + mom[0] / n_global
-        self._dev[key + "_ss"] = mom[1] - mom[0] * mom[0] / n_global
-        self._n_global = n_global
-
     def _scalar(self, key):
         return self._dev[key].item()
 
