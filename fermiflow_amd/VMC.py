@@ -140,7 +140,7 @@ class _Sweep:
         if getattr(self, "_z_prev", None) is not None:
             st["z_prev"] = self._z_prev
         if getattr(self, "_z_next", None) is not None:      # prefetched walkers of the next iteration (GSVMC)
-            zn, done, nloc = self._z_next
+            zn, done = self._z_next[0], self._z_next[1]
             if done is not None:
                 done.synchronize()
             st["z_next"] = zn
@@ -153,7 +153,7 @@ class _Sweep:
         if "z_prev" in st:
             self._z_prev = st["z_prev"]
         if "z_next" in st and hasattr(self, "_z_next"):
-            self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]))
+            self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), None)      # (the checkpoint restores the generator too)
 
 
 class GSVMC(_Sweep, torch.nn.Module):
@@ -177,7 +177,7 @@ class GSVMC(_Sweep, torch.nn.Module):
         # DESIGN.md 6).  Same seeds in the same order, hence the same walkers as without it; the prefetched walkers travel in
         # checkpoints.
         self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1") != "0"
-        self._z_next = None          # (walkers, event on the side stream, nloc)
+        self._z_next = None          # (walkers, event on the side stream, nloc, CPU generator state after their seed was drawn)
         self._side = None
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
@@ -229,8 +229,8 @@ class GSVMC(_Sweep, torch.nn.Module):
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
                                          equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
-            elif self._z_next is not None and self._z_next[2] == nloc and not self.persistent_walkers:
-                z, done, _ = self._z_next          # sampled beside the previous iteration's adjoint
+            elif self._prefetched_ok(nloc):
+                z, done = self._z_next[0], self._z_next[1]          # sampled beside the previous iteration's adjoint
                 if done is not None:
                     torch.cuda.current_stream().wait_event(done)
                     z.record_stream(torch.cuda.current_stream())
@@ -240,6 +240,15 @@ class GSVMC(_Sweep, torch.nn.Module):
             self._z_prev = z if self.persistent_walkers else None
         self._mark(ev, "mcmc")
         return self._sweep(z, batch, ev, prefetch=nloc if (self.prefetch_walkers and not self.persistent_walkers and z.is_cuda) else 0)
+
+    def _prefetched_ok(self, nloc):
+        """The prefetched walkers stand for "sample now" only if nothing touched torch's CPU generator since their seed was drawn
+        from it: after a torch.manual_seed() (or any draw) in between they are dropped and fresh ones are sampled, so re-seeding
+        between iterations means what it means without the prefetch."""
+        if self._z_next is None or self.persistent_walkers or self._z_next[2] != nloc:
+            return False
+        snap = self._z_next[3]
+        return snap is None or torch.equal(snap, torch.get_rng_state())
 
     def _prefetch(self, nloc, go):
         """Next iteration's walkers on the side stream: starts when `go` (recorded on the main stream in front of the adjoint)
@@ -253,7 +262,7 @@ class GSVMC(_Sweep, torch.nn.Module):
             z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
             done = torch.cuda.Event()
             done.record()
-        self._z_next = (z, done, nloc)
+        self._z_next = (z, done, nloc, torch.get_rng_state())
 
     def forward_from(self, z, batch=None):
         """forward() on GIVEN base walkers z (nloc, n, 2) -- this rank's shard of a global batch of `batch` walkers

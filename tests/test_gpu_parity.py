@@ -642,6 +642,12 @@ def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
         assert torch.equal(a, b)
     st_on, st_off = out[0][2].get_extra_state(), out[1][2].get_extra_state()
     assert "z_next" in st_on and st_on["z_next"].shape == (4096, 6, 2) and "z_next" not in st_off
+    # re-seeding between iterations is honoured: the prefetched walkers are dropped when torch's generator was touched
+    m = out[0][2]
+    torch.manual_seed(77); m(4096); e1 = m.E
+    torch.manual_seed(77); m(4096); e2 = m.E            # same walkers again (the warm-start step sizes differ: not the same bits)
+    m(4096); e3 = m.E                                   # the next, prefetched, batch: other walkers
+    assert abs(e1 - e2) < 1e-7 * abs(e1) and abs(e3 - e1) > 1e-4 * abs(e1)
 
 
 def test_persistent_walkers_opt_in(dev):
