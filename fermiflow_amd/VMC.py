@@ -351,8 +351,14 @@ class BetaVMC(_Sweep, torch.nn.Module):
         """Many-body state of every walker of the GLOBAL batch, sorted as the reference does (src/VMC.py:94-96), on the
         device; rank 0 draws and broadcasts so that every rank cuts its shard from the same list."""
         logits = self.log_state_weights.detach()
-        idx = torch.multinomial(torch.softmax(logits, dim=0), int(batch), replacement=True)   # = Categorical(logits).sample
-        idx, _ = torch.sort(idx)
+        # sorted(Categorical(logits).sample((batch,))) without the sort: the order statistics of `batch` uniforms are the
+        # normalised partial sums of batch + 1 exponentials, and the inverse CDF is monotone -- so pushing the (already sorted)
+        # uniforms through it gives the sorted state list directly (one scan instead of multinomial + radix/merge sort)
+        g = torch.empty(int(batch) + 1, dtype=torch.float64, device=logits.device).exponential_()
+        c = torch.cumsum(g, 0)
+        u = c[:-1] / c[-1]
+        cdf = torch.cumsum(torch.softmax(logits.double(), dim=0), 0)
+        idx = torch.bucketize(u, cdf[:-1], right=True)
         D.broadcast_(idx)
         return idx
 
