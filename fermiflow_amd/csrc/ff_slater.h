@@ -96,16 +96,11 @@ FF_D double ff_herm_rec(int n, double x, int md) {
 
 // nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop;
 // md: a wave-uniform upper bound of those degrees.
+// log|det D| of a register-resident NS x NS matrix (destroyed): LU with partial pivoting, |det| as the product of the pivots,
+// one log per determinant (NS <= 6: no over/underflow)
 template <int NS>
-FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* x, int md) {
-  double D[NS][NS];
-#pragma unroll
-  for (int i = 0; i < NS; i++) {
-    double gs = ff_gauss2d_fast(x[2 * i], x[2 * i + 1]);
-#pragma unroll
-    for (int j = 0; j < NS; j++) D[i][j] = gs * ff_herm_rec(nx[j], x[2 * i], md) * ff_herm_rec(ny[j], x[2 * i + 1], md);
-  }
-  double prod = 1.0;   // |det| as the product of the pivots: one log per determinant (NS <= 6: no over/underflow)
+FF_D double ff_lu_logabsdet_reg(double (&D)[NS][NS]) {
+  double prod = 1.0;
 #pragma unroll
   for (int c = 0; c < NS; c++) {
     int p = c;
@@ -136,6 +131,22 @@ FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* 
     }
   }
   return ff_log(prod);
+}
+
+// one row of the Slater matrix: phi_j(x, y), j = 0..NS-1
+template <int NS>
+FF_D void ff_slater_row_reg(const int* nx, const int* ny, double x, double y, int md, double* row) {
+  double gs = ff_gauss2d_fast(x, y);
+#pragma unroll
+  for (int j = 0; j < NS; j++) row[j] = gs * ff_herm_rec(nx[j], x, md) * ff_herm_rec(ny[j], y, md);
+}
+
+template <int NS>
+FF_D double ff_slater_logabsdet_reg(const int* nx, const int* ny, const double* x, int md) {
+  double D[NS][NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) ff_slater_row_reg<NS>(nx, ny, x[2 * i], x[2 * i + 1], md, D[i]);
+  return ff_lu_logabsdet_reg<NS>(D);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -258,6 +258,119 @@ ff_mcmc_spin_kernel(int64_t B, const int* __restrict__ tab_up, const int* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Metropolis chain of ONE spin species (ndown = 0: the finite-temperature runs, src/BetaFermionHO2D.py) with TWO lanes per
+// walker.  One lane per walker is one wave per SIMD at 65 536 walkers and nothing hides its serial chain; there is no second
+// species to split off here, so the lanes split the PARTICLES: lane h of a walker owns the Philox quads q = h, h + 2, ...
+// (quad q = the four normals of particles 2q, 2q + 1), proposes those particles' moves and evaluates their rows of the Slater
+// matrix; the rows change hands through one DPP swap per entry, then both lanes run the same LU on the same matrix -- the
+// same determinant bits, hence the same accept decision, as ff_mcmc_kernel.  Same noise stream, same results, bit for bit.
+template <int NS, bool NOISE>
+__global__ void __launch_bounds__(128)
+ff_mcmc_pair_kernel(int64_t B, const int* __restrict__ tab_up, const int* __restrict__ wstate, int steps, double tau,
+                    const double* __restrict__ g0, const double* __restrict__ g, const double* __restrict__ u, uint64_t seed,
+                    int64_t woff, double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept,
+                    int* __restrict__ acc_count) {
+  constexpr int M = 2 * NS, NQT = (NS + 1) / 2, NQL = (NQT + 1) / 2, NPL = 2 * NQL, MPL = 2 * NPL;   // quads total / per lane, slots
+  __shared__ int s_md;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = gid >> 1;
+  const int h = (int)(gid & 1);
+  if (threadIdx.x == 0) s_md = 0;
+  __syncthreads();
+  const bool live = b < B;
+  if (!live) b = B - 1;
+  const int st = wstate ? wstate[b] : 0;
+  int oo[2 * NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) ff_orb_decode(tab_up[st * NS + j], oo[j], oo[NS + j]);
+  int md = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * NS; j++) md = oo[j] > md ? oo[j] : md;
+  atomicMax(&s_md, md);
+  __syncthreads();
+  md = FF_UNIFORM(s_md);
+
+  // slot s of this lane: particle pid(s) = 4 (s / 2) + 2 h + (s & 1)  (quad q = 2 (s / 2) + h); it exists if pid < NS
+  double xm[MPL], nxm[MPL];
+#pragma unroll
+  for (int i = 0; i < MPL; i++) xm[i] = 0.0;
+  const uint64_t wid = (uint64_t)(woff + b);
+  auto pid = [&](int sl) -> int { return 4 * (sl >> 1) + 2 * h + (sl & 1); };
+  auto draw = [&](uint32_t step, double* dst, bool propose) {
+#pragma unroll
+    for (int k = 0; k < NQL; k++) {
+      double z4[4];
+      ff_normal_quad(seed, wid, step, (uint32_t)(2 * k + h), z4);
+#pragma unroll
+      for (int c = 0; c < 4; c++) dst[4 * k + c] = propose ? ff_add_rn(xm[4 * k + c], ff_mul_rn(tau, z4[c])) : z4[c];
+    }
+  };
+  auto load = [&](const double* src, double* dst) {     // this lane's coordinates of a (B, NS, 2) array row
+#pragma unroll
+    for (int sl = 0; sl < NPL; sl++) {
+      const int p = pid(sl) < NS ? pid(sl) : 0;
+      dst[2 * sl] = src[2 * p]; dst[2 * sl + 1] = src[2 * p + 1];
+    }
+  };
+  // log|psi|^2 of the walker whose coordinates (this lane's share) are in `xs`
+  auto logprob = [&](const double* xs) -> double {
+    double Dm[NPL][NS];
+#pragma unroll
+    for (int sl = 0; sl < NPL; sl++) ff_slater_row_reg<NS>(oo, oo + NS, xs[2 * sl], xs[2 * sl + 1], md, Dm[sl]);
+    double Dfull[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int q = i >> 1, owner = q & 1, sl = 2 * (q >> 1) + (i & 1);   // static: which lane and slot hold row i
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const double mine = Dm[sl][j], other = ff_swap1(mine);
+        Dfull[i][j] = (h == owner) ? mine : other;
+      }
+    }
+    return 2.0 * (0.0 + ff_lu_logabsdet_reg<NS>(Dfull));
+  };
+
+  if (NOISE || g0 != nullptr) load(g0 + b * M, xm);
+  else draw(0u, xm, false);
+  double logp = logprob(xm);
+  int nacc = 0;
+  double gq[MPL], uq = 0.0;
+  if (NOISE && steps > 0) { load(g + b * M, gq); uq = u[b]; }
+  for (int s = 0; s < steps; s++) {
+    double ucur = 0.0;
+    if (NOISE) {
+#pragma unroll
+      for (int i = 0; i < MPL; i++) nxm[i] = ff_add_rn(xm[i], ff_mul_rn(tau, gq[i]));
+      ucur = uq;
+      if (s + 1 < steps) { load(g + ((int64_t)(s + 1) * B + b) * M, gq); uq = u[(int64_t)(s + 1) * B + b]; }
+    } else {
+      draw((uint32_t)(s + 1), nxm, true);
+    }
+    const double nl = logprob(nxm);
+    const double dlp = nl - logp;
+    const double p = !(dlp == dlp) ? dlp : (dlp < -708.0 ? 0.0 : ff_exp(fmin(dlp, 708.0)));
+    const double uu = NOISE ? ucur : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)NS);
+    const bool acc = uu < p;
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < MPL; i++) xm[i] = nxm[i];
+      logp = nl;
+      nacc++;
+    }
+    if (accept && live && h == 0) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+  }
+  if (!live) return;
+#pragma unroll
+  for (int sl = 0; sl < NPL; sl++) {
+    if (pid(sl) < NS) { x_out[b * M + 2 * pid(sl)] = xm[2 * sl]; x_out[b * M + 2 * pid(sl) + 1] = xm[2 * sl + 1]; }
+  }
+  if (h == 0) {
+    if (logp_out) logp_out[b] = logp;
+    if (acc_count) acc_count[b] = nacc;
+  }
+}
+
 // materialise the Philox noise stream of ff_mcmc_kernel<.., false>
 __global__ void __launch_bounds__(128)
 ff_rng_fill_kernel(int64_t B, int n, int steps, uint64_t seed, int64_t woff, double* __restrict__ g0,
@@ -774,6 +887,19 @@ static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, c
       else
         FF_LAUNCH((ff_mcmc_spin_kernel<NU, false>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, g, u, seed, woff,
                   x_out, logp_out, accept, acc_count);
+      return;
+    }
+  }
+  if constexpr (ND == 0 && NU >= 2 && NU <= 6) {
+    // one spin species: two lanes per walker split the particles (ff_mcmc_pair_kernel); FF_MCMC_ONE_LANE=1 keeps one lane
+    static const bool one_lane = getenv("FF_MCMC_ONE_LANE") != nullptr;
+    if (!one_lane) {
+      if (noise)
+        FF_LAUNCH((ff_mcmc_pair_kernel<NU, true>), ff_grid(2 * B, 128), 128, stream, B, tu, ws, steps, tau, g0, g, u, seed, woff, x_out,
+                  logp_out, accept, acc_count);
+      else
+        FF_LAUNCH((ff_mcmc_pair_kernel<NU, false>), ff_grid(2 * B, 128), 128, stream, B, tu, ws, steps, tau, g0, g, u, seed, woff, x_out,
+                  logp_out, accept, acc_count);
       return;
     }
   }

@@ -93,6 +93,33 @@ def test_known_answer_eigenfunctions_full_size(dev):
 
 
 # ------------------------------------------------------------------------------------------------ MCMC
+@pytest.mark.parametrize("nup", [2, 3, 4, 5, 6])
+def test_particle_split_metropolis_kernel_vs_oracle(dev, nup):
+    """One spin species (the finite-temperature runs): ff_mcmc_pair_kernel, two lanes per walker splitting the particles.
+    Noise-fed chain == the oracle bit for bit (walkers, accept masks), also with one orbital set per walker; the Philox path
+    == the noise path on the materialised stream; 4097 walkers: the last workgroup is ragged."""
+    from fermiflow_amd import native
+    rng = np.random.default_rng(100 + nup)
+    B, steps = 4097, 25
+    g0 = rng.normal(size=(B, nup, 2)); g = rng.normal(size=(steps, B, nup, 2)); u = rng.random((steps, B))
+    tab1 = native.orbital_table(list(range(nup)), dev)
+    x, lp, acc = native.mcmc_sample_noise(tab1, None, nup, 0, T(g0, dev), T(g, dev), T(u, dev), 0.1)
+    xo, lpo, acco = O.mcmc_noise(g0, g, u, nup, 0)
+    assert (N(x) == xo).all() and (N(acc) == acco).all()
+    np.testing.assert_allclose(N(lp), lpo, rtol=1e-12, atol=1e-12)
+    sets = np.stack([np.sort(rng.choice(15, size=nup, replace=False)) for _ in range(5)]).astype(np.int32)
+    ws = np.sort(rng.integers(0, 5, size=B)).astype(np.int32)
+    tabs = native.orbital_table([list(map(int, r)) for r in sets], dev)
+    x, lp, acc = native.mcmc_sample_noise(tabs, None, nup, 0, T(g0, dev), T(g, dev), T(u, dev), 0.1,
+                                          walker_state=torch.as_tensor(ws, device=dev))
+    xo, lpo, acco = O.mcmc_noise(g0, g, u, nup, 0, tab_up=sets, wstate=ws)
+    assert (N(x) == xo).all() and (N(acc) == acco).all()
+    h0, h, hu = native.rng_fill(B, nup, steps, 4242, dev, walker_offset=7)
+    x1, _, a1 = native.mcmc_sample_noise(tab1, None, nup, 0, h0, h, hu, 0.1)
+    x2, _, cnt = native.mcmc_sample(tab1, None, nup, 0, B, steps, 0.1, 4242, dev, walker_offset=7)
+    assert torch.equal(x1, x2) and torch.equal(a1.sum(0).to(torch.int32), cnt.to(torch.int32))
+
+
 @pytest.mark.parametrize("name", ["u3d3", "u6d0", "u6d6", "u1d0", "u10d0", "u3d3_b512"])
 def test_mcmc_bit_exact_vs_reference(golden, dev, name):
     import fermiflow_amd as ff

@@ -26,7 +26,7 @@ def test_slater_kernels(golden):
     np.testing.assert_allclose(lap, G["ms_lap"], rtol=1e-9, atol=1e-8)
 
 
-@pytest.mark.parametrize("name", ["u3d3", "u6d6", "u10d0"])
+@pytest.mark.parametrize("name", ["u3d3", "u6d6", "u10d0", "u6d0", "u1d0"])
 def test_mcmc_kernel_bit_exact(golden, name):
     G = golden["g1_mcmc"]
     nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name)
@@ -44,6 +44,28 @@ def test_philox_mcmc_equals_noise_path():
     xb, _, _ = S.mcmc(25, 3, 3, 20, 1234, offset=20)
     assert (np.concatenate([xa, xb]) == x2).all()
     assert abs(g.mean()) < 0.02 and abs(g.std() - 1) < 0.02 and abs(u.mean() - 0.5) < 0.03
+
+
+@pytest.mark.parametrize("nup", [2, 3, 4, 5, 6])
+def test_particle_split_metropolis_kernel(nup):
+    """ff_mcmc_pair_kernel (one spin species, two lanes per walker): the noise-fed chain equals the oracle's bit for bit --
+    walkers, log-probabilities and accept masks, also with a different orbital set per walker -- and the Philox path equals
+    the noise path on the materialised stream (ragged batch: the last workgroup has idle lanes)."""
+    rng = np.random.default_rng(nup)
+    B, steps = 37, 12
+    g0 = rng.normal(size=(B, nup, 2)); g = rng.normal(size=(steps, B, nup, 2)); u = rng.random((steps, B))
+    x, lp, acc = S.mcmc_noise(g0, g, u, nup, 0)
+    xo, lpo, acco = O.mcmc_noise(g0, g, u, nup, 0)
+    assert (x == xo).all() and (acc == acco).all() and np.allclose(lp, lpo, rtol=1e-13, atol=1e-13)
+    tab = np.stack([np.sort(rng.choice(15, size=nup, replace=False)) for _ in range(4)]).astype(np.int32)      # four orbital sets
+    ws = np.sort(rng.integers(0, 4, size=B)).astype(np.int32)
+    x, lp, acc = S.mcmc_noise(g0, g, u, nup, 0, tab_up=tab, wstate=ws)
+    xo, lpo, acco = O.mcmc_noise(g0, g, u, nup, 0, tab_up=tab, wstate=ws)
+    assert (x == xo).all() and (acc == acco).all() and np.allclose(lp, lpo, rtol=1e-13, atol=1e-13)
+    h0, h, hu = S.rng_fill(B, nup, steps, 99, offset=3)
+    x1, _, acc1 = S.mcmc_noise(h0, h, hu, nup, 0)
+    x2, _, cnt = S.mcmc(B, nup, 0, steps, 99, offset=3)
+    assert (x1 == x2).all() and (acc1.sum(0) == cnt).all()
 
 
 def test_backflow_kernel(golden):
