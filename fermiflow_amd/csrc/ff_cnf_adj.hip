@@ -484,9 +484,13 @@ FF_D void ff_row_add(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict_
 #pragma unroll
     for (int k = 0; k < FF_DEP_ROW; k++) atomicAdd(row + k, c[k]);
   } else {
+    // (hipcc otherwise sinks the two atomic loops into one over a select of an LDS and a global pointer -- a flat pointer
+    // whose aperture test it then fails to encode: "Illegal instruction detected" in the one-walker-per-wave kernels)
     double* row = ovf + ((size_t)t * FF_DEP_NTOT + j) * FF_DEP_ROW;
 #pragma unroll
     for (int k = 0; k < FF_DEP_ROW; k++) atomicAdd(row + k, c[k]);
+    int jo = j;
+    FF_OPAQUE(jo);   // an empty asm as this branch's LAST instruction: the two atomic loops stay two
   }
 }
 
@@ -881,6 +885,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   }
 }
 
+extern bool ff_wide_forced();                  // ff_wide.hip
+extern int ff_wide_supported(int n, int d);
+#include "ff_adj_wide.h"   // one walker per wave, run-time particle number (n > 12 in d = 2, n > 4 in d = 3)
+
 // Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
 #ifdef FF_HOSTSIM          // (host simulator: four threads per workgroup, as FF_RBLOCK)
 #define FF_DEPR_EX 2
@@ -1020,9 +1028,18 @@ static size_t adj_table_doubles(int64_t B, int Gtab) {   // one private table pe
 // workspace = [direct rows | private tables + Wtot | off-table flag]
 static size_t adj_direct_doubles(int64_t B, int G, int He, int Hm) { return (size_t)adj_grid(B, G) * G * (size_t)(3 * He + 3 * Hm); }
 
+// the narrow kernels are instantiated for n = 1..12 in d = 2 and n = 2..4 in d = 3; everything else (and everything under
+// FF_WIDE=1) goes to the one-walker-per-wave kernels of ff_adj_wide.h
+static bool adj_is_wide(int n, int d) {
+  const bool narrow = (d == 2 && n >= 1 && n <= 12) || (d == 3 && n >= 2 && n <= 4);
+  return ff_wide_supported(n, d) && (!narrow || ff_wide_forced());
+}
+
 size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
+  if (B <= 0) return 0;
+  if (adj_is_wide(n, d)) return sizeof(double) * (adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1);
   int G = adj_G(n, d);
-  if (G == 0 || B <= 0) return 0;
+  if (G == 0) return 0;
   return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d)) + 1);
 }
 
@@ -1065,14 +1082,24 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_index = w_index; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
+  const bool wide = adj_is_wide(n, d);
   {
-    const int Gq = adj_G(n, d);
+    const int Gq = wide ? 1 : adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
-    a.off_table = a.trows + adj_table_doubles(B, adj_tab_G(n, d));
+    a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d));
   }
   if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
+  if (wide) {
+    // radius slots per lane: pairs + one-body radii over 64 lanes
+    const int nq = (n * (n + 1) / 2 + FF_WAVE - 1) / FF_WAVE;
+    const unsigned grid = adj_grid(a.B, 1);
+#define FF_WA(D_, Q_) if (d == D_ && nq <= Q_ && G == 0) { if (net->radial_table) FF_LAUNCH((ff_wide_adjtab_kernel<D_, Q_>), grid, FF_WAVE, stream, a, n); \
+                                                            FF_LAUNCH((ff_wide_adj_kernel<D_, Q_>), grid, FF_WAVE, stream, a, n); G = 1; }
+    FF_WA(2, 2) FF_WA(2, 4) FF_WA(2, 5) FF_WA(3, 2) FF_WA(3, 4) FF_WA(3, 5)
+#undef FF_WA
+  } else
   // both variants are enqueued; on the device exactly one of them runs, chosen by the radial-table header
   // (no table / weights too stiff for the deposit grid -> direct evaluation), so the host never has to look at it
 #define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_adjtab_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
@@ -1080,7 +1107,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2) else FF_ND(2, 3) else FF_ND(3, 3) else FF_ND(4, 3)
 #undef FF_ND
   if (G == 0) {
-    ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2 and n = 2..4 in d = 3");
+    ff_set_error("fused CNF kernels serve n <= 24 particles with n*d <= 60 in d = 2, 3");
     return FF_EUNSUPPORTED;
   }
   FF_LAUNCH_CHECK();
@@ -1088,7 +1115,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk * G, P, (const double*)a.rows, grad_params);
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
-    const int ntab = (int)adj_grid(B, adj_tab_G(n, d));     // workgroups (= private tables) of the tabulated kernel
+    const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d));     // workgroups (= private tables) of the tabulated kernel
     double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_EX - 1) / FF_DEPR_EX), FF_DEPR_EX * FF_DEPR_TY, stream, *net,
               (const double*)a.off_table, ntab, (const double*)a.trows, wtot);

@@ -41,39 +41,7 @@
 #define FF_TAB_MODE(MODE) true
 #endif
 
-struct ff_fwd_args {
-  int64_t B;
-  ff_net net;
-  double ta, tb, rtol, atol;
-  int max_steps;
-  const double* y_in;   // (B, M)
-  double* y_out;        // (B, M)   z(tb)
-  double* dl_out;       // (B)      Delta(tb)                  MODE >= 1
-  double* Jt;           // (B, M, M) Jt[b][i][k] = dz_k/dx_i   MODE 2
-  double* kbar;         // (B, M)
-  double* dD;           // (B, M)   d Delta / d x_i
-  double* Lpart;        // (B, M)   per-direction parts of lap_x Delta
-  int32_t* stats;
-  const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
-  double h_scale;          // negative: h_init holds ONE entry used by every walker (ff_ode.walker_h_uniform), scale = -h_scale
-  double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
-  int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
-  const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place
-  // Off-table protocol (TAB kernels): a kernel that meets a radius beyond the table, or an unusable table, stores
-  // evt_id into *evt (a slot of the table header); the direct-evaluation kernel launched right behind it with the
-  // same id returns at once unless it finds its id there.  ids are unique per process, so slots need no reset.
-  double* evt;
-  double evt_id;
-  // local-energy pass, optional (B): a cost class per walker (ff_ode.walker_class).  Walkers with class <= sens_class weigh
-  // the sensitivity components (J, kbar, the Delta derivatives) with sens_w = 1 / ff_ode.sens_tol in the error norm and
-  // open with h_init * h_scale_loose
-  const int32_t* wclass;
-  int sens_class;
-  double sens_w, h_scale_loose;
-  // Work queue (optional): with `queue` set the launch is a persistent grid and every workgroup takes its next walker
-  // group from this counter (slot 0: table kernel, slot 1: direct kernel), zeroed by the host before the launch.
-  unsigned long long* queue;
-};
+#include "ff_fwd_args.h"
 
 #ifndef FF_FORM_EARLY
 #define FF_FORM_EARLY 1   // MODE 2: form the stage input between the two halves of the radius phase
@@ -1357,6 +1325,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   // FF_ELOC_KERNEL = auto (default) | mfma | rows | columns forces one where it is instantiated.  auto takes the fastest
   // measured on MI355X (tools/probes/eloc_ab.py): the column sweep up to 8 particles, the row layout from 9 on (and for
   // every particle number the column sweep is not instantiated for).
+  if (ff_wide_forced() && ff_wide_supported(n, d)) return ff_wide_dispatch_fwd(MODE, stream, n, d, a);   // FF_WIDE=1: A/B and parity testing
   static const int eloc_kind = [] {
     const char* e = getenv("FF_ELOC_KERNEL");
     return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : 0)));
@@ -1383,8 +1352,8 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
   if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) FF_ND(2, 3) FF_ND(3, 3) FF_ND(4, 3) }   // (their local-energy pass is the row-layout kernel above)
 #undef FF_ND
-  ff_set_error("fused CNF kernels are instantiated for n = 1..12 particles in d = 2 and n = 2..4 in d = 3");
-  return FF_EUNSUPPORTED;
+  // everything else: one walker per workgroup (ff_wide.hip: n <= 24, n d <= 60)
+  return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
 }
 
 static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode* ode) {

@@ -135,6 +135,12 @@ FF_D double ff_mfma4(double a, double b, double c) {
 #endif
 }
 
+// v_mfma_f64_16x16x4_f64: D (16x16) = A (16x4) B (4x16) + C per wave.  Lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16];
+// register v of lane l holds C/D[4 v + l / 16][l % 16] (measured on gfx950: tools/probes/mfma_f64.hip, wide_probe.hip).
+// 64 cycles per instruction = 16 FMA per cycle and SIMD: the fp64 peak of the vector pipe, in one issue slot.
+typedef double ff_d4 __attribute__((vector_size(32)));
+FF_D ff_d4 ff_mfma16(double a, double b, ff_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
 // --- exp for |x| <= 708.  Rounding and scaling use the integer pipe instead of the quarter-rate
 //     v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64: adding 1.5*2^52 leaves round(x*log2e) in the low mantissa word, and
 //     2^k is applied by adding k to the exponent field (the polynomial value is in [0.7,1.42], |k| <= 1010: always normal).

@@ -1,0 +1,620 @@
+// ff_wide.hip -- the forward CNF integrations for walkers that do not fit one wave's layouts: ONE WALKER PER WORKGROUP.
+//
+//   CNF.generate / CNF.delta_logp (src/flow.py:42-55)           ff_wide_flow_kernel<D, MODE, TAB>    64 lanes per walker
+//   local-energy sensitivities (src/VMC.py:46-49 through
+//   src/utils.py:40-65, by forward sensitivities as ff_eloc)     ff_wide_eloc_kernel<D, T, TAB>       64 T lanes per walker
+//
+// Particle numbers are run-time values here (n <= 24, M = n d <= 60): BASELINE.json configs[4] (nup = ndown = 10 in a 3-D
+// trap, M = 60) and every 2-D system beyond 12 particles (the reference is shape-generic: src/equivariant_funs.py:17-102).
+//
+// The local-energy kernel integrates the system of ff_eloc_rows.h,
+//     z' = v(z)      J' = A J  (A = dv/dz, J = dz/dx)      kbar' = A kbar + sum_i D2v[u_i, u_i]
+//     Delta' = -div v      (grad Delta)' = -J^T g  (g = grad_z div v)      (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar)
+// with the quadratic sources taken from S = J J^T (O(1) work per radius), so that per right-hand side two dense
+// MP x MP x MP products remain -- J' = A J and S = J J^T -- and both run on the matrix cores (v_mfma_f64_16x16x4_f64):
+//   * MP = 16 T >= M + 4 is the padded size, the workgroup has T waves, wave w owns COLUMN block w of J: lane (g, c)
+//     (g = lane / 16, c = lane % 16) keeps J[16 K + 4 v + g][16 w + c] for the row tiles K = 0..T-1 and v = 0..3 -- the
+//     instruction's own C/D layout, so J' = A J lands where the Runge-Kutta arithmetic wants it, and the stage input is the
+//     B operand as it stands (k-slot g of step (K, v) is row 16 K + 4 v + g);
+//   * row M of J is grad_x Delta: row M of A holds -g, so (A J)[M][i] = -sum_p g_p J[p][i] comes out of the same product;
+//   * A (assembled from the D x D pair blocks B = eta I + (eta'/r) rho rho^T that the radius lanes leave in per-radius
+//     records) and the stage J are read as MFMA operands from LDS (row stride MP + 2 doubles: conflict-free for the
+//     (row = lane % 16, column = k0 + lane / 16) operand pattern); S is written over A once every wave is done with A.
+// Per right-hand side: publish -> R1 (one radius per lane: heads, record) -> own-row sums, A assembly -> S = J J^T and
+// J' = A J -> S to LDS -> R2 (radius lanes contract their terms with S) -> second-order sums -> Dormand-Prince bookkeeping
+// (ff_dp5.h).  fp64 matrix and vector instructions have the same peak on this part (and do not overlap,
+// tools/probes/mfma_f64.hip), so the matrix cores buy instruction slots and operand traffic, not flops: the kernel is
+// bound by 2 * T * ceil(M/4) matrix instructions of 64 cycles per wave and evaluation.
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include "ff_common.h"
+#include "ff_ode.h"
+#include "ff_dp5.h"
+#include "ff_radial.h"
+#include "ff_fwd_args.h"
+
+#define FF_WIDE_NMAX 24
+#define FF_WIDE_MMAX 60
+#define FF_WIDE_RMAX (FF_WIDE_NMAX * (FF_WIDE_NMAX + 1) / 2)   // pairs + one-body radii
+
+// radius q of a walker with n particles (pairs a < b in a-major order, then the one-body radii) -> a | b << 5 | q << 10
+// (b = 31: one-body); -1 beyond nrad
+FF_D int ff_wide_radius_id(int n, int q, int nrad) {
+  if (q >= nrad) return -1;
+  const int P = n * (n - 1) / 2;
+  if (q >= P) return (q - P) | (31 << 5) | (q << 10);
+  int a = 0, off = 0;
+  while (q >= off + (n - 1 - a)) { off += n - 1 - a; a++; }
+  return a | ((a + 1 + q - off) << 5) | (q << 10);
+}
+
+// index of the radius between particle a and partner j (j = a: the one-body radius)
+FF_D int ff_wide_partner(int n, int P, int a, int j) {
+  const int lo = j < a ? j : a, hi = j < a ? a : j;
+  return (j == a) ? P + a : ff_pair_index(n, lo, hi);
+}
+
+// sum of a per-lane partial over a workgroup of NTHR lanes, identical on every lane: 16 column sums, then their sum
+template <int NTHR>
+FF_D double ff_wide_sum(double* s_red, double* s_red2, int tid, double part) {
+  s_red[tid] = part;
+  __syncthreads();
+  if (tid < 16) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NTHR / 16; k++) t += s_red[tid + 16 * k];
+    s_red2[tid] = t;
+  }
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) t += s_red2[k];
+  __syncthreads();
+  return t;
+}
+
+// =====================================================================================================================
+// CNF.generate (MODE 0) / CNF.delta_logp (MODE 1): one wave per walker; lane l owns coordinates l and l + 64 and the
+// radii l, l + 64, ... (for MODE 1 also the share of Delta that its radii contribute: a plain quadrature).
+template <int D, int MODE, bool TAB>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_wide_flow_kernel(ff_fwd_args A, int n) {
+  constexpr int NH = MODE == 0 ? 1 : 2;
+  constexpr int NP = 1;                                  // coordinate slots per lane (M <= 64)
+  constexpr int NQ = (FF_WIDE_RMAX + FF_WAVE - 1) / FF_WAVE;
+  constexpr int NV = NP + (MODE == 1 ? 1 : 0);
+  __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
+  __shared__ double s_e2[TAB ? 1 : 64];
+  __shared__ double s_z[FF_WAVE], s_f0[FF_WIDE_RMAX], s_red[FF_WAVE], s_red2[16];
+  __shared__ int s_st[4];
+
+  const int lane = threadIdx.x;
+  const int M = n * D, P = n * (n - 1) / 2;
+  const double* __restrict__ rtab = A.net.radial_table;
+  if constexpr (TAB) {
+    if (rtab[3] != 0.0) {   // table unusable for these weights: leave the call to the direct kernel
+      if (lane == 0 && blockIdx.x == 0) *A.evt = A.evt_id;
+      return;
+    }
+  } else {
+    if (A.evt && *A.evt != A.evt_id) return;   // fallback launch that is not needed
+    ff_fill_exp2_table(s_e2, lane);
+    ff_load_weights(s_w, A.net, lane);
+  }
+  bool off_table = false;
+  if (lane < 4) s_st[lane] = 0;
+  __syncthreads();
+  const int He = A.net.He, Hm = A.net.Hm;
+  const bool has_mu = Hm > 0;
+  const int nrad = has_mu ? P + n : P;
+  const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
+  int rq_id[NQ];
+#pragma unroll
+  for (int qk = 0; qk < NQ; qk++) rq_id[qk] = ff_wide_radius_id(n, lane + qk * FF_WAVE, nrad);
+  const bool own = lane < M;
+  const int ai = own ? lane / D : 0, ci = own ? lane % D : 0;
+
+  for (int64_t bq = blockIdx.x; bq < A.B; bq += gridDim.x) {
+    const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);
+    double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
+    if (own) y[0] = A.y_in[b * M + lane];
+    ff_stepper S;
+    S.begin(A.ta, A.tb, true);
+    ff_dp5_ctl C;
+    C.rtol = A.rtol; C.atol = A.atol; C.nt_inv = 1.0 / (double)(M + (MODE == 1 ? 1 : 0)); C.max_steps = A.max_steps;
+    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
+    C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
+    const double hwarm0 = C.hwarm;
+    double rmin = 1e300;
+    int s = -2, nev = 0;
+    auto wgt = [&](int v) -> double { return 1.0; };
+    auto gsum = [&](double part) -> double { return ff_wide_sum<FF_WAVE>(s_red, s_red2, lane, part); };
+
+#pragma unroll 1
+    for (;;) {
+      double gy, g0, g1, g2;
+      ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
+      __syncthreads();
+      if (own) s_z[lane] = fma(g2, c2[0], fma(g1, c1[0], fma(g0, c0[0], gy * y[0])));
+      __syncthreads();
+      // ---------------------------------------------------------------- radius phase
+      double dsum = 0.0;
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int a = id & 31, bb0 = (id >> 5) & 31, pr = id >> 10;
+        const bool pair = bb0 != 31;
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          const double rho = s_z[a * D + c] - (pair ? s_z[bb0 * D + c] : 0.0);
+          r2 = fma(rho, rho, r2);
+        }
+        double r, ri, hd[NH];
+        ff_sqrt_rcp(r2, r, ri);
+        rmin = fmin(rmin, r);
+        if constexpr (TAB) {
+          if (!ff_heads_table<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd)) {
+            off_table = true;
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, r, hd);
+        }
+        s_f0[pr] = hd[0];
+        if constexpr (MODE == 1) dsum = fma(pair ? 2.0 : 1.0, fma(hd[NH - 1], r, D * hd[0]), dsum);
+      }
+      __syncthreads();
+      nev++;
+      // ---------------------------------------------------------------- component phase
+      double out[NV];
+      {
+        double vi = 0.0;
+        if (own) {
+          const double zc = s_z[lane];
+          for (int j = 0; j < n; j++) {
+            if (j == ai) continue;
+            vi = fma(s_f0[ff_wide_partner(n, P, ai, j)], zc - s_z[j * D + ci], vi);
+          }
+          if (has_mu) vi = fma(s_f0[P + ai], zc, vi);
+        }
+        out[0] = vi;
+        if constexpr (MODE == 1) out[1] = -dsum;
+      }
+      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
+      if (s == 99) break;
+    }
+    // -------------------------------------------------------------------- results
+    const bool failed = S.fail != 0;
+    const double bad = failed ? __builtin_nan("") : 0.0;
+    if (own) A.y_out[b * M + lane] = y[0] + bad;
+    double delta = 0.0;
+    if constexpr (MODE == 1) delta = gsum(y[NV - 1]);
+    if (A.wcost) {
+      s_red[lane] = rmin;
+      __syncthreads();
+    }
+    if (lane == 0) {
+      if constexpr (MODE == 1) A.dl_out[b] = delta + bad;
+      if (A.h_out) A.h_out[b] = C.hmax_acc > 0.0 ? C.hmax_acc : hwarm0;
+      if (A.wcost) {
+        double m = 1e300;
+        for (int k = 0; k < FF_WAVE; k++) m = fmin(m, s_red[k]);
+        A.wcost[b] = ff_cost_class(S.nacc + S.nrej, m);
+      }
+      if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
+    }
+    __syncthreads();
+  }
+  if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
+  __syncthreads();
+  if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
+  }
+}
+
+// =====================================================================================================================
+// Local-energy sensitivities: one walker per workgroup of T waves, both dense products on the matrix cores (file header).
+// Lane state (NV = 4 T + 4 doubles): [0, 4T) its elements of J (rows 0..M-1: dz/dx; row M: grad_x Delta), [4T] z_p and
+// [4T+1] kbar_p for the owner lanes tid = p < M, [4T+2] / [4T+3] the shares of Delta / lap_x Delta that the lane's own
+// radii contribute (plain quadratures, summed at the end).
+template <int D, int T, bool TAB>
+__global__ void __launch_bounds__(FF_WAVE * T)
+ff_wide_eloc_kernel(ff_fwd_args A, int n) {
+  constexpr int MP = 16 * T, NTHR = FF_WAVE * T, JS = MP + 2;
+  constexpr int NVJ = 4 * T, NV = NVJ + 4, IZ = NVJ, IK = NVJ + 1, IDL = NVJ + 2, ILP = NVJ + 3;
+  constexpr int NH = 4;
+  constexpr int NCAP = (MP - 4) / D > FF_WIDE_NMAX ? FF_WIDE_NMAX : (MP - 4) / D;   // particles this instantiation can hold
+  constexpr int RCAP = NCAP * (NCAP + 1) / 2;
+  constexpr int NQ = (RCAP + NTHR - 1) / NTHR;
+  // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
+  //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
+  // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
+  constexpr int RW = 2 * D + 8;
+  constexpr int QF0 = D, QF1 = D + 1, QGQ = D + 2, QPW = D + 3, QRI2 = 2 * D + 4, QF2 = 2 * D + 5, QBC = 2 * D + 6;
+
+  __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
+  __shared__ double s_e2[TAB ? 1 : 64];
+  __shared__ __attribute__((aligned(16))) double s_J[MP * JS];   // stage J, [p][i]
+  __shared__ __attribute__((aligned(16))) double s_A[MP * JS];   // A = dv/dz with row M = -grad div; then S = J J^T
+  __shared__ __attribute__((aligned(16))) double s_rec[RCAP * RW];
+  __shared__ double s_z[MP], s_kb[MP], s_red[NTHR], s_red2[16];
+  __shared__ int s_st[4];
+  __shared__ long long s_next;
+
+  const int tid = threadIdx.x, w = tid / FF_WAVE, l = tid % FF_WAVE, lg = l / 16, lc = l % 16;
+  const int M = n * D, P = n * (n - 1) / 2;
+  const double* __restrict__ rtab = A.net.radial_table;
+  if constexpr (TAB) {
+    if (rtab[3] != 0.0) {
+      if (tid == 0 && blockIdx.x == 0) *A.evt = A.evt_id;
+      return;
+    }
+  } else {
+    if (A.evt && *A.evt != A.evt_id) return;
+    if (tid < FF_WAVE) { ff_fill_exp2_table(s_e2, tid); ff_load_weights(s_w, A.net, tid); }
+  }
+  bool off_table = false;
+  if (tid < 4) s_st[tid] = 0;
+  for (int e = tid; e < MP * JS; e += NTHR) { s_J[e] = 0.0; s_A[e] = 0.0; }
+  for (int e = tid; e < RCAP * RW; e += NTHR) s_rec[e] = 0.0;
+  if (tid < MP) { s_z[tid] = 0.0; s_kb[tid] = 0.0; }
+  __syncthreads();
+  const int He = A.net.He, Hm = A.net.Hm;
+  const bool has_mu = Hm > 0;
+  const int nrad = has_mu ? P + n : P;
+  const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
+  int rq_id[NQ];
+#pragma unroll
+  for (int qk = 0; qk < NQ; qk++) rq_id[qk] = ff_wide_radius_id(n, tid + qk * NTHR, nrad);
+  const bool own = tid < M;
+  const int ai = own ? tid / D : 0, ci = own ? tid % D : 0;
+  // A assembly: row p = tid / 4 (p <= M - 1), partners b = tid % 4, + 4, ...
+  const int asm_p = tid >> 2, asm_s = tid & 3;
+  const bool asm_on = asm_p < M;
+  const int asm_a = asm_on ? asm_p / D : 0, asm_c = asm_on ? asm_p % D : 0;
+  const int ksteps = (M + 3) / 4;            // k-steps of both products: columns / rows beyond M are zero
+
+  for (int64_t bq = blockIdx.x;; bq += gridDim.x) {
+    if (A.queue) {   // persistent grid: next walker from the launch's work counter (heavy walkers sit at the front)
+      __syncthreads();
+      if (tid == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
+      __syncthreads();
+      bq = s_next;
+    }
+    if (bq >= A.B) break;
+    const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);
+    double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
+    if (own) y[IZ] = A.y_in[b * M + tid];
+#pragma unroll
+    for (int K = 0; K < T; K++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int p = 16 * K + 4 * v + lg, i = 16 * w + lc;
+        y[4 * K + v] = (p == i && p < M) ? 1.0 : 0.0;
+      }
+    ff_stepper S;
+    S.begin(A.ta, A.tb, true);
+    const bool loose = ff_opt_load(A.wclass, true, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+    ff_dp5_ctl C;
+    C.rtol = A.rtol; C.atol = A.atol; C.nt_inv = 1.0 / ((double)M * (M + 4) + 1.0); C.max_steps = A.max_steps;
+    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
+    if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
+    C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
+    const double hwarm0 = C.hwarm;
+    const double sens_w = loose ? A.sens_w : 1.0;
+    int s = -2, nev = 0;
+    auto wgt = [&](int v) -> double { return v == IZ ? 1.0 : sens_w; };
+    auto gsum = [&](double part) -> double { return ff_wide_sum<NTHR>(s_red, s_red2, tid, part); };
+
+#pragma unroll 1
+    for (;;) {
+      double gy, g0, g1, g2;
+      ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
+      auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
+      // ---------------------------------------------------------------- publish z, kbar, J (the stage J stays in registers:
+      // it is the B operand of J' = A J)
+      double Jin[NVJ];
+#pragma unroll
+      for (int v = 0; v < NVJ; v++) Jin[v] = form(v);
+      const double kb_in = form(IK);
+      __syncthreads();
+      if (own) { s_z[tid] = form(IZ); s_kb[tid] = kb_in; }
+#pragma unroll
+      for (int K = 0; K < T; K++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = Jin[4 * K + v];
+      __syncthreads();
+      // ---------------------------------------------------------------- R1: radius lanes
+      double dsum = 0.0;
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int a = id & 31, bb0 = (id >> 5) & 31, pr = id >> 10;
+        const bool pair = bb0 != 31;
+        double rho[D], dk[D], r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          rho[c] = s_z[a * D + c] - (pair ? s_z[bb0 * D + c] : 0.0);
+          dk[c] = s_kb[a * D + c] - (pair ? s_kb[bb0 * D + c] : 0.0);
+          r2 = fma(rho[c], rho[c], r2);
+        }
+        double r, ri, hd[NH];
+        ff_sqrt_rcp(r2, r, ri);
+        if constexpr (TAB) {
+          if (!ff_heads_table<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd)) {
+            off_table = true;
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, r, hd);
+        }
+        const double cf = pair ? 2.0 : 1.0;
+        const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
+        const double Ac = cf * fma(f2, r, (1.0 + D) * f1), Bc = cf * fma(f3, r, (2.0 + D) * f2);
+        double rdk = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) rdk = fma(rho[c], dk[c], rdk);
+        const double f1ri = f1 * ri, F1k = f1ri * rdk;
+        double* rec = &s_rec[pr * RW];
+#pragma unroll
+        for (int c = 0; c < D; c++) { rec[c] = rho[c]; rec[QPW + c] = fma(F1k, rho[c], f0 * dk[c]); }
+        rec[QF0] = f0; rec[QF1] = f1ri; rec[QGQ] = Ac * ri;
+        rec[QRI2] = ri * ri; rec[QF2] = f2; rec[QBC] = Bc;
+        dsum = fma(cf, fma(f1, r, D * f0), dsum);           // this radius' share of div v
+      }
+      __syncthreads();
+      nev++;
+      // ---------------------------------------------------------------- own-row sums (owner lanes) and the assembly of A
+      double vi = 0.0, wk = 0.0, gdi = 0.0;
+      if (own) {
+        double Ad[D];
+#pragma unroll
+        for (int c = 0; c < D; c++) Ad[c] = 0.0;
+        for (int j = 0; j < n; j++) {
+          if (j == ai && !has_mu) continue;
+          const double* rec = &s_rec[ff_wide_partner(n, P, ai, j) * RW];
+          const double sg = j < ai ? -1.0 : 1.0;
+          const double f0 = rec[QF0], fc = rec[QF1] * rec[ci];
+          vi = fma(sg * f0, rec[ci], vi);
+          wk = fma(sg, rec[QPW + ci], wk);
+          gdi = fma(sg * rec[QGQ], rec[ci], gdi);
+#pragma unroll
+          for (int c = 0; c < D; c++) Ad[c] += fma(fc, rec[c], ci == c ? f0 : 0.0);
+        }
+#pragma unroll
+        for (int c = 0; c < D; c++) s_A[tid * JS + ai * D + c] = Ad[c];        // row ci of the diagonal block of particle ai
+        s_A[M * JS + tid] = -gdi;                                               // row M: (grad Delta)' = -g^T J
+      }
+      if (asm_on) {
+        for (int bp = asm_s; bp < n; bp += 4) {
+          if (bp == asm_a) continue;
+          const double* rec = &s_rec[ff_wide_partner(n, P, asm_a, bp) * RW];
+          const double f0 = rec[QF0], fc = rec[QF1] * rec[asm_c];
+#pragma unroll
+          for (int c = 0; c < D; c++) s_A[asm_p * JS + bp * D + c] = -fma(fc, rec[c], asm_c == c ? f0 : 0.0);
+        }
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- the two products on the matrix cores
+      ff_d4 accS[T], accJ[T];
+#pragma unroll
+      for (int I = 0; I < T; I++) {
+        const ff_d4 zero = {0.0, 0.0, 0.0, 0.0};
+        accS[I] = zero; accJ[I] = zero;
+      }
+      // S tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k]
+      {
+        const double* Jb = &s_J[(16 * w + lc) * JS + lg];
+        const double* Ja = &s_J[lc * JS + lg];
+#pragma unroll 2
+        for (int ks = 0; ks < ksteps; ks++) {
+          const double bv = Jb[4 * ks];
+          double av[T];
+#pragma unroll
+          for (int I = 0; I < T; I++) av[I] = Ja[16 * I * JS + 4 * ks];
+#pragma unroll
+          for (int I = 0; I < T; I++) accS[I] = ff_mfma16(av[I], bv, accS[I]);
+        }
+      }
+      // J' tiles (I, w) = sum_k A[16 I + i][k] J[k][16 w + j]: the B operand of k-step (K, v) is the lane's own Jin[4 K + v]
+      {
+        const double* Aa = &s_A[lc * JS + lg];
+#pragma unroll
+        for (int K = 0; K < T; K++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            if (4 * (4 * K + v) < M) {     // workgroup-uniform
+              const double bv = Jin[4 * K + v];
+              double av[T];
+#pragma unroll
+              for (int I = 0; I < T; I++) av[I] = Aa[16 * I * JS + 16 * K + 4 * v];
+#pragma unroll
+              for (int I = 0; I < T; I++) accJ[I] = ff_mfma16(av[I], bv, accJ[I]);
+            }
+          }
+      }
+      __syncthreads();      // every wave is done reading A ...
+#pragma unroll
+      for (int I = 0; I < T; I++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {   // ... which now holds S (only the M x M part: the padding of A must stay zero)
+          if (16 * I + 4 * v + lg < M && 16 * w + lc < M) s_A[(16 * I + 4 * v + lg) * JS + 16 * w + lc] = accS[I][v];
+        }
+      __syncthreads();
+      // ---------------------------------------------------------------- R2: radius lanes contract their terms with S
+      double qsum = 0.0;
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int a = id & 31, bb0 = (id >> 5) & 31, pr = id >> 10;
+        const bool pair = bb0 != 31;
+        const int bb = pair ? bb0 : a;
+        double* rec = &s_rec[pr * RW];
+        double rho[D];
+#pragma unroll
+        for (int c = 0; c < D; c++) rho[c] = rec[c];
+        const double f1ri = rec[QF1], gq = rec[QGQ], ri2 = rec[QRI2], f2 = rec[QF2], Bc = rec[QBC];
+        double w1[D], qq = 0.0, tr = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          double t = 0.0;
+#pragma unroll
+          for (int c2i = 0; c2i < D; c2i++) {
+            double ww = s_A[(a * D + c) * JS + a * D + c2i];
+            if (pair) ww += s_A[(bb * D + c) * JS + bb * D + c2i] - s_A[(a * D + c) * JS + bb * D + c2i] - s_A[(a * D + c2i) * JS + bb * D + c];
+            t = fma(ww, rho[c2i], t);
+            if (c2i == c) tr += ww;
+          }
+          w1[c] = t;
+          qq = fma(rho[c], t, qq);
+        }
+        qq *= ri2;
+        const double tq = tr - qq;
+        const double F2 = fma(f2, qq, f1ri * tq), F1x2 = 2.0 * f1ri;
+#pragma unroll
+        for (int c = 0; c < D; c++) rec[QPW + c] = fma(F2, rho[c], F1x2 * w1[c]);
+        qsum += fma(Bc, qq, gq * tq);
+      }
+      __syncthreads();
+      // ---------------------------------------------------------------- second-order sums, right-hand side
+      double out[NV];
+      double qs = 0.0;
+      if (own) {
+        for (int j = 0; j < n; j++) {
+          if (j == ai && !has_mu) continue;
+          qs = fma(j < ai ? -1.0 : 1.0, s_rec[ff_wide_partner(n, P, ai, j) * RW + QPW + ci], qs);
+        }
+      }
+#pragma unroll
+      for (int I = 0; I < T; I++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) out[4 * I + v] = accJ[I][v];
+      out[IZ] = vi;
+      out[IK] = wk + qs;
+      out[IDL] = -dsum;
+      out[ILP] = -(qsum + gdi * kb_in);
+      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
+      if (s == 99) break;
+    }
+    // -------------------------------------------------------------------- results
+    const bool failed = S.fail != 0;
+    const double bad = failed ? __builtin_nan("") : 0.0;
+    const double delta = gsum(y[IDL]);
+    const double lapd = gsum(y[ILP]);
+    __syncthreads();
+#pragma unroll
+    for (int K = 0; K < T; K++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = y[4 * K + v];
+    __syncthreads();
+    // Jt[b][i][p] = dz_p/dx_i: wave w writes the rows i = w, w + T, ... as contiguous spans
+    for (int i = w; i < M; i += T) {
+      if (l < M) A.Jt[(b * M + i) * M + l] = s_J[l * JS + i];
+    }
+    if (own) {
+      A.y_out[b * M + tid] = y[IZ] + bad;
+      A.kbar[b * M + tid] = y[IK];
+      A.dD[b * M + tid] = s_J[M * JS + tid];
+      A.Lpart[b * M + tid] = tid == 0 ? lapd : 0.0;
+    }
+    if (tid == 0) {
+      A.dl_out[b] = delta + bad;
+      if (A.h_out) A.h_out[b] = C.hmax_acc > 0.0 ? C.hmax_acc : hwarm0;
+      if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
+      if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
+    }
+    __syncthreads();
+  }
+  if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
+  __syncthreads();
+  if (A.stats && tid == 0 && (s_st[0] || s_st[3])) {
+    atomicAdd(&A.stats[0], s_st[0]);
+    atomicMax(&A.stats[1], s_st[1]);
+    atomicAdd(&A.stats[2], s_st[2]);
+    if (s_st[3]) atomicMax(&A.stats[3], 1);
+  }
+}
+
+// =====================================================================================================================
+extern void ff_set_error(const char* msg);
+#define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
+
+static std::atomic<int> g_family{-1};   // -1: not decided yet (FF_WIDE in the environment), 0: by particle number, 1: wide for all
+bool ff_wide_forced() {
+  int f = g_family.load();
+  if (f < 0) {
+    const char* e = getenv("FF_WIDE");
+    f = (e && e[0] == '1') ? 1 : 0;
+    g_family.store(f);
+  }
+  return f == 1;
+}
+extern "C" int ff_set_kernel_family(int family) {
+  const int prev = ff_wide_forced() ? 1 : 0;
+  g_family.store(family == 1 ? 1 : 0);
+  return prev;
+}
+
+int ff_wide_supported(int n, int d) {
+  return (d == 2 || d == 3) && n >= 1 && n <= FF_WIDE_NMAX && n * d <= FF_WIDE_MMAX;
+}
+
+static int64_t wide_cus() {
+  static int64_t n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = cus;
+  }
+  return n;
+}
+
+template <int D, int MODE>
+static void launch_wide_flow(void* stream, const ff_fwd_args& a, int n) {
+  const unsigned grid = (unsigned)(a.B < 64 * wide_cus() ? a.B : 64 * wide_cus());
+  if (a.evt) FF_LAUNCH((ff_wide_flow_kernel<D, MODE, true>), grid, FF_WAVE, stream, a, n);
+  FF_LAUNCH((ff_wide_flow_kernel<D, MODE, false>), grid, FF_WAVE, stream, a, n);
+}
+
+template <int D, int T>
+static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
+  // persistent grid when the launch has a work queue: as many workgroups as stay resident (one per CU at T = 4)
+  const int64_t per_cu = T >= 3 ? 1 : (T == 2 ? 2 : 4);
+  const int64_t cap = a.queue ? per_cu * wide_cus() : ((int64_t)1 << 20);
+  const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
+  if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true>), grid, FF_WAVE * T, stream, a, n);
+  FF_LAUNCH((ff_wide_eloc_kernel<D, T, false>), grid, FF_WAVE * T, stream, a, n);
+}
+
+int ff_wide_dispatch_fwd(int mode, void* stream, int n, int d, const ff_fwd_args& a) {
+  if (!ff_wide_supported(n, d)) {
+    ff_set_error("fused CNF kernels serve n <= 24 particles with n*d <= 60 in d = 2, 3");
+    return FF_EUNSUPPORTED;
+  }
+  if (mode == 0) { if (d == 2) launch_wide_flow<2, 0>(stream, a, n); else launch_wide_flow<3, 0>(stream, a, n); }
+  else if (mode == 1) { if (d == 2) launch_wide_flow<2, 1>(stream, a, n); else launch_wide_flow<3, 1>(stream, a, n); }
+  else {
+    const int T = (n * d + 4 + 15) / 16;
+#define FF_WE(D_, T_) if (d == D_ && T == T_) launch_wide_eloc<D_, T_>(stream, a, n);
+    FF_WE(2, 1) FF_WE(2, 2) FF_WE(2, 3) FF_WE(2, 4) FF_WE(3, 1) FF_WE(3, 2) FF_WE(3, 3) FF_WE(3, 4)
+#undef FF_WE
+  }
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}

@@ -26,6 +26,12 @@ def orbital_table(idx, device):
     return tab
 
 
+def set_kernel_family(family):
+    """ff_set_kernel_family: 0 = by particle number (default), 1 = one walker per workgroup for every particle number.
+    Returns the previous setting."""
+    return int(L.lib().ff_set_kernel_family(int(family)))
+
+
 def _state(ws):
     return None if ws is None else L.dev(ws, torch.int32, "walker_state")
 

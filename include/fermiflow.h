@@ -79,6 +79,11 @@ int ff_version(void);   /* 102; changes whenever a struct of this header changes
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);
 const char* ff_last_error(void);
+/* Kernel family of the fused CNF kernels (ff_cnf_generate, ff_cnf_delta_logp, ff_eloc_sensitivities, ff_cnf_adjoint*):
+ * 0 (default) = by particle number -- one wave per walker group up to 12 particles in d = 2 / 4 in d = 3, one walker per
+ * workgroup beyond (up to 24 particles, n d <= 60); 1 = one walker per workgroup for EVERY particle number (A/B and parity
+ * testing; FF_WIDE=1 in the environment selects it at load time).  Returns the previous value. */
+int ff_set_kernel_family(int family);
 
 /* ---- many-body state enumeration (host code, no GPU) ------------------------------------------ */
 /* Orbitals.fermion_states (src/orbitals.py:33-54; the subset search of :14-31): all Slater-determinant states of nup

@@ -91,6 +91,23 @@ inline double ff_sim_mfma4(double a, double b, double c) {
   return acc;
 }
 
+// v_mfma_f64_16x16x4_f64 per wave of a (possibly multi-wave) workgroup; every lane of the workgroup must call it
+typedef double ff_sim_d4 __attribute__((vector_size(32)));
+static double ff_sim_mfma16_a[1024], ff_sim_mfma16_b[1024];
+inline ff_sim_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, ff_sim_d4 c, int, int, int) {
+  const int t = threadIdx.x, w0 = t & ~63, l = t & 63;
+  ff_sim_mfma16_a[t] = a; ff_sim_mfma16_b[t] = b;
+  __syncthreads();
+  for (int v = 0; v < 4; v++) {
+    const int i = 4 * v + l / 16, j = l % 16;
+    double acc = c[v];
+    for (int k = 0; k < 4; k++) acc = __builtin_fma(ff_sim_mfma16_a[w0 + 16 * k + i], ff_sim_mfma16_b[w0 + 16 * k + j], acc);
+    c[v] = acc;
+  }
+  __syncthreads();
+  return c;
+}
+
 template <class K, class... A>
 inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   pthread_barrier_t bar;

@@ -1,0 +1,205 @@
+"""GPU parity of the one-walker-per-workgroup kernel family (csrc/ff_wide.hip, csrc/ff_adj_wide.h): BASELINE.json configs[4]
+(nup = ndown = 10 in a 3-D trap, n d = 60) and every 2-D system beyond 12 particles -- shapes the reference serves through
+its shape-generic PyTorch code (src/equivariant_funs.py:17-102, --nup/--ndown of src/FermionHO2D.py:18-19).
+
+The oracle (oracle/ff_oracle.c) is the checker; the north-star bar for E_loc is 1e-5 relative (fp64).  d = 3 has no upstream
+code: its oracle is pinned by the eigenfunction known-answer test only (tests/test_oracle_golden.py), which is repeated here
+through the production path at BASELINE size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.common import net_arrays
+
+pytestmark = pytest.mark.gpu
+ELOC_RTOL = 1e-5     # BASELINE.json north_star: "E_loc within 1e-5 relative fp64"
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _onet(model):
+    v = model.cnf.v_wrapper.v
+    return O.Net(tuple(N(t) for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
+                 tuple(N(t) for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+
+
+@pytest.fixture
+def wide_family():
+    """ff_set_kernel_family(1): every particle number takes the one-walker-per-workgroup kernels."""
+    from fermiflow_amd import native
+    prev = native.set_kernel_family(1)
+    yield
+    native.set_kernel_family(prev)
+
+
+@pytest.mark.parametrize("nup,ndn", [(3, 3), (2, 1), (4, 3), (6, 6)])
+def test_wide_kernels_agree_with_the_wave_per_group_kernels(dev, nup, ndn):
+    """Same walkers, same weights, both kernel families (ff_set_kernel_family): flow, log-density, local energy (E_loc, grad,
+    logp) and the adjoint's parameter gradient agree to solver tolerance -- the two families share nothing but the radial
+    table and the step-size rules."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, nup, ndn, 2.0)
+    v = model.cnf.v_wrapper.v
+    B = 96
+    torch.manual_seed(11 + nup)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    res = []
+    for fam in (0, 1):
+        prev = native.set_kernel_family(fam)
+        try:
+            net = v.net(refresh=True)
+            x = native.cnf_generate(net, z, 0.0, 1.0, 1e-9, 1e-11)
+            zb, dl = native.cnf_delta_logp(net, x, 0.0, 1.0, 1e-9, 1e-11)
+            tu, td = model._tables(dev)
+            r = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-9, 1e-11, 2.0, True, want_stats=True)
+            assert int(r["stats"][3]) == 0
+            w = (r["eloc"] - r["eloc"].mean()) / B
+            gx, gp = native.cnf_adjoint(net, r["z"].clone(), w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-9, 1e-11)
+            res.append(dict(x=N(x), zb=N(zb), dl=N(dl), eloc=N(r["eloc"]), grad=N(r["grad"]), logp=N(r["logp"]), gx=N(gx), gp=N(gp)))
+        finally:
+            native.set_kernel_family(prev)
+    a, b = res
+    np.testing.assert_allclose(b["x"], a["x"], atol=1e-8)
+    np.testing.assert_allclose(b["zb"], a["zb"], atol=1e-8)
+    np.testing.assert_allclose(b["dl"], a["dl"], atol=1e-8)
+    assert (np.abs(b["eloc"] - a["eloc"]) / np.abs(a["eloc"])).max() < 1e-6
+    np.testing.assert_allclose(b["grad"], a["grad"], atol=1e-6 * max(1.0, np.abs(a["grad"]).max()))
+    np.testing.assert_allclose(b["logp"], a["logp"], atol=1e-7)
+    np.testing.assert_allclose(b["gx"], a["gx"], atol=1e-7 * max(1.0, np.abs(a["gx"]).max()))
+    np.testing.assert_allclose(b["gp"], a["gp"], atol=1e-7 * max(1.0, np.abs(a["gp"]).max()))
+
+
+@pytest.mark.parametrize("nup,ndn", [(7, 6), (8, 8), (12, 12)])
+def test_more_than_twelve_particles_vs_oracle(golden, dev, nup, ndn):
+    """GSVMC(7, 6, HO2D(), ...) and beyond (VERDICT r02 missing #2): flow, local energy and the parameter gradient of a 13-,
+    16- and 24-particle dot against the oracle."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    G = golden["g5_gsvmc"]
+    n = nup + ndn
+    model = Gm._model(dev, nup, ndn, 1.0)
+    net = O.Net(*net_arrays(G, "z2_nt_"))
+    B = 6 if n <= 16 else 3
+    torch.manual_seed(100 + n)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    v = model.cnf.v_wrapper.v
+    x = native.cnf_generate(v.net(), z, 0.0, 1.0, 1e-8, 1e-10)
+    xo, _ = O.cnf_generate(N(z), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(x), xo, atol=1e-7)
+    r = model.local_energy(x, want_stats=True)
+    assert int(r["stats"][3]) == 0
+    ref = O.eloc(N(x), nup, ndn, net, 1.0, rtol=1e-9, atol=1e-11)
+    assert (np.abs(N(r["eloc"]) - ref["eloc"]) / np.abs(ref["eloc"])).max() < ELOC_RTOL
+    np.testing.assert_allclose(N(r["grad"]), ref["grad"], atol=2e-5 * max(1.0, np.abs(ref["grad"]).max()))
+    w = (r["eloc"] - r["eloc"].mean()) / B
+    _, gp = native.cnf_adjoint(v.net(), r["z"], w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-8, 1e-10, need_gx=False)
+    zo, dlo, _ = O.cnf_delta_logp(N(x), net, rtol=1e-10, atol=1e-12)
+    _, g0o, _ = O.logprob(zo, nup, ndn)
+    _, gpo, _ = O.cnf_adjoint(zo, dlo, N(w)[:, None, None] * g0o, -N(w), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(gp), gpo, atol=2e-5 * np.abs(gpo).max())
+
+
+def test_thirteen_particle_training_iteration(dev):
+    """the drop-in surface at 13 particles: GSVMC(7, 6, HO2D(), ...)(batch).backward() fills every .grad."""
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 7, 6, 2.0)
+    torch.manual_seed(3)
+    g = model(2048)
+    g.backward()
+    assert np.isfinite(model.E) and np.isfinite(model.E_std)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def _model3d(dev, nup, ndn, Z, zero):
+    import fermiflow_amd as ff
+    import __graft_entry__ as Gm
+    gs = Gm._model(dev, 2, 2, Z)
+    if zero:
+        for p in gs.parameters():
+            torch.nn.init.zeros_(p)
+    return ff.GSVMC(nup, ndn, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(Z), sp_potential=ff.HO())
+
+
+def test_config5_known_answer_at_full_size(dev):
+    """BASELINE.json configs[4] at its per-GPU size: nup = ndown = 10 in the 3-D trap (closed shells 0..2), 131 072 walkers.
+    Zero flow and Z = 0: every walker's E_loc is the sum of the occupied orbital energies, 2 (1.5 + 3 * 2.5 + 6 * 3.5) = 60
+    (tests/test_basedist.py:5-60 one dimension up).  The 10 x 10 determinants of Metropolis walkers are occasionally
+    ill-conditioned, hence quantile criteria as in test_ho3d_base_distribution."""
+    model = _model3d(dev, 10, 10, 0.0, True)
+    torch.manual_seed(4)
+    g = model(131072)
+    g.backward()
+    assert model.x.shape == (131072, 20, 3)
+    err = (model.Eloc - 60.0).abs()
+    q = torch.quantile(err, torch.tensor([0.5, 0.99, 0.9999], dtype=torch.float64, device=dev))
+    assert q[0].item() < 1e-9 and q[1].item() < 1e-6 and q[2].item() < 1e-3, q
+    assert np.isfinite(model.E) and abs(model.Eloc.median().item() - 60.0) < 1e-9
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_config5_local_energy_vs_oracle(dev):
+    """configs[4] with the benchmark's flow and Z = 2: 24 walkers of a training iteration against the oracle's generic jet
+    arithmetic (O.eloc3d), E_loc within the north-star bar; flow and parameter gradient too."""
+    from fermiflow_amd import native
+    model = _model3d(dev, 10, 10, 2.0, False)
+    torch.manual_seed(5)
+    g = model(2048)
+    g.backward()
+    assert np.isfinite(model.E) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+    net = _onet(model)
+    nb = 24
+    ref = O.eloc3d(N(model.x[:nb]), 10, 10, net, 2.0, rtol=1e-9, atol=1e-11)
+    rel = np.abs(N(model.Eloc[:nb]) - ref["eloc"]) / np.abs(ref["eloc"])
+    print(f"config 5, 24 walkers: max rel E_loc error vs oracle {rel.max():.2e}")
+    assert rel.max() < ELOC_RTOL, rel.max()
+    # stand-alone calls at a tight tolerance: flow, log-density and the adjoint's parameter gradient
+    v = model.cnf.v_wrapper.v
+    torch.manual_seed(6)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (4,))
+    x = native.cnf_generate(v.net(), z, 0.0, 1.0, 1e-9, 1e-11)
+    xo, _ = O.cnf_generate(N(z), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(x), xo, atol=1e-7)
+    zb, dl = native.cnf_delta_logp(v.net(), x, 0.0, 1.0, 1e-9, 1e-11)
+    zo, dlo, _ = O.cnf_delta_logp(N(x), net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(zb), zo, atol=1e-7)
+    np.testing.assert_allclose(N(dl), dlo, atol=1e-7)
+    rng = np.random.default_rng(0)
+    az, ad = rng.normal(size=zo.shape), rng.normal(size=4)
+    gx, gp = native.cnf_adjoint(v.net(), torch.as_tensor(zo, device=dev), torch.as_tensor(az, device=dev), torch.as_tensor(ad, device=dev),
+                                0.0, 1.0, 1e-9, 1e-11)
+    gxo, gpo, _ = O.cnf_adjoint(zo, dlo, az, ad, net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(N(gx), gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
+    np.testing.assert_allclose(N(gp), gpo, atol=1e-6 * np.abs(gpo).max())
+
+
+def test_wide_direct_evaluation_equals_the_table_path(dev):
+    """Backflow.net(radial="exact") (what FERMIFLOW_RADIAL=exact selects; no radial table: every sigmoid evaluated, parameter gradient integrated per hidden unit) against the
+    tabulated kernels, 13 particles: E_loc and the parameter gradient agree far below the solver tolerance."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    out = []
+    for mode in ("table", "exact"):
+        model = Gm._model(dev, 7, 6, 2.0)
+        v = model.cnf.v_wrapper.v
+        torch.manual_seed(21)
+        z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (64,))
+        net = v.net(radial=mode, refresh=True)
+        x = native.cnf_generate(net, z, 0.0, 1.0, 1e-9, 1e-11)
+        tu, td = model._tables(dev)
+        r = native.eloc(tu, td, 7, 6, net, x, 0.0, 1.0, 1e-9, 1e-11, 2.0, True)
+        w = (r["eloc"] - r["eloc"].mean()) / 64
+        _, gp = native.cnf_adjoint(net, r["z"].clone(), w[:, None, None] * r["glogp0"], -w, 0.0, 1.0, 1e-9, 1e-11, need_gx=False)
+        out.append((N(x), N(r["eloc"]), N(gp)))
+    np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-9)
+    assert (np.abs(out[1][1] - out[0][1]) / np.abs(out[0][1])).max() < 1e-8
+    np.testing.assert_allclose(out[1][2], out[0][2], atol=1e-8 * np.abs(out[0][2]).max())
