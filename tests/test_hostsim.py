@@ -575,3 +575,43 @@ def test_finite_temperature_estimator_kernels(golden):
     gx1, gp1, _ = S.cnf_adjoint_energy(r["z"], r["glogp0"], r["eloc"], m3, 1.0 / 6, net, mean_index=st)
     np.testing.assert_allclose(gx1, gx0, rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(gp1, gp0, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("nup,ndn,d,B,force", [(2, 1, 2, 2, True), (3, 2, 3, 1, True), (7, 6, 2, 1, False)])
+def test_one_walker_per_workgroup_kernels(nup, ndn, d, B, force):
+    """csrc/ff_wide.hip and csrc/ff_adj_wide.h in the host simulator (multi-wave workgroups; the 16x16x4 matrix instruction
+    emulated per wave): flow, log-density, the matrix-core local-energy kernel and the adjoint (table and direct variants)
+    against the oracle -- forced onto small systems (ff_set_kernel_family) and where they are the only kernels (13 particles)."""
+    n = nup + ndn
+    rng = np.random.default_rng(7 + n)
+    He = Hm = 8
+    eta = [rng.normal(size=He) * 0.5, rng.normal(size=He) * 0.3, rng.normal(size=He) * 0.05]
+    mu = [rng.normal(size=Hm) * 0.5, rng.normal(size=Hm) * 0.3, rng.normal(size=Hm) * 0.05]
+    x = rng.normal(size=(B, n, d)) * (1.0 if n < 10 else 0.7)
+    onet = O.Net(eta, mu)
+    tol = dict(rtol=1e-8, atol=1e-10)
+    xo, _ = O.cnf_generate(x, onet, rtol=1e-11, atol=1e-13)
+    zo, dlo, _ = O.cnf_delta_logp(xo, onet, rtol=1e-11, atol=1e-13)
+    ref = (O.eloc3d if d == 3 else O.eloc)(xo, nup, ndn, onet, 2.0, rtol=1e-11, atol=1e-13)
+    az, ad = rng.normal(size=x.shape), rng.normal(size=B)
+    gxo, gpo, _ = O.cnf_adjoint(zo, dlo, az, ad, onet, rtol=1e-11, atol=1e-13)
+    prev = S.lib().ff_set_kernel_family(1 if force else 0)
+    try:
+        for table in ((True, False) if n < 10 else (True,)):
+            net = S.Net(eta, mu, table=table)
+            xs, st = S.cnf_generate(x, net, **tol)
+            assert st[3] == 0
+            np.testing.assert_allclose(xs, xo, atol=1e-7)
+            zs, dls, st = S.cnf_delta_logp(xo, net, **tol)
+            np.testing.assert_allclose(zs, zo, atol=1e-7)
+            np.testing.assert_allclose(dls, dlo, atol=1e-7)
+            r = (S.eloc3d if d == 3 else S.eloc)(xo, nup, ndn, net, 2.0, **tol)
+            assert r["stats"][3] == 0
+            np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-6)
+            np.testing.assert_allclose(r["grad"], ref["grad"], atol=1e-6 * max(1.0, np.abs(ref["grad"]).max()))
+            np.testing.assert_allclose(r["logp"], ref["logp"], atol=1e-7)
+            gx, gp, st = S.cnf_adjoint(zo, az, ad, net, **tol)
+            np.testing.assert_allclose(gx, gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
+            np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
+    finally:
+        S.lib().ff_set_kernel_family(prev)
