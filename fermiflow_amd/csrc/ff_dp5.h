@@ -36,8 +36,9 @@ struct ff_dp5_ctl {
 
 // Consumes out = f(stage input of stage s).  wgt(v): weight of component v in the error norm; gsum(part): the sum of a
 // per-lane partial over the workgroup (identical on all lanes).  Returns the next stage, or 99 when the walker is done.
-template <int NV, class W, class G>
-FF_D int ff_dp5_consume(int s, ff_stepper& S, ff_dp5_ctl& C, double* y, double* c0, double* c1, double* c2, double* c3,
+// c3 is any indexable per-lane vector (registers, or lane-private LDS columns).
+template <int NV, class C3, class W, class G>
+FF_D int ff_dp5_consume(int s, ff_stepper& S, ff_dp5_ctl& C, double* y, double* c0, double* c1, double* c2, C3& c3,
                         const double* out, W wgt, G gsum) {
   const double h = S.h, rtol = C.rtol, atol = C.atol;
   if (s == -2) {

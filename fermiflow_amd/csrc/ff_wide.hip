@@ -34,6 +34,14 @@
 #include "ff_radial.h"
 #include "ff_fwd_args.h"
 
+// FF_STAMPS: diagnostic build only (make variant NAME=stamps EXTRA=-DFF_STAMPS; tools/probes/wide_c5.py): s_memtime shares
+// of the phases of the local-energy kernel's right-hand side, added into stats[8..] as 64-bit counters by wave 0.
+#ifdef FF_STAMPS
+#define FF_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_prev; stamp_prev = t_; } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
+
 #define FF_WIDE_NMAX 24
 #define FF_WIDE_MMAX 60
 #define FF_WIDE_RMAX (FF_WIDE_NMAX * (FF_WIDE_NMAX + 1) / 2)   // pairs + one-body radii
@@ -224,9 +232,39 @@ ff_wide_flow_kernel(ff_fwd_args A, int n) {
 
 // =====================================================================================================================
 // Local-energy sensitivities: one walker per workgroup of T waves, both dense products on the matrix cores (file header).
-// Lane state (NV = 4 T + 4 doubles): [0, 4T) its elements of J (rows 0..M-1: dz/dx; row M: grad_x Delta), [4T] z_p and
-// [4T+1] kbar_p for the owner lanes tid = p < M, [4T+2] / [4T+3] the shares of Delta / lap_x Delta that the lane's own
-// radii contribute (plain quadratures, summed at the end).
+// Lane roles (NTHR = 64 T lanes):
+//   * every lane: its 4 T elements of J (rows 0..M-1: dz/dx; row M: grad_x Delta);
+//   * "row lanes" tid = 4 p + s, p < M: the four lanes of coordinate p split the partners of p's particle (b = s, s + 4, ...):
+//     own-row sums (v, D_v[kbar], grad div, the diagonal block of A) as quad reductions (DPP), the off-diagonal blocks of row p
+//     of A written on the way; lane s = 0 owns z_p and kbar_p;
+//   * "radius lanes" tid < nrad (NQ slots): one radius each in R1 / R2, and the shares of Delta / lap_x Delta of its radii.
+// Lane state (NV = 4 T + 4 doubles): [0, 4T) J, [4T] z_p, [4T+1] kbar_p, [4T+2] / [4T+3] the Delta / lap Delta shares.
+// The error accumulator of the Dormand-Prince step lives in lane-private LDS columns for T >= 3 (registers: the four other
+// vectors, the stage J and two sets of MFMA accumulators already fill the file).
+template <int NV, int NTHR, bool IN_LDS>
+struct ff_wide_vec;
+template <int NV, int NTHR>
+struct ff_wide_vec<NV, NTHR, false> {
+  double r[NV];
+  FF_D ff_wide_vec(double*, int) {}
+  FF_D double& operator[](int v) { return r[v]; }
+  FF_D const double& operator[](int v) const { return r[v]; }
+};
+template <int NV, int NTHR>
+struct ff_wide_vec<NV, NTHR, true> {
+  double* col;
+  FF_D ff_wide_vec(double* base, int tid) : col(base + tid) {}
+  FF_D double& operator[](int v) { return col[v * NTHR]; }
+  FF_D const double& operator[](int v) const { return col[v * NTHR]; }
+};
+
+// sum over the four lanes of a quad (lanes 4q .. 4q+3), result on all four
+FF_D double ff_quad_sum(double v) {
+  v += ff_swap1(v);
+  v += ff_swap2(v);
+  return v;
+}
+
 template <int D, int T, bool TAB>
 __global__ void __launch_bounds__(FF_WAVE * T)
 ff_wide_eloc_kernel(ff_fwd_args A, int n) {
@@ -236,6 +274,8 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   constexpr int NCAP = (MP - 4) / D > FF_WIDE_NMAX ? FF_WIDE_NMAX : (MP - 4) / D;   // particles this instantiation can hold
   constexpr int RCAP = NCAP * (NCAP + 1) / 2;
   constexpr int NQ = (RCAP + NTHR - 1) / NTHR;
+  constexpr int NPK = (NCAP + 3) / 4;                  // partners per row lane
+  constexpr bool C3_LDS = T >= 3 && TAB;       // (the direct-evaluation variant needs the LDS for its weight tables)
   // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
   //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
   // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
@@ -248,6 +288,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   __shared__ __attribute__((aligned(16))) double s_A[MP * JS];   // A = dv/dz with row M = -grad div; then S = J J^T
   __shared__ __attribute__((aligned(16))) double s_rec[RCAP * RW];
   __shared__ double s_z[MP], s_kb[MP], s_red[NTHR], s_red2[16];
+  __shared__ double s_c3[C3_LDS ? NV * NTHR : 1];
   __shared__ int s_st[4];
   __shared__ long long s_next;
 
@@ -276,13 +317,22 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   int rq_id[NQ];
 #pragma unroll
   for (int qk = 0; qk < NQ; qk++) rq_id[qk] = ff_wide_radius_id(n, tid + qk * NTHR, nrad);
-  const bool own = tid < M;
-  const int ai = own ? tid / D : 0, ci = own ? tid % D : 0;
-  // A assembly: row p = tid / 4 (p <= M - 1), partners b = tid % 4, + 4, ...
-  const int asm_p = tid >> 2, asm_s = tid & 3;
-  const bool asm_on = asm_p < M;
-  const int asm_a = asm_on ? asm_p / D : 0, asm_c = asm_on ? asm_p % D : 0;
-  const int ksteps = (M + 3) / 4;            // k-steps of both products: columns / rows beyond M are zero
+  // row lanes: coordinate p = tid / 4 of particle ra, partners rs, rs + 4, ...; packed per partner:
+  // record offset << 3 | (partner < ra) << 2 | (partner == ra) << 1 | valid
+  const int rp = tid >> 2, rs = tid & 3;
+  const bool rowlane = rp < M;
+  const bool own = rowlane && rs == 0;
+  const int ra = rowlane ? rp / D : 0, rc = rowlane ? rp % D : 0;
+  int pinfo[NPK];
+#pragma unroll
+  for (int k = 0; k < NPK; k++) {
+    const int bpart = rs + 4 * k;
+    const bool valid = rowlane && bpart < n && (bpart != ra || has_mu);
+    pinfo[k] = valid ? ((ff_wide_partner(n, P, ra, bpart) * RW) << 3) | ((bpart < ra) << 2) | ((bpart == ra) << 1) | 1 : 0;
+  }
+#ifdef FF_STAMPS
+  unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int64_t bq = blockIdx.x;; bq += gridDim.x) {
     if (A.queue) {   // persistent grid: next walker from the launch's work counter (heavy walkers sit at the front)
@@ -293,10 +343,11 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     }
     if (bq >= A.B) break;
     const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);
-    double y[NV], c0[NV], c1[NV], c2[NV], c3[NV];
+    double y[NV], c0[NV], c1[NV], c2[NV];
+    ff_wide_vec<NV, NTHR, C3_LDS> c3(s_c3, tid);
 #pragma unroll
     for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
-    if (own) y[IZ] = A.y_in[b * M + tid];
+    y[IZ] = ff_opt_load(A.y_in, own, b * M + rp, A.y_in, 0.0);
 #pragma unroll
     for (int K = 0; K < T; K++)
 #pragma unroll
@@ -323,6 +374,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       double gy, g0, g1, g2;
       ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
+      FF_STAMP(7);
       // ---------------------------------------------------------------- publish z, kbar, J (the stage J stays in registers:
       // it is the B operand of J' = A J)
       double Jin[NVJ];
@@ -330,12 +382,13 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       for (int v = 0; v < NVJ; v++) Jin[v] = form(v);
       const double kb_in = form(IK);
       __syncthreads();
-      if (own) { s_z[tid] = form(IZ); s_kb[tid] = kb_in; }
+      if (own) { s_z[rp] = form(IZ); s_kb[rp] = kb_in; }
 #pragma unroll
       for (int K = 0; K < T; K++)
 #pragma unroll
         for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = Jin[4 * K + v];
       __syncthreads();
+      FF_STAMP(0);
       // ---------------------------------------------------------------- R1: radius lanes
       double dsum = 0.0;
 #pragma unroll
@@ -378,75 +431,72 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       }
       __syncthreads();
       nev++;
-      // ---------------------------------------------------------------- own-row sums (owner lanes) and the assembly of A
-      double vi = 0.0, wk = 0.0, gdi = 0.0;
-      if (own) {
-        double Ad[D];
+      FF_STAMP(1);
+      // ---------------------------------------------------------------- row lanes: own-row sums and row p of A
+      double vi = 0.0, wk = 0.0, gdi = 0.0, Ad[D];
 #pragma unroll
-        for (int c = 0; c < D; c++) Ad[c] = 0.0;
-        for (int j = 0; j < n; j++) {
-          if (j == ai && !has_mu) continue;
-          const double* rec = &s_rec[ff_wide_partner(n, P, ai, j) * RW];
-          const double sg = j < ai ? -1.0 : 1.0;
-          const double f0 = rec[QF0], fc = rec[QF1] * rec[ci];
-          vi = fma(sg * f0, rec[ci], vi);
-          wk = fma(sg, rec[QPW + ci], wk);
-          gdi = fma(sg * rec[QGQ], rec[ci], gdi);
+      for (int c = 0; c < D; c++) Ad[c] = 0.0;
 #pragma unroll
-          for (int c = 0; c < D; c++) Ad[c] += fma(fc, rec[c], ci == c ? f0 : 0.0);
+      for (int k = 0; k < NPK; k++) {
+        const int pi = pinfo[k];
+        if (pi & 1) {
+          const double* rec = &s_rec[pi >> 3];
+          const double sg = (pi & 4) ? -1.0 : 1.0;
+          const double f0 = rec[QF0], rcv = rec[rc], fc = rec[QF1] * rcv;
+          vi = fma(sg * f0, rcv, vi);
+          wk = fma(sg, rec[QPW + rc], wk);
+          gdi = fma(sg * rec[QGQ], rcv, gdi);
+          double* arow = &s_A[rp * JS + (rs + 4 * k) * D];
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            const double Bcc = fma(fc, rec[c], rc == c ? f0 : 0.0);
+            Ad[c] += Bcc;
+            if (!(pi & 2)) arow[c] = -Bcc;
+          }
         }
-#pragma unroll
-        for (int c = 0; c < D; c++) s_A[tid * JS + ai * D + c] = Ad[c];        // row ci of the diagonal block of particle ai
-        s_A[M * JS + tid] = -gdi;                                               // row M: (grad Delta)' = -g^T J
       }
-      if (asm_on) {
-        for (int bp = asm_s; bp < n; bp += 4) {
-          if (bp == asm_a) continue;
-          const double* rec = &s_rec[ff_wide_partner(n, P, asm_a, bp) * RW];
-          const double f0 = rec[QF0], fc = rec[QF1] * rec[asm_c];
+      vi = ff_quad_sum(vi); wk = ff_quad_sum(wk); gdi = ff_quad_sum(gdi);
 #pragma unroll
-          for (int c = 0; c < D; c++) s_A[asm_p * JS + bp * D + c] = -fma(fc, rec[c], asm_c == c ? f0 : 0.0);
-        }
+      for (int c = 0; c < D; c++) Ad[c] = ff_quad_sum(Ad[c]);
+      if (rowlane) {
+        double adv = Ad[0];
+#pragma unroll
+        for (int c = 1; c < D; c++) adv = (rs == c) ? Ad[c] : adv;
+        if (rs < D) s_A[rp * JS + ra * D + rs] = adv;                           // the diagonal block of particle ra, row rc
+        if (rs == 3) s_A[M * JS + rp] = -gdi;                                    // row M: (grad Delta)' = -g^T J
       }
       __syncthreads();
-      // ---------------------------------------------------------------- the two products on the matrix cores
+      FF_STAMP(2);
+      // ---------------------------------------------------------------- the two products on the matrix cores, k-step by
+      // k-step side by side: S tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k] and J' tiles (I, w) = sum_k A[16 I + i][k] J[k][16 w + j]
+      // (the B operand of k-step ks = 4 K + v of J' is the lane's own Jin[ks]).  Column blocks beyond M are zero and skipped.
       ff_d4 accS[T], accJ[T];
 #pragma unroll
       for (int I = 0; I < T; I++) {
         const ff_d4 zero = {0.0, 0.0, 0.0, 0.0};
         accS[I] = zero; accJ[I] = zero;
       }
-      // S tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k]
       {
         const double* Jb = &s_J[(16 * w + lc) * JS + lg];
         const double* Ja = &s_J[lc * JS + lg];
-#pragma unroll 2
-        for (int ks = 0; ks < ksteps; ks++) {
-          const double bv = Jb[4 * ks];
-          double av[T];
-#pragma unroll
-          for (int I = 0; I < T; I++) av[I] = Ja[16 * I * JS + 4 * ks];
-#pragma unroll
-          for (int I = 0; I < T; I++) accS[I] = ff_mfma16(av[I], bv, accS[I]);
-        }
-      }
-      // J' tiles (I, w) = sum_k A[16 I + i][k] J[k][16 w + j]: the B operand of k-step (K, v) is the lane's own Jin[4 K + v]
-      {
         const double* Aa = &s_A[lc * JS + lg];
 #pragma unroll
-        for (int K = 0; K < T; K++)
+        for (int K = 0; K < T; K++) {
+          if (16 * K < M) {      // workgroup-uniform
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            if (4 * (4 * K + v) < M) {     // workgroup-uniform
-              const double bv = Jin[4 * K + v];
-              double av[T];
+            for (int v = 0; v < 4; v++) {
+              const int ks = 4 * K + v;
+              const double bS = Jb[4 * ks], bJ = Jin[ks];
+              double aS[T], aJ[T];
 #pragma unroll
-              for (int I = 0; I < T; I++) av[I] = Aa[16 * I * JS + 16 * K + 4 * v];
+              for (int I = 0; I < T; I++) { aS[I] = Ja[16 * I * JS + 4 * ks]; aJ[I] = Aa[16 * I * JS + 4 * ks]; }
 #pragma unroll
-              for (int I = 0; I < T; I++) accJ[I] = ff_mfma16(av[I], bv, accJ[I]);
+              for (int I = 0; I < T; I++) { accS[I] = ff_mfma16(aS[I], bS, accS[I]); accJ[I] = ff_mfma16(aJ[I], bJ, accJ[I]); }
             }
           }
+        }
       }
+      FF_STAMP(3);
       __syncthreads();      // every wave is done reading A ...
 #pragma unroll
       for (int I = 0; I < T; I++)
@@ -455,6 +505,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
           if (16 * I + 4 * v + lg < M && 16 * w + lc < M) s_A[(16 * I + 4 * v + lg) * JS + 16 * w + lc] = accS[I][v];
         }
       __syncthreads();
+      FF_STAMP(4);
       // ---------------------------------------------------------------- R2: radius lanes contract their terms with S
       double qsum = 0.0;
 #pragma unroll
@@ -491,23 +542,25 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         qsum += fma(Bc, qq, gq * tq);
       }
       __syncthreads();
+      FF_STAMP(5);
       // ---------------------------------------------------------------- second-order sums, right-hand side
       double out[NV];
       double qs = 0.0;
-      if (own) {
-        for (int j = 0; j < n; j++) {
-          if (j == ai && !has_mu) continue;
-          qs = fma(j < ai ? -1.0 : 1.0, s_rec[ff_wide_partner(n, P, ai, j) * RW + QPW + ci], qs);
-        }
+#pragma unroll
+      for (int k = 0; k < NPK; k++) {
+        const int pi = pinfo[k];
+        if (pi & 1) qs = fma((pi & 4) ? -1.0 : 1.0, s_rec[(pi >> 3) + QPW + rc], qs);
       }
+      qs = ff_quad_sum(qs);
 #pragma unroll
       for (int I = 0; I < T; I++)
 #pragma unroll
         for (int v = 0; v < 4; v++) out[4 * I + v] = accJ[I][v];
-      out[IZ] = vi;
-      out[IK] = wk + qs;
+      out[IZ] = own ? vi : 0.0;
+      out[IK] = own ? wk + qs : 0.0;
       out[IDL] = -dsum;
-      out[ILP] = -(qsum + gdi * kb_in);
+      out[ILP] = -(qsum + (own ? gdi * kb_in : 0.0));
+      FF_STAMP(6);
       s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
       if (s == 99) break;
     }
@@ -527,10 +580,10 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       if (l < M) A.Jt[(b * M + i) * M + l] = s_J[l * JS + i];
     }
     if (own) {
-      A.y_out[b * M + tid] = y[IZ] + bad;
-      A.kbar[b * M + tid] = y[IK];
-      A.dD[b * M + tid] = s_J[M * JS + tid];
-      A.Lpart[b * M + tid] = tid == 0 ? lapd : 0.0;
+      A.y_out[b * M + rp] = y[IZ] + bad;
+      A.kbar[b * M + rp] = y[IK];
+      A.dD[b * M + rp] = s_J[M * JS + rp];
+      A.Lpart[b * M + rp] = rp == 0 ? lapd : 0.0;
     }
     if (tid == 0) {
       A.dl_out[b] = delta + bad;
@@ -540,6 +593,10 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     }
     __syncthreads();
   }
+#ifdef FF_STAMPS
+  if (A.stats && tid == 0)
+    for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+#endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
   __syncthreads();
   if (A.stats && tid == 0 && (s_st[0] || s_st[3])) {

@@ -74,7 +74,7 @@ inline double ff_sim_swap1(double v) {
 inline double ff_sim_lane_read(double v, int src) {
   ff_sim_swap_buf[threadIdx.x] = v;
   __syncthreads();
-  const double o = ff_sim_swap_buf[src & 63];
+  const double o = ff_sim_swap_buf[(threadIdx.x & ~63u) | (src & 63)];   // lanes of the caller's own wave
   __syncthreads();
   return o;
 }

@@ -32,3 +32,7 @@ for it in range(iters):
     print(f"iter {it}: {1e3 * (t1 - t0):8.2f} ms  E = {model.E:.6f} +- {model.E_std:.4f}  stages(ms) " +
           " ".join(f"{k}={v:.2f}" for k, v in st.items()) + f"  sens-kernel={p1[0].elapsed_time(p1[1]):.2f} ms  evals/walker={stats[0] / B:.2f} "
           f"max steps={stats[1]} rejected={stats[2]} fail={stats[3]}", flush=True)
+    if os.environ.get("FERMIFLOW_LIB", "").endswith("stamps.so"):
+        st8 = model.profile["eloc_stats"][0][8:26].view(torch.int64)[:9].double()
+        names8 = ["publish", "R1", "own rows + A", "products", "S to LDS", "R2", "2nd-order sums", "consume"]
+        print("   ticks per evaluation: " + "  ".join(f"{nm} {v / stats[0]:.0f}" for nm, v in zip(names8, st8.tolist())) + f"   total {st8.sum().item() / stats[0]:.0f}")
