@@ -19,10 +19,10 @@
 //   * row M of J is grad_x Delta: row M of A holds -g, so (A J)[M][i] = -sum_p g_p J[p][i] comes out of the same product;
 //   * A (assembled from the D x D pair blocks B = eta I + (eta'/r) rho rho^T that the radius lanes leave in per-radius
 //     records) and the stage J are read as MFMA operands from LDS (row stride MP + 2 doubles: conflict-free for the
-//     (row = lane % 16, column = k0 + lane / 16) operand pattern); S is written over A once every wave is done with A.
-// Per right-hand side: publish -> R1 (one radius per lane: heads, record) -> own-row sums, A assembly -> S = J J^T and
-// J' = A J -> S to LDS -> R2 (radius lanes contract their terms with S) -> second-order sums -> Dormand-Prince bookkeeping
-// (ff_dp5.h).  fp64 matrix and vector instructions have the same peak on this part (and do not overlap,
+//     (row = lane % 16, column = k0 + lane / 16) operand pattern); S is written over the stage J once every wave has read it.
+// Per right-hand side (four workgroup barriers): publish | radii, table rows requested, S = J J^T under the fetch, heads ->
+// records | S takes the stage J's place in LDS; own-row sums, A assembled | J' = A J; radius lanes contract their terms with S |
+// second-order sums, Dormand-Prince bookkeeping (ff_dp5.h).  fp64 matrix and vector instructions have the same peak on this part (and do not overlap,
 // tools/probes/mfma_f64.hip), so the matrix cores buy instruction slots and operand traffic, not flops: the kernel is
 // bound by 2 * T * ceil(M/4) matrix instructions of 64 cycles per wave and evaluation.
 #include <stdlib.h>
@@ -284,9 +284,9 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 
   __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
   __shared__ double s_e2[TAB ? 1 : 64];
-  __shared__ __attribute__((aligned(16))) double s_J[MP * JS];   // stage J, [p][i]
-  __shared__ __attribute__((aligned(16))) double s_A[MP * JS];   // A = dv/dz with row M = -grad div; then S = J J^T
-  __shared__ __attribute__((aligned(16))) double s_rec[RCAP * RW];
+  __shared__ __attribute__((aligned(16))) double s_J[MP * JS];   // stage J, [p][i]; then S = J J^T
+  __shared__ __attribute__((aligned(16))) double s_A[MP * JS];   // A = dv/dz with row M = -grad div
+  __shared__ __attribute__((aligned(16))) double s_rec[(RCAP + 1) * RW];   // + one record that stays zero
   __shared__ double s_z[MP], s_kb[MP], s_red[NTHR], s_red2[16];
   __shared__ double s_c3[C3_LDS ? NV * NTHR : 1];
   __shared__ int s_st[4];
@@ -307,7 +307,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   bool off_table = false;
   if (tid < 4) s_st[tid] = 0;
   for (int e = tid; e < MP * JS; e += NTHR) { s_J[e] = 0.0; s_A[e] = 0.0; }
-  for (int e = tid; e < RCAP * RW; e += NTHR) s_rec[e] = 0.0;
+  for (int e = tid; e < (RCAP + 1) * RW; e += NTHR) s_rec[e] = 0.0;
   if (tid < MP) { s_z[tid] = 0.0; s_kb[tid] = 0.0; }
   __syncthreads();
   const int He = A.net.He, Hm = A.net.Hm;
@@ -323,12 +323,15 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   const bool rowlane = rp < M;
   const bool own = rowlane && rs == 0;
   const int ra = rowlane ? rp / D : 0, rc = rowlane ? rp % D : 0;
-  int pinfo[NPK];
+  // per partner slot (branch-free: an absent partner reads the all-zero record behind the last one and "writes" -0.0 where the
+  // diagonal block is stored afterwards): record offset | sign bit, and the destination of the off-diagonal block row in A
+  int prec[NPK], pdst[NPK];
 #pragma unroll
   for (int k = 0; k < NPK; k++) {
     const int bpart = rs + 4 * k;
     const bool valid = rowlane && bpart < n && (bpart != ra || has_mu);
-    pinfo[k] = valid ? ((ff_wide_partner(n, P, ra, bpart) * RW) << 3) | ((bpart < ra) << 2) | ((bpart == ra) << 1) | 1 : 0;
+    prec[k] = ((valid ? ff_wide_partner(n, P, ra, bpart) : RCAP) * RW) << 1 | ((valid && bpart < ra) ? 1 : 0);
+    pdst[k] = rp * JS + ((valid && bpart != ra) ? bpart : ra) * D;
   }
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
@@ -381,7 +384,6 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
       for (int v = 0; v < NVJ; v++) Jin[v] = form(v);
       const double kb_in = form(IK);
-      __syncthreads();
       if (own) { s_z[rp] = form(IZ); s_kb[rp] = kb_in; }
 #pragma unroll
       for (int K = 0; K < T; K++)
@@ -389,26 +391,73 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = Jin[4 * K + v];
       __syncthreads();
       FF_STAMP(0);
-      // ---------------------------------------------------------------- R1: radius lanes
+      // ---------------------------------------------------------------- R1, first half: radii, table rows requested
+      double rq_rho[NQ][D], rq_dk[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
+      bool rq_ok[NQ];
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        const bool act = id >= 0;
+        const int a = act ? (id & 31) : 0, bb0 = act ? ((id >> 5) & 31) : 31;
+        const bool pair = bb0 != 31;
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          rq_rho[qk][c] = s_z[a * D + c] - (pair ? s_z[bb0 * D + c] : 0.0);
+          rq_dk[qk][c] = s_kb[a * D + c] - (pair ? s_kb[bb0 * D + c] : 0.0);
+          r2 = fma(rq_rho[qk][c], rq_rho[qk][c], r2);
+        }
+        ff_sqrt_rcp(r2, rq_r[qk], rq_ri[qk]);
+        rq_dr[qk] = 0.0;
+        rq_ok[qk] = true;
+        if constexpr (TAB) {
+          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, act ? rq_r[qk] : 1.0, rq_T[qk], rq_dr[qk]);
+          if (act && !rq_ok[qk]) off_table = true;
+        }
+      }
+      // ---------------------------------------------------------------- S = J J^T on the matrix cores (under the table fetch):
+      // tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k]; column blocks beyond M are zero and skipped
+      ff_d4 accS[T], accJ[T];
+#pragma unroll
+      for (int I = 0; I < T; I++) {
+        const ff_d4 zero = {0.0, 0.0, 0.0, 0.0};
+        accS[I] = zero; accJ[I] = zero;
+      }
+      {
+        const double* Jb = &s_J[(16 * w + lc) * JS + lg];
+        const double* Ja = &s_J[lc * JS + lg];
+#pragma unroll
+        for (int K = 0; K < T; K++) {
+          if (16 * K < M) {      // workgroup-uniform
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              const int ks = 4 * K + v;
+              const double bS = Jb[4 * ks];
+              double aS[T];
+#pragma unroll
+              for (int I = 0; I < T; I++) aS[I] = Ja[16 * I * JS + 4 * ks];
+#pragma unroll
+              for (int I = 0; I < T; I++) accS[I] = ff_mfma16(aS[I], bS, accS[I]);
+            }
+          }
+        }
+      }
+      FF_STAMP(1);
+      // ---------------------------------------------------------------- R1, second half: heads, records
       double dsum = 0.0;
 #pragma unroll
       for (int qk = 0; qk < NQ; qk++) {
         const int id = rq_id[qk];
         if (id < 0) break;
-        const int a = id & 31, bb0 = (id >> 5) & 31, pr = id >> 10;
+        const int bb0 = (id >> 5) & 31, pr = id >> 10;
         const bool pair = bb0 != 31;
-        double rho[D], dk[D], r2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; c++) {
-          rho[c] = s_z[a * D + c] - (pair ? s_z[bb0 * D + c] : 0.0);
-          dk[c] = s_kb[a * D + c] - (pair ? s_kb[bb0 * D + c] : 0.0);
-          r2 = fma(rho[c], rho[c], r2);
-        }
-        double r, ri, hd[NH];
-        ff_sqrt_rcp(r2, r, ri);
+        const double* rho = rq_rho[qk];
+        const double* dk = rq_dk[qk];
+        const double r = rq_r[qk], ri = rq_ri[qk];
+        double hd[NH];
         if constexpr (TAB) {
-          if (!ff_heads_table<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd)) {
-            off_table = true;
+          if (rq_ok[qk]) ff_table_eval<NH>(rq_T[qk], rq_dr[qk], hd);
+          else {
 #pragma unroll
             for (int m = 0; m < NH; m++) hd[m] = 0.0;
           }
@@ -429,30 +478,31 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         rec[QRI2] = ri * ri; rec[QF2] = f2; rec[QBC] = Bc;
         dsum = fma(cf, fma(f1, r, D * f0), dsum);           // this radius' share of div v
       }
-      __syncthreads();
+      __syncthreads();      // records complete; every wave is done reading the stage J ...
       nev++;
-      FF_STAMP(1);
+      FF_STAMP(2);
+#pragma unroll
+      for (int I = 0; I < T; I++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) s_J[(16 * I + 4 * v + lg) * JS + 16 * w + lc] = accS[I][v];   // ... whose place S takes
       // ---------------------------------------------------------------- row lanes: own-row sums and row p of A
       double vi = 0.0, wk = 0.0, gdi = 0.0, Ad[D];
 #pragma unroll
       for (int c = 0; c < D; c++) Ad[c] = 0.0;
 #pragma unroll
       for (int k = 0; k < NPK; k++) {
-        const int pi = pinfo[k];
-        if (pi & 1) {
-          const double* rec = &s_rec[pi >> 3];
-          const double sg = (pi & 4) ? -1.0 : 1.0;
-          const double f0 = rec[QF0], rcv = rec[rc], fc = rec[QF1] * rcv;
-          vi = fma(sg * f0, rcv, vi);
-          wk = fma(sg, rec[QPW + rc], wk);
-          gdi = fma(sg * rec[QGQ], rcv, gdi);
-          double* arow = &s_A[rp * JS + (rs + 4 * k) * D];
+        const double* rec = &s_rec[prec[k] >> 1];
+        const double sg = (prec[k] & 1) ? -1.0 : 1.0;
+        const double f0 = rec[QF0], rcv = rec[rc], fc = rec[QF1] * rcv;
+        vi = fma(sg * f0, rcv, vi);
+        wk = fma(sg, rec[QPW + rc], wk);
+        gdi = fma(sg * rec[QGQ], rcv, gdi);
+        double* arow = &s_A[pdst[k]];
 #pragma unroll
-          for (int c = 0; c < D; c++) {
-            const double Bcc = fma(fc, rec[c], rc == c ? f0 : 0.0);
-            Ad[c] += Bcc;
-            if (!(pi & 2)) arow[c] = -Bcc;
-          }
+        for (int c = 0; c < D; c++) {
+          const double Bcc = fma(fc, rec[c], rc == c ? f0 : 0.0);
+          Ad[c] += Bcc;
+          arow[c] = -Bcc;
         }
       }
       vi = ff_quad_sum(vi); wk = ff_quad_sum(wk); gdi = ff_quad_sum(gdi);
@@ -466,19 +516,10 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         if (rs == 3) s_A[M * JS + rp] = -gdi;                                    // row M: (grad Delta)' = -g^T J
       }
       __syncthreads();
-      FF_STAMP(2);
-      // ---------------------------------------------------------------- the two products on the matrix cores, k-step by
-      // k-step side by side: S tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k] and J' tiles (I, w) = sum_k A[16 I + i][k] J[k][16 w + j]
-      // (the B operand of k-step ks = 4 K + v of J' is the lane's own Jin[ks]).  Column blocks beyond M are zero and skipped.
-      ff_d4 accS[T], accJ[T];
-#pragma unroll
-      for (int I = 0; I < T; I++) {
-        const ff_d4 zero = {0.0, 0.0, 0.0, 0.0};
-        accS[I] = zero; accJ[I] = zero;
-      }
+      FF_STAMP(3);
+      // ---------------------------------------------------------------- J' = A J on the matrix cores: tiles (I, w) =
+      // sum_k A[16 I + i][k] J[k][16 w + j]; the B operand of k-step ks = 4 K + v is the lane's own Jin[ks]
       {
-        const double* Jb = &s_J[(16 * w + lc) * JS + lg];
-        const double* Ja = &s_J[lc * JS + lg];
         const double* Aa = &s_A[lc * JS + lg];
 #pragma unroll
         for (int K = 0; K < T; K++) {
@@ -486,25 +527,15 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               const int ks = 4 * K + v;
-              const double bS = Jb[4 * ks], bJ = Jin[ks];
-              double aS[T], aJ[T];
+              double aJ[T];
 #pragma unroll
-              for (int I = 0; I < T; I++) { aS[I] = Ja[16 * I * JS + 4 * ks]; aJ[I] = Aa[16 * I * JS + 4 * ks]; }
+              for (int I = 0; I < T; I++) aJ[I] = Aa[16 * I * JS + 4 * ks];
 #pragma unroll
-              for (int I = 0; I < T; I++) { accS[I] = ff_mfma16(aS[I], bS, accS[I]); accJ[I] = ff_mfma16(aJ[I], bJ, accJ[I]); }
+              for (int I = 0; I < T; I++) accJ[I] = ff_mfma16(aJ[I], Jin[ks], accJ[I]);
             }
           }
         }
       }
-      FF_STAMP(3);
-      __syncthreads();      // every wave is done reading A ...
-#pragma unroll
-      for (int I = 0; I < T; I++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {   // ... which now holds S (only the M x M part: the padding of A must stay zero)
-          if (16 * I + 4 * v + lg < M && 16 * w + lc < M) s_A[(16 * I + 4 * v + lg) * JS + 16 * w + lc] = accS[I][v];
-        }
-      __syncthreads();
       FF_STAMP(4);
       // ---------------------------------------------------------------- R2: radius lanes contract their terms with S
       double qsum = 0.0;
@@ -526,8 +557,8 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
           double t = 0.0;
 #pragma unroll
           for (int c2i = 0; c2i < D; c2i++) {
-            double ww = s_A[(a * D + c) * JS + a * D + c2i];
-            if (pair) ww += s_A[(bb * D + c) * JS + bb * D + c2i] - s_A[(a * D + c) * JS + bb * D + c2i] - s_A[(a * D + c2i) * JS + bb * D + c];
+            double ww = s_J[(a * D + c) * JS + a * D + c2i];
+            if (pair) ww += s_J[(bb * D + c) * JS + bb * D + c2i] - s_J[(a * D + c) * JS + bb * D + c2i] - s_J[(a * D + c2i) * JS + bb * D + c];
             t = fma(ww, rho[c2i], t);
             if (c2i == c) tr += ww;
           }
@@ -547,10 +578,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       double out[NV];
       double qs = 0.0;
 #pragma unroll
-      for (int k = 0; k < NPK; k++) {
-        const int pi = pinfo[k];
-        if (pi & 1) qs = fma((pi & 4) ? -1.0 : 1.0, s_rec[(pi >> 3) + QPW + rc], qs);
-      }
+      for (int k = 0; k < NPK; k++) qs = fma((prec[k] & 1) ? -1.0 : 1.0, s_rec[(prec[k] >> 1) + QPW + rc], qs);
       qs = ff_quad_sum(qs);
 #pragma unroll
       for (int I = 0; I < T; I++)

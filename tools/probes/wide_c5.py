@@ -34,5 +34,5 @@ for it in range(iters):
           f"max steps={stats[1]} rejected={stats[2]} fail={stats[3]}", flush=True)
     if os.environ.get("FERMIFLOW_LIB", "").endswith("stamps.so"):
         st8 = model.profile["eloc_stats"][0][8:26].view(torch.int64)[:9].double()
-        names8 = ["publish", "R1", "own rows + A", "products", "S to LDS", "R2", "2nd-order sums", "consume"]
+        names8 = ["publish", "radii + S product", "heads + records", "S to LDS + row lanes", "J product", "R2", "2nd-order sums", "consume"]
         print("   ticks per evaluation: " + "  ".join(f"{nm} {v / stats[0]:.0f}" for nm, v in zip(names8, st8.tolist())) + f"   total {st8.sum().item() / stats[0]:.0f}")
