@@ -12,11 +12,18 @@ i.e. 100 Metropolis walker-steps per walker + CNF.generate + local energy + E/E_
 estimator all-reduces of fermiflow_amd/dist.py).  value = n_gpus * walkers * 100 * K / time.
   --workload beta   BASELINE.json configs[2]: BetaFermionHO2D beta = 10, nup = 3, boltzmann, 65 536 walkers
   --workload n12    BASELINE.json configs[3]: nup = ndown = 6, 32 768 walkers per GPU
+  --workload c5     BASELINE.json configs[4]: nup = ndown = 10 in a 3-D trap, 131 072 walkers per GPU (fp64; matrix-core kernel)
 (parity-test cases; their lines are kept under profiles/, the driver's line is the default workload).
+  --scaling strong  the global batch stays at --walkers-per-gpu (default 65 536) however many GPUs share it
+                    (BASELINE.json words its metric "65536 walkers, 1/2/4/8 GPUs"); default: weak, that many walkers PER GPU.
+A second, shorter timed leg (`trained_leg`) repeats the measurement after --trained-iters untimed training iterations at
+lr 1e-4: as the flow strengthens the ODE solves take more steps (tools/probes/long_run.py), so the headline -- synthetic
+weights held in place by a tiny learning rate -- is the best case; both numbers are on the line.
 
 Extra objects on the JSON line (rank 0, N = 1): `roofline` for the dominant kernel (the fused local-energy
-integration) with its live HIP-event time, its algorithmic flops and -- from two rocprofv3 --pmc child
-passes of this very script -- its HBM traffic; `roofline_adjoint`, `roofline_mcmc` for the other two kernels above
+integration) with its live HIP-event time, its algorithmic flops and -- from four rocprofv3 --pmc child
+passes of this very script -- its HBM traffic, VALU-active / waiting shares of the wave-cycles, LDS bank-conflict share and
+matrix-core operation count; `roofline_adjoint`, `roofline_mcmc` for the other two kernels above
 10 % of a step; `roofline_hbm` (parity-mode Metropolis sweep: the HBM-bound kernel of the path), `roofline_pairwise`
 (stand-alone potential / backflow kernels); `stages_ms`; `cpu_baseline` (the C oracle on the host cores, bounded sample).
 """
@@ -65,9 +72,11 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def eloc_kernel_name(n):
-    """The local-energy kernel the dispatcher picks (csrc/ff_cnf_fwd.hip, dispatch_fwd)."""
+def eloc_kernel_name(n, d=2):
+    """The local-energy kernel the dispatcher picks (csrc/ff_cnf_fwd.hip, dispatch_fwd; csrc/ff_wide.hip beyond 12 / 4 particles)."""
     kind = os.environ.get("FF_ELOC_KERNEL", "auto")
+    if os.environ.get("FF_WIDE") == "1" or (d == 2 and n > 12) or (d == 3 and n > 4):
+        return "wide", f"ff_wide_eloc_kernel<{d}, {(n * d + 4 + 15) // 16}, true>"
     if kind == "mfma" and n <= 6:
         return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 1>"
     split = {7: 2, 8: 2, 9: 3, 10: 3, 11: 2, 12: 2}.get(n, 1)
@@ -78,8 +87,8 @@ def eloc_kernel_name(n):
     return "columns", f"ff_ode_fwd_kernel<{n}, 2, 2, true>"
 
 
-def eloc_flop_per_eval(kind, n, H, radial):
-    M, P = 2 * n, n * (n - 1) // 2
+def eloc_flop_per_eval(kind, n, H, radial, d=2):
+    M, P = d * n, n * (n - 1) // 2
     R = P + n
     heads = H * FLOP_PER_SIGMOID_UNIT if radial == "exact" else FLOP_PER_TABLE_RADIUS
     if kind == "columns":
@@ -88,10 +97,14 @@ def eloc_flop_per_eval(kind, n, H, radial):
     return 2 * 2 * M * M * M + R * (heads + FLOP_PER_RADIUS_RECORD + FLOP_PER_RADIUS_S) + M * FLOP_PER_LANE_GATHER
 
 
-def pmc_traffic(kernel_substr, argv):
-    """HBM bytes per launch of one kernel from two `rocprofv3 --pmc` child passes (FETCH_SIZE and WRITE_SIZE do not fit
-    one pass; FETCH_SIZE is doubled on gfx950 -- MI355X_MICROARCH.md, HBM).  The profiled program is this script with
-    --steps 2 --no-extras.  Returns (bytes, detail) or (None, reason)."""
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_INSTS_VALU"),
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES"))
+
+
+def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
+    """Per-launch averages of hardware counters of one kernel, from `rocprofv3 --pmc` child passes of this script (counters
+    in their own runs, no tracing; --steps 2 --no-extras).  Returns (dict counter -> value per launch, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -101,27 +114,31 @@ def pmc_traffic(kernel_substr, argv):
     if exe is None:
         return None, "rocprofv3 not found"
     out = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for ctrs in passes:
         d = tempfile.mkdtemp(prefix="ffpmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
-        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + \
+        cmd = [exe, "--pmc"] + list(ctrs) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + \
               ["--steps", "2", "--warmup", "1", "--no-extras"]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
         except Exception as e:      # noqa: BLE001
             shutil.rmtree(d, ignore_errors=True)
-            return None, f"rocprofv3 pass failed: {type(e).__name__}"
-        tot, cnt = 0.0, 0
+            if ctrs[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                return None, f"rocprofv3 pass {ctrs} failed: {type(e).__name__}"
+            continue
+        tot, cnt = {c: 0.0 for c in ctrs}, {c: 0 for c in ctrs}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
-                    tot += float(row["Counter_Value"]); cnt += 1
+                c = row["Counter_Name"]
+                if kernel_substr in row["Kernel_Name"] and c in tot:
+                    tot[c] += float(row["Counter_Value"]); cnt[c] += 1
         shutil.rmtree(d, ignore_errors=True)
-        if cnt == 0:
-            return None, f"kernel {kernel_substr} not in the {ctr} pass"
-        out[ctr] = tot / cnt
-    nbytes = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
-    return nbytes, {"FETCH_SIZE_KB": out["FETCH_SIZE"], "WRITE_SIZE_KB": out["WRITE_SIZE"]}
+        for c in ctrs:
+            if cnt[c]:
+                out[c] = tot[c] / cnt[c]
+        if ctrs[0] in ("FETCH_SIZE", "WRITE_SIZE") and ctrs[0] not in out:
+            return None, f"kernel {kernel_substr} not in the {ctrs[0]} pass"
+    return out, None
 
 
 def main():
@@ -129,8 +146,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["gsvmc", "beta", "n12"], default="gsvmc")
-    ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12)")
+    ap.add_argument("--workload", choices=["gsvmc", "beta", "n12", "c5"], default="gsvmc")
+    ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12), 131072 (c5)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --walkers-per-gpu walkers on EVERY GPU; strong: that many walkers in total, split over the GPUs")
+    ap.add_argument("--trained-iters", type=int, default=300,
+                    help="untimed training iterations at lr 1e-4 in front of the second timed leg (0 = no second leg)")
     ap.add_argument("--nup", type=int, default=0)
     ap.add_argument("--ndown", type=int, default=-1)
     ap.add_argument("--Z", type=float, default=2.0)
@@ -139,7 +160,7 @@ def main():
                          "(the reference's 1e-2 from these weights changes eta by 250 %% per step; --lr 1e-2 runs it)")
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone kernel legs, the PMC passes and the CPU baseline")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -181,12 +202,15 @@ def main():
     torch.cuda.set_device(dev)
 
     wl = args.workload
-    nup = args.nup or {"gsvmc": 3, "beta": 3, "n12": 6}[wl]
-    ndown = args.ndown if args.ndown >= 0 else {"gsvmc": 3, "beta": 0, "n12": 6}[wl]
-    wpg = args.walkers_per_gpu or {"gsvmc": 65536, "beta": 65536, "n12": 32768}[wl]
+    nup = args.nup or {"gsvmc": 3, "beta": 3, "n12": 6, "c5": 10}[wl]
+    ndown = args.ndown if args.ndown >= 0 else {"gsvmc": 3, "beta": 0, "n12": 6, "c5": 10}[wl]
+    wpg = args.walkers_per_gpu or {"gsvmc": 65536, "beta": 65536, "n12": 32768, "c5": 131072}[wl]
     n = nup + ndown
-    gs = G._model(dev, nup, ndown, args.Z)
-    if wl == "beta":
+    dim = 3 if wl == "c5" else 2
+    gs = G._model(dev, nup, ndown, args.Z) if dim == 2 else G._model(dev, 2, 2, args.Z)
+    if wl == "c5":      # the 3-D trap: HO3D orbitals (closed shells 0..2), same flow network
+        model = ff.GSVMC(nup, ndown, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(args.Z), sp_potential=ff.HO())
+    elif wl == "beta":
         model = ff.BetaVMC(10.0, nup, ndown, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), gs.cnf,
                            ff.CoulombPairPotential(args.Z), sp_potential=ff.HO())
         model.to(dev)
@@ -194,7 +218,10 @@ def main():
         model = gs
     from fermiflow_amd.utils import make_adam
     opt = make_adam(model.parameters(), lr=args.lr)
-    B_glob = wpg * n_gpus
+    if args.scaling == "strong":      # fixed global batch: every rank takes 1 / n_gpus of it
+        B_glob, wpg = wpg, -(-wpg // n_gpus)
+    else:
+        B_glob = wpg * n_gpus
     torch.manual_seed(1234)      # same Philox key on every rank; streams are separated by the global walker index
 
     def step():
@@ -225,6 +252,42 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     prof, model.profile = model.profile, None
+    E_head, Estd_head = model.E, model.E_std
+    _v = gs.cnf.v_wrapper.v      # the headline's weights, for the CPU baseline (the second leg trains them)
+    w_head = (tuple(t.detach().cpu().numpy().copy() for t in (_v.eta.fc1.weight, _v.eta.fc1.bias, _v.eta.fc2.weight)),
+              tuple(t.detach().cpu().numpy().copy() for t in (_v.mu.fc1.weight, _v.mu.fc1.bias, _v.mu.fc2.weight)))
+    beta_head = (model.F, model.F_std, model.S) if wl == "beta" else None
+
+    # ---- second leg: the same measurement on a flow that has been trained for a while (the headline's weights are held in
+    #      place by the tiny learning rate: its ODE step counts are the best case)
+    trained = None
+    n_tr = args.trained_iters if wl != "c5" else 0
+    if n_tr > 0 and not args.no_extras:
+        for g in opt.param_groups:
+            g["lr"] = 1e-4
+        for _ in range(n_tr):
+            step()
+        for g in opt.param_groups:
+            g["lr"] = args.lr
+        k2 = max(2, args.steps // 2)
+        step()
+        model.profile = {}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        fence()
+        dt2 = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = tt.item()
+        p2, model.profile = model.profile, None
+        ev2 = sum(int(st_[0].item()) for st_ in p2["eloc_stats"]) / k2
+        trained = {"after": f"{n_tr} training iterations at Adam lr=1e-4 from the headline's weights (untimed), then lr={args.lr}",
+                   "steps": k2, "ms_per_step": dt2 / k2 * 1e3, "value": B_glob * 100 * k2 / dt2,
+                   "rhs_evals_per_walker": ev2 / wpg, "eloc_kernel_ms": sum(a.elapsed_time(b) for a, b in p2["pass1"]) / k2,
+                   "E": model.E, "E_std": model.E_std}
 
     # ---- per-stage times and the dominant kernel's roofline (HIP events recorded on the launch stream)
     names = ["mcmc", "generate", "eloc", "estimator", "adjoint"]
@@ -236,14 +299,15 @@ def main():
     stages = {k: v / args.steps for k, v in stages.items()}
     k_ms = sum(a.elapsed_time(b) for a, b in prof["pass1"]) / args.steps
     evals = sum(int(s[0].item()) for s in prof["eloc_stats"]) / args.steps          # RHS evaluations summed over walkers
-    M, R, H = 2 * n, n * (n - 1) // 2 + n, 50
+    M, R, H = dim * n, n * (n - 1) // 2 + n, 50
     radial = L.RADIAL_MODE
-    kind, kname = eloc_kernel_name(n)
-    flop_per_eval = eloc_flop_per_eval(kind, n, H, radial)
+    kind, kname = eloc_kernel_name(n, dim)
+    flop_per_eval = eloc_flop_per_eval(kind, n, H, radial, dim)
     achieved = evals * flop_per_eval / (k_ms * 1e-3) / 1e12
     roofline = {"kernel": kname + " (local-energy sensitivities)",
-                "bound": "mfma" if kind == "mfma" else "fp64-valu",
-                "note": ("runs on v_mfma_f64_4x4x4 + fp64 VALU" if kind == "mfma" else
+                "bound": "mfma" if kind in ("mfma", "wide") else "fp64-valu",
+                "note": ("one walker per workgroup; J' = A J and S = J J^T on v_mfma_f64_16x16x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
+                         if kind == "wide" else "runs on v_mfma_f64_4x4x4 + fp64 VALU" if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
                         "; peak = MI355X fp64 vector = fp64 matrix peak",
@@ -254,15 +318,20 @@ def main():
 
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",
            "value": B_glob * 100 * args.steps / dt, "unit": "walker-steps/s", "n_gpus": n_gpus, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": ("BetaVMC beta=10 boltzmann deltaE=2 " if wl == "beta" else "GSVMC ") +
-                                  f"nup={nup} ndown={ndown} 2D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8, "
+                                  f"nup={nup} ndown={ndown} {dim}D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8 "
+                                  f"(sensitivity components of walkers with flow cost class <= {model.sens_tol_class}: x{model.sens_tol:g}; "
+                                  f"step-size warm start {'on' if model.warm_start else 'off'}; "
+                                  f"walker prefetch {'on' if getattr(model, 'prefetch_walkers', False) else 'off'}), "
                                   f"{wpg} walkers/GPU, 100 Metropolis steps/iter, seeded gaussian weights x(30,300), Adam lr={args.lr}",
                       "global_walkers": B_glob, "parallelism": f"walker-dp{n_gpus}"},
-           "E": model.E, "E_std": model.E_std, "stages_ms": stages, "roofline": roofline}
+           "E": E_head, "E_std": Estd_head, "stages_ms": stages, "roofline": roofline}
+    if trained is not None:
+        out["trained_leg"] = trained
     if wl == "beta":
-        out.update(F=model.F, F_std=model.F_std, S=model.S)
+        out.update(F=beta_head[0], F_std=beta_head[1], S=beta_head[2])
 
     if rank == 0 and n_gpus == 1 and not args.no_extras:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -277,38 +346,39 @@ def main():
         net = v.net()
         tu, td = (model._state_tables(dev) if wl == "beta" else model._tables(dev))
         ws = model._ws if wl == "beta" else None
-        # ---- the adjoint and the production Metropolis kernel stand-alone, on the last sweep's walkers
-        with torch.no_grad():
-            z0 = native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws)[0]
-            ms_mc = timed(lambda: native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws))
-            hg = torch.empty(wpg, dtype=torch.float64, device=dev); he = torch.empty_like(hg)
-            x = native.cnf_generate(net, z0, 0.0, 1.0, 1e-6, 1e-8, walker_h_out=hg)
-            r = native.eloc(tu, td, nup, ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, args.Z, True, walker_state=ws,
-                            walker_h_init=hg, walker_h_scale=model._h_scale_eloc, walker_h_out=he)
-            w = (r["eloc"] - r["eloc"].mean()) / wpg
-            az, ad = w[:, None, None] * r["glogp0"], -w
-            st = native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False, want_stats=True,
-                                    walker_h_init=he, walker_h_scale=1.25)[2]
-            adj_evals = int(st[0].item())
-            ms_adj = timed(lambda: native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False,
-                                                      walker_h_init=he, walker_h_scale=1.25))
-        flop_adj = R * FLOP_ADJ_RADIUS + M * FLOP_ADJ_LANE
-        a_adj = adj_evals * flop_adj / (ms_adj * 1e-3) / 1e12
-        out["roofline_adjoint"] = {
-            "kernel": f"ff_ode_adjtab_kernel<{n}, 2> + deposit reduce/contract (theta-gradient adjoint, whole ff_cnf_adjoint call)",
-            "bound": "fp64-valu", "achieved": a_adj, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_adj / PEAK_FP64_TFLOPS,
-            "avg_launch_ms": ms_adj, "rhs_evals_per_walker": adj_evals / wpg, "flop_per_walker_eval": flop_adj,
-            "note": "instruction-issue and LDS-atomic bound: per accepted step 5 records per radius go into the deposit table"}
-        flop_mc = n * FLOP_MCMC_STEP_PER_PARTICLE
-        a_mc = wpg * 100 * flop_mc / (ms_mc * 1e-3) / 1e12
-        out["roofline_mcmc"] = {
-            "kernel": (f"ff_mcmc_spin_kernel<{nup}, false>" if nup == ndown and 1 <= nup <= 6 and wl != "beta" else f"ff_mcmc_kernel<{nup}, {ndown}, false>") +
-                      " (Philox + Box-Muller on chip, the production sampler)",
-            "bound": "fp64-valu", "achieved": a_mc, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_mc / PEAK_FP64_TFLOPS,
-            "avg_launch_ms": ms_mc, "walker_steps_per_s": wpg * 100 / (ms_mc * 1e-3), "flop_per_walker_step": flop_mc,
-            "hbm_bytes_per_walker": 2 * (8 * M + 8),
-            "note": "instruction-issue bound (integer Philox rounds, log / sincos of Box-Muller, serial LU chain); HBM sees 208 B per "
-                    "walker per SWEEP, i.e. nothing"}
+        if dim == 2:      # (the 3-D sampler is another entry point; config 5 reports its stages in stages_ms)
+            # ---- the adjoint and the production Metropolis kernel stand-alone, on the last sweep's walkers
+            with torch.no_grad():
+                z0 = native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws)[0]
+                ms_mc = timed(lambda: native.mcmc_sample(tu, td, nup, ndown, wpg, 100, 0.1, 77, dev, walker_state=ws))
+                hg = torch.empty(wpg, dtype=torch.float64, device=dev); he = torch.empty_like(hg)
+                x = native.cnf_generate(net, z0, 0.0, 1.0, 1e-6, 1e-8, walker_h_out=hg)
+                r = native.eloc(tu, td, nup, ndown, net, x, 0.0, 1.0, 1e-6, 1e-8, args.Z, True, walker_state=ws,
+                                walker_h_init=hg, walker_h_scale=model._h_scale_eloc, walker_h_out=he)
+                w = (r["eloc"] - r["eloc"].mean()) / wpg
+                az, ad = w[:, None, None] * r["glogp0"], -w
+                st = native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False, want_stats=True,
+                                        walker_h_init=he, walker_h_scale=1.25)[2]
+                adj_evals = int(st[0].item())
+                ms_adj = timed(lambda: native.cnf_adjoint(net, r["z"], az, ad, 0.0, 1.0, 1e-6, 1e-8, need_gx=False,
+                                                          walker_h_init=he, walker_h_scale=1.25))
+            flop_adj = R * FLOP_ADJ_RADIUS + M * FLOP_ADJ_LANE
+            a_adj = adj_evals * flop_adj / (ms_adj * 1e-3) / 1e12
+            out["roofline_adjoint"] = {
+                "kernel": f"ff_ode_adjtab_kernel<{n}, 2> + deposit reduce/contract (theta-gradient adjoint, whole ff_cnf_adjoint call)",
+                "bound": "fp64-valu", "achieved": a_adj, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_adj / PEAK_FP64_TFLOPS,
+                "avg_launch_ms": ms_adj, "rhs_evals_per_walker": adj_evals / wpg, "flop_per_walker_eval": flop_adj,
+                "note": "instruction-issue and LDS-atomic bound: per accepted step 5 records per radius go into the deposit table"}
+            flop_mc = n * FLOP_MCMC_STEP_PER_PARTICLE
+            a_mc = wpg * 100 * flop_mc / (ms_mc * 1e-3) / 1e12
+            out["roofline_mcmc"] = {
+                "kernel": (f"ff_mcmc_spin_kernel<{nup}, false>" if nup == ndown and 1 <= nup <= 6 and wl != "beta" else f"ff_mcmc_kernel<{nup}, {ndown}, false>") +
+                          " (Philox + Box-Muller on chip, the production sampler)",
+                "bound": "fp64-valu", "achieved": a_mc, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_mc / PEAK_FP64_TFLOPS,
+                "avg_launch_ms": ms_mc, "walker_steps_per_s": wpg * 100 / (ms_mc * 1e-3), "flop_per_walker_step": flop_mc,
+                "hbm_bytes_per_walker": 2 * (8 * M + 8),
+                "note": "instruction-issue bound (integer Philox rounds, log / sincos of Box-Muller, serial LU chain); HBM sees 208 B per "
+                        "walker per SWEEP, i.e. nothing"}
         if wl == "gsvmc":
             # ---- the HBM-bound kernel of the path: parity-mode Metropolis sweep (noise streamed from HBM)
             S = 100
@@ -339,19 +409,32 @@ def main():
                              "unit": "TFLOP/s", "frac": flop_b / (ms_b * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                              "note": "fp64 VALU (exp/rcp chains); no MFMA: 1->H->1 layers"}}
             del xp
-        # ---- HBM traffic of the dominant kernel, measured now: two rocprofv3 --pmc child passes of this script
+        # ---- counters of the dominant kernel, measured now: rocprofv3 --pmc child passes of this script (HBM bytes = 2 x FETCH_SIZE
+        #      + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; then the issue / wait / LDS / matrix-core counters)
         if not args.no_pmc and os.environ.get("FF_BENCH_CHILD") != "1":
             os.environ["FF_BENCH_CHILD"] = "1"
-            argv = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--lr", str(args.lr)]
-            nb, detail = pmc_traffic(kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0], argv)
-            roofline["traffic"] = nb
-            roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run, bytes per launch = "
-                                          "2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), " + json.dumps(detail)) if nb else f"unavailable: {detail}"
+            argv = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--lr", str(args.lr), "--nup", str(nup),
+                    "--ndown", str(ndown)]
+            ctr, why = pmc_counters(kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0], argv)
+            if ctr is None:
+                roofline["traffic_source"] = f"unavailable: {why}"
+            else:
+                roofline["traffic"] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
+                roofline["traffic_source"] = ("rocprofv3 --pmc child passes of this run (counters per launch): bytes = 2 x FETCH_SIZE + WRITE_SIZE "
+                                              "(KB; gfx950 correction)")
+                roofline["pmc_per_launch"] = ctr
+                wc = ctr.get("SQ_WAVE_CYCLES")
+                if wc:
+                    roofline["valu_active"] = ctr.get("SQ_ACTIVE_INST_VALU", 0.0) / wc      # share of the wave-cycles a VALU instruction is executing
+                    roofline["wait_any"] = ctr.get("SQ_WAIT_ANY", 0.0) / wc
+                if ctr.get("SQ_LDS_IDX_ACTIVE"):
+                    roofline["lds_bank_conflict"] = ctr.get("SQ_LDS_BANK_CONFLICT", 0.0) / ctr["SQ_LDS_IDX_ACTIVE"]
+                if "SQ_INSTS_VALU_MFMA_MOPS_F64" in ctr:
+                    roofline["mfma_mops_f64"] = ctr["SQ_INSTS_VALU_MFMA_MOPS_F64"]
         # ---- CPU baseline: the oracle's full sweep on the host cores, bounded sample
-        if args.cpu_walkers > 0 and wl != "beta":
+        if args.cpu_walkers > 0 and wl not in ("beta", "c5"):
             from oracle import oracle as O
-            onet = O.Net(tuple(t.detach().cpu().numpy() for t in (v.eta.fc1.weight, v.eta.fc1.bias, v.eta.fc2.weight)),
-                         tuple(t.detach().cpu().numpy() for t in (v.mu.fc1.weight, v.mu.fc1.bias, v.mu.fc2.weight)))
+            onet = O.Net(*w_head)
             ncpu = args.cpu_walkers if wl == "gsvmc" else max(256, args.cpu_walkers // 8)
             O.gsvmc_sweep(64, nup, ndown, onet, args.Z, seed=1)      # thread-pool warm-up
             t1 = time.perf_counter()

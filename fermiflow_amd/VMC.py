@@ -143,17 +143,45 @@ class _Sweep:
             zn, done = self._z_next[0], self._z_next[1]
             if done is not None:
                 done.synchronize()
+            # they are THIS rank's shard: stamped with (rank, world, walker offset) so that no other rank mistakes them for its own
+            rank, ws = D.world()
             st["z_next"] = zn
+            st["z_next_shard"] = (int(rank), int(ws), int(getattr(self.basedist, "walker_offset", 0)))
+            if len(self._z_next) > 4 and self._z_next[4] is not None:
+                st["z_next_seed"] = int(self._z_next[4])      # the Philox key they were drawn with
         return st
 
     def set_extra_state(self, st):
+        st = st or {}      # (an absent _extra_state -- a plain parameter state_dict -- is a cold sweep state)
         self._h_flow = st.get("h_flow")
         self._dev = dict(st.get("dev", {}))
         self._n_global = st.get("n_global", 0)
         if "z_prev" in st:
             self._z_prev = st["z_prev"]
-        if "z_next" in st and hasattr(self, "_z_next"):
-            self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), None)      # (the checkpoint restores the generator too)
+        if hasattr(self, "_z_next"):
+            self._z_next = None
+            if "z_next" in st:
+                # The drivers write ONE checkpoint (rank 0's) and every rank loads it: only the rank the prefetched walkers belong
+                # to takes them; the others sample afresh from the restored seed -- which is what they would have drawn anyway
+                # (the Philox key comes from the restored CPU generator, the counters from the global walker index).
+                rank, ws = D.world()
+                shard = tuple(st.get("z_next_shard", (0, 1, 0)))
+                if shard[0] == rank and shard[1] == ws:
+                    self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), None, st.get("z_next_seed"))
+                else:
+                    self._resume_seed = st.get("z_next_seed")      # this rank re-draws ITS shard with the same key (forward())
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a state_dict without "_extra_state" (weights trained with the reference, an earlier checkpoint, another model's
+        # parameters) loads as a cold sweep state instead of failing strict loading
+        key = prefix + "_extra_state"
+        if key not in state_dict:
+            state_dict[key] = {}
+            try:
+                return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+            finally:
+                del state_dict[key]
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
 class GSVMC(_Sweep, torch.nn.Module):
@@ -229,6 +257,10 @@ class GSVMC(_Sweep, torch.nn.Module):
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
                                          equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
+            elif self._z_next is None and getattr(self, "_resume_seed", None) is not None and not self.persistent_walkers:
+                # resumed on a rank other than the one whose prefetched walkers the checkpoint holds: the same Philox key and this
+                # rank's walker offset give exactly the walkers the uninterrupted run prefetched here (the CPU generator is not touched)
+                z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=self._resume_seed)
             elif self._prefetched_ok(nloc):
                 z, done = self._z_next[0], self._z_next[1]          # sampled beside the previous iteration's adjoint
                 if done is not None:
@@ -237,6 +269,7 @@ class GSVMC(_Sweep, torch.nn.Module):
             else:
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
             self._z_next = None
+            self._resume_seed = None
             self._z_prev = z if self.persistent_walkers else None
         self._mark(ev, "mcmc")
         return self._sweep(z, batch, ev, prefetch=nloc if (self.prefetch_walkers and not self.persistent_walkers and z.is_cuda) else 0)
@@ -259,10 +292,12 @@ class GSVMC(_Sweep, torch.nn.Module):
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
             native.stream_delay(40.0)
-            z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
+            from .base_dist import _draw_seed
+            seed = _draw_seed()
+            z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
             done = torch.cuda.Event()
             done.record()
-        self._z_next = (z, done, nloc, torch.get_rng_state())
+        self._z_next = (z, done, nloc, torch.get_rng_state(), seed)
 
     def forward_from(self, z, batch=None):
         """forward() on GIVEN base walkers z (nloc, n, 2) -- this rank's shard of a global batch of `batch` walkers

@@ -41,9 +41,11 @@ class FreeFermion(BaseDist):
         td = native.orbital_table(orbital_indices(orbitals_down), self.device) if len(orbitals_down) else None
         return tu, td
 
-    def sample(self, orbitals_up, orbitals_down, sample_shape, equilibrim_steps=100, tau=0.1, x_init=None):
+    def sample(self, orbitals_up, orbitals_down, sample_shape, equilibrim_steps=100, tau=0.1, x_init=None, seed=None):
         """100-step Metropolis chain from N(0,1) walkers, fused in one kernel (src/base_dist.py:58-71).
-        x_init (not in the reference): continue the chain of these walkers instead of starting from N(0,1)."""
+        x_init (not in the reference): continue the chain of these walkers instead of starting from N(0,1).
+        seed (not in the reference): the Philox key; default: drawn from torch's CPU generator."""
+        _seed = (lambda: seed) if seed is not None else _draw_seed
         nup, ndown = len(orbitals_up), len(orbitals_down)
         B = 1
         for s in sample_shape:
@@ -52,14 +54,14 @@ class FreeFermion(BaseDist):
         if orbital_dim(tuple(orbitals_up) + tuple(orbitals_down)) == 3:      # HO3D walkers (B, n, 3)
             if x_init is not None:
                 raise NotImplementedError("persistent walkers in three dimensions")
-            x, _, _ = native.mcmc_sample3d(tu, td, nup, ndown, B, equilibrim_steps, tau, _draw_seed(), self.device,
+            x, _, _ = native.mcmc_sample3d(tu, td, nup, ndown, B, equilibrim_steps, tau, _seed(), self.device,
                                            walker_offset=self.walker_offset)
             return x.reshape(*sample_shape, nup + ndown, 3)
         if x_init is not None:
             x, _, _ = native.mcmc_continue(tu, td, nup, ndown, x_init.reshape(B, nup + ndown, 2), equilibrim_steps, tau,
-                                           _draw_seed(), walker_offset=self.walker_offset)
+                                           _seed(), walker_offset=self.walker_offset)
         else:
-            x, _, _ = native.mcmc_sample(tu, td, nup, ndown, B, equilibrim_steps, tau, _draw_seed(), self.device,
+            x, _, _ = native.mcmc_sample(tu, td, nup, ndown, B, equilibrim_steps, tau, _seed(), self.device,
                                          walker_offset=self.walker_offset)
         return x.reshape(*sample_shape, nup + ndown, 2)
 

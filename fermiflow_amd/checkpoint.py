@@ -20,7 +20,7 @@ def save(path, model, optimizer, it, device=None):
 
 def load(path, model, optimizer, device=None):
     """Restores model / optimizer / RNG state in place; returns the iteration the checkpoint was written after."""
-    ck = torch.load(path, map_location=device, weights_only=False)
+    ck = torch.load(path, map_location=device, weights_only=True)      # tensors, dicts, ints only: nothing to unpickle
     model.load_state_dict(ck["model"])
     optimizer.load_state_dict(ck["optimizer"])
     if "rng_cpu" in ck:

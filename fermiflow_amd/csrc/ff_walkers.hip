@@ -645,6 +645,11 @@ ff_backflow_kernel(int64_t B, int n, int d, ff_net net, const double* __restrict
   if (div) div[b] = dv;
 }
 
+// The reduction shift is a numerical convenience (sums about the previous sweep's mean have no cancellation): a non-finite
+// one -- a failed integration yields NaN local energies by design, hence a NaN mean -- counts as 0, so that one bad sweep
+// cannot poison every later one (every kernel that reads a shift goes through here).
+FF_D double ff_finite_shift(double c) { return (c - c == 0.0) ? c : 0.0; }
+
 // ---------------------------------------------------------------------------------------------------
 // out[0] = sum (e - shift), out[1] = sum (e - shift)^2; one workgroup, fixed summation tree (deterministic for a given
 // block size); four independent accumulator pairs per thread keep several loads in flight
@@ -652,7 +657,7 @@ __global__ void __launch_bounds__(1024)
 ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, const double* __restrict__ shift_dev,
                   double shift_dev_scale, double* __restrict__ out) {
   __shared__ double s1[1024], s2[1024];
-  const double shift = shift_dev ? shift_dev[0] * shift_dev_scale : shift_host;
+  const double shift = ff_finite_shift(shift_dev ? shift_dev[0] * shift_dev_scale : shift_host);
   const int nt = blockDim.x, t = threadIdx.x;
   double a[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
   int64_t i = t;
@@ -690,7 +695,7 @@ __global__ void __launch_bounds__(1024)
 ff_energy_sums_kernel(int64_t B, const double* __restrict__ e, const double* __restrict__ logp, const double* __restrict__ shift_dev,
                       double* __restrict__ out) {
   __shared__ double sm[4][1024];
-  const double shift = shift_dev[0];
+  const double shift = ff_finite_shift(shift_dev[0]);
   const int nt = blockDim.x, t = threadIdx.x;
   double a[2] = {0.0, 0.0}, q[2] = {0.0, 0.0}, l[2] = {0.0, 0.0}, m[2] = {0.0, 0.0};
   int64_t i = t;
@@ -721,7 +726,7 @@ __global__ void ff_energy_finish_kernel(const double* __restrict__ sums, const d
                                         double* __restrict__ est) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double d = sums[0] / n;                 // E - c
-  est[0] = shift_dev[0] + d;
+  est[0] = ff_finite_shift(shift_dev[0]) + d;
   est[1] = sums[1] - sums[0] * d;
   est[2] = (sums[3] - d * sums[2]) / n;
 }
@@ -843,7 +848,7 @@ ff_beta_finish_kernel(const double* __restrict__ buf, const double* __restrict__
     sF += se + cnt * c; sCE += c * se; sCC += cnt * c * c; sS += cnt * lp; sSa += lp * exp(lp);
   }
   sF = block_sum(sF); sCE = block_sum(sCE); sCC = block_sum(sCC); sS = block_sum(sS); sSa = block_sum(sSa);
-  const double c0 = shift_dev[0], d = buf[0] / n;            // E - c
+  const double c0 = ff_finite_shift(shift_dev[0]), d = buf[0] / n;            // E - c
   const double E = c0 + d, Ess = buf[1] - buf[0] * d, F = sF / n;
   // sum f^2 = sum e^2 + 2 sum_s c_s sum_e(s) + sum_s cnt_s c_s^2,  sum e^2 = sum (e - c)^2 + 2 c sum (e - c) + n c^2
   const double se2 = buf[1] + 2.0 * c0 * buf[0] + n * c0 * c0;

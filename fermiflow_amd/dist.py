@@ -1,9 +1,10 @@
 """Data parallelism over walkers: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
-Walkers are independent in the MCMC, the flow and the local energy; ranks couple only through
-  phase A: [sum E_loc, count]            -> E           (src/VMC.py:57, mean)
-  phase B: [sum (E_loc - E)^2]           -> E_std       (src/VMC.py:57, unbiased std)
-  phase C: [sum_b w_b logp_b] + the 3(He+Hm)-double parameter gradient (src/VMC.py:58, FermionHO2D.py:71)
+Walkers are independent in the MCMC, the flow and the local energy; ranks couple only through two all-reduces per sweep
+  GSVMC:   [sum (e - c), sum (e - c)^2, sum logp, sum logp (e - c)]   (ff_reduce_energy -> here -> ff_energy_finish: E, E_std, surrogate;
+           c = the previous sweep's E, src/VMC.py:56-59), then the 3(He+Hm)-double parameter gradient (src/FermionHO2D.py:71)
+  BetaVMC: [moments of E_loc | partial per-state sums]                 (ff_beta_state_partials -> here -> ff_beta_finish,
+           src/VMC.py:146-171), then the parameter gradient
 all a few hundred bytes to 2.4 KB, i.e. latency-bound: one fused buffer per phase, no bucketing.
 The functions work on any device so the same code runs under gloo on CPU in the tests.
 """
@@ -76,41 +77,3 @@ def shard(batch, rank=None, world_size=None):
     count = base + (1 if rank < rem else 0)
     offset = rank * base + min(rank, rem)
     return offset, count
-
-
-def global_mean_ss_dev(sum_e, n_global, centered_sumsq_fn):
-    """As global_mean_std_dev, but returns (mean, centred sum of squares) -- the caller forms the std when it is read."""
-    buf = sum_e.reshape(1).clone()
-    all_reduce_sum_(buf)
-    mean = buf[0] / n_global
-    ss = centered_sumsq_fn(buf, 1.0 / n_global).reshape(1)
-    all_reduce_sum_(ss)
-    return mean, ss[0]
-
-
-def global_mean_std_dev(sum_e, n_global, centered_sumsq_fn):
-    """Mean and unbiased std over all ranks as 0-dim DEVICE tensors, without a host synchronisation.
-    sum_e: 0-dim tensor, the local sum; n_global: the global number of samples (known on the host: the shards are a
-    fixed split of the batch); centered_sumsq_fn(sum_tensor, scale) -> 0-dim tensor with the local
-    sum of (e - sum_tensor*scale)^2."""
-    buf = sum_e.reshape(1).clone()
-    all_reduce_sum_(buf)
-    mean = buf[0] / n_global
-    ss = centered_sumsq_fn(buf, 1.0 / n_global).reshape(1).clone()
-    all_reduce_sum_(ss)
-    std = (ss[0] / (n_global - 1)).sqrt() if n_global > 1 else torch.full_like(mean, float("nan"))
-    return mean, std
-
-
-def global_mean_std(sum_e, count, centered_sumsq_fn):
-    """Two-phase mean / unbiased std over all ranks.
-    sum_e: 0-dim tensor with the local sum; count: local number of walkers;
-    centered_sumsq_fn(mean) -> 0-dim tensor with the local sum of (e - mean)^2."""
-    buf = torch.stack([sum_e, torch.as_tensor(float(count), dtype=sum_e.dtype, device=sum_e.device)])
-    all_reduce_sum_(buf)
-    n = buf[1].item()
-    mean = (buf[0] / buf[1]).item()
-    ss = centered_sumsq_fn(mean).reshape(1).clone()
-    all_reduce_sum_(ss)
-    std = (ss[0] / (n - 1)).sqrt().item() if n > 1 else float("nan")
-    return mean, std, int(round(n))

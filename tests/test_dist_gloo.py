@@ -1,5 +1,8 @@
-"""world_size-2 CPU test (gloo) of the data-parallel estimator reductions in fermiflow_amd/dist.py:
-two ranks holding halves of a walker batch must produce the single-process E, E_std and gradient."""
+"""world_size-2 CPU tests (gloo) of the data-parallel sweep reductions: the SAME kernels and the same call order as
+GSVMC._sweep / BetaVMC._sweep (fermiflow_amd/VMC.py) -- ff_reduce_energy -> all_reduce_sum_ -> ff_energy_finish, and
+ff_reduce_moments + ff_beta_state_partials -> all_reduce_sum_ -> ff_beta_finish -- with the kernels' host build
+(tests/hostsim) standing in for the GPU: two ranks holding the halves of a walker batch must produce the single-process E,
+E_std, surrogate value, F, S, logits gradient and per-state baseline.  Plus rank-0 parameter / state-list authority."""
 import os
 import socket
 
@@ -17,48 +20,94 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, eloc_all, logp_all, g_all, out):
+def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _gs_worker(rank, world, port, eloc_all, logp_all, shift, out):
+    _init(rank, world, port)
     from fermiflow_amd import dist as D
-    B = eloc_all.numel()
+    from tests.hostsim import simlib as S
+    B = len(eloc_all)
     off, cnt = D.shard(B)
-    e = eloc_all[off:off + cnt]
-    E, E_std, n = D.global_mean_std(e.sum(), cnt, lambda m: ((e - m) ** 2).sum())
-    # the sweep's variant: tensors in, tensors out, global count known on the host (no .item() anywhere)
-    Et, St = D.global_mean_std_dev(e.sum(), B, lambda tot, scale: ((e - tot[0] * scale) ** 2).sum())
-    assert isinstance(Et, torch.Tensor) and abs(Et.item() - E) < 1e-13 * abs(E) and abs(St.item() - E_std) < 1e-12 * E_std
-    w = (e - E) / n
-    buf = torch.cat([(logp_all[off:off + cnt] * w).sum().reshape(1), (w[:, None] * g_all[off:off + cnt]).sum(0)])
-    D.all_reduce_sum_(buf)
-    out[rank] = (E, E_std, n, buf.clone())
+    sums = torch.from_numpy(S.reduce_energy(eloc_all[off:off + cnt], logp_all[off:off + cnt], shift))      # this rank's four sums
+    D.all_reduce_sum_(sums)
+    est = S.energy_finish(sums.numpy(), shift, B)                                                         # identical on every rank
+    out[rank] = est
     dist.destroy_process_group()
 
 
-def test_two_rank_estimator_matches_single_process():
-    torch.manual_seed(0)
-    B, P = 1001, 300
-    eloc = 30 + 4 * torch.randn(B, dtype=torch.float64)
-    logp = torch.randn(B, dtype=torch.float64)
-    g = torch.randn(B, P, dtype=torch.float64)
+def test_two_rank_ground_state_estimator_matches_single_process():
+    """GSVMC._sweep's estimator path on two gloo ranks (uneven shards): E, sum (e - E)^2, mean(logp (e - E))."""
+    from tests.hostsim import simlib as S
+    S.lib()      # build the host library once, here, not in both workers at the same time
+    rng = np.random.default_rng(0)
+    B = 1001
+    eloc = 30 + 4 * rng.normal(size=B)
+    logp = rng.normal(size=B)
+    mgr = mp.Manager()
+    for shift in (0.0, 29.5, float("nan")):      # first sweep; a warm sweep; a poisoned previous mean (must count as 0)
+        out = mgr.dict()
+        mp.spawn(_gs_worker, args=(2, _free_port(), eloc, logp, shift, out), nprocs=2, join=True)
+        E = eloc.mean()
+        ref = np.array([E, ((eloc - E) ** 2).sum(), (logp * (eloc - E)).mean()])
+        for r in (0, 1):
+            np.testing.assert_allclose(out[r], ref, rtol=1e-11, atol=1e-12)
+        np.testing.assert_array_equal(out[0], out[1])
+        assert abs(np.sqrt(out[0][1] / (B - 1)) - eloc.std(ddof=1)) < 1e-12 * eloc.std()
+
+
+def _beta_worker(rank, world, port, eloc_all, logp_all, ws_all, logits, beta, shift, out):
+    _init(rank, world, port)
+    import ctypes as C
+    from fermiflow_amd import dist as D
+    from tests.hostsim import simlib as S
+    B, ns = len(eloc_all), len(logits)
+    off, cnt = D.shard(B)
+    e, lp, ws = (np.ascontiguousarray(a[off:off + cnt]) for a in (eloc_all, logp_all, ws_all))
+    lib = S.lib()
+    lib.ff_beta_buffer_doubles.restype = C.c_size_t
+    buf = np.zeros(lib.ff_beta_buffer_doubles(ns))
+    sh = np.array([shift])
+    mom = np.empty(2)
+    S._ck(lib.ff_reduce_moments(None, C.c_int64(cnt), S._p(e), C.c_double(0.0), S._p(sh), C.c_double(1.0), S._p(mom)))
+    S._ck(lib.ff_beta_state_partials(None, C.c_int64(cnt), ns, S._p(S._i(ws)), S._p(e), S._p(lp), S._p(buf)))
+    buf[:2] = mom
+    t = torch.from_numpy(buf)
+    D.all_reduce_sum_(t)
+    est, gphi, mean_e, lpa = np.empty(8), np.empty(ns), np.empty(ns), np.empty(ns)
+    S._ck(lib.ff_beta_finish(None, S._p(buf), S._p(sh), S._p(np.ascontiguousarray(logits)), ns, C.c_double(beta), C.c_int64(B),
+                             S._p(est), S._p(gphi), S._p(mean_e), S._p(lpa)))
+    out[rank] = (est, gphi, mean_e)
+    dist.destroy_process_group()
+
+
+def test_two_rank_finite_temperature_estimator_matches_single_process():
+    """BetaVMC._sweep's estimator path on two gloo ranks; the shard boundary splits a many-body state."""
+    from tests.hostsim import simlib as S
+    rng = np.random.default_rng(1)
+    ns, B, beta = 7, 900, 2.0
+    logits = rng.normal(size=ns)
+    ws = np.sort(rng.integers(0, ns, size=B)).astype(np.int32)
+    eloc = 10 + ws + rng.normal(size=B)
+    logp = rng.normal(size=B)
+    one = S.beta_estimator(eloc, logp, ws, logits, beta, 9.0)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), eloc, logp, g, out), nprocs=2, join=True)
-    E, E_std = eloc.mean().item(), eloc.std().item()
-    w = (eloc - E) / B
-    ref = torch.cat([(logp * w).sum().reshape(1), (w[:, None] * g).sum(0)])
+    mp.spawn(_beta_worker, args=(2, _free_port(), eloc, logp, ws, logits, beta, 9.0, out), nprocs=2, join=True)
     for r in (0, 1):
-        e, s, n, buf = out[r]
-        assert n == B
-        assert abs(e - E) < 1e-12 * abs(E) and abs(s - E_std) < 1e-12 * E_std
-        np.testing.assert_allclose(buf.numpy(), ref.numpy(), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(out[r][0], one[0], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(out[r][1], one[1], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(out[r][2], one[2], rtol=1e-12, atol=1e-12)
+    for k in range(3):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+    assert abs(one[0][0] - eloc.mean()) < 1e-12 * abs(eloc.mean())
 
 
 def _sync_worker(rank, world, port, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     from fermiflow_amd import dist as D
     torch.manual_seed(100 + rank)                      # ranks build DIFFERENT parameters (e.g. BetaVMC's random state logits)
     m = torch.nn.Sequential(torch.nn.Linear(1, 5), torch.nn.Linear(5, 1)).double()
@@ -81,3 +130,26 @@ def test_ranks_adopt_rank0_parameters_and_state_list():
     assert not torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1][:out[0][0].numel()], out[0][0])
     assert torch.equal(out[0][2], out[1][2]) and out[1][2].tolist() == list(range(10))
+
+
+def _resume_worker(rank, world, port, out):
+    _init(rank, world, port)
+    import fermiflow_amd as ff
+    eta, mu = ff.MLP(1, 4), ff.MLP(1, 4)
+    m = ff.GSVMC(3, 3, ff.HO2D(), ff.FreeFermion(), ff.CNF(ff.Backflow(eta, mu=mu), (0.0, 1.0)), ff.CoulombPairPotential(2.0),
+                 sp_potential=ff.HO())
+    z = torch.arange(5 * 6 * 2, dtype=torch.float64).reshape(5, 6, 2)
+    st = {"h_flow": None, "dev": {}, "n_global": 10, "z_next": z, "z_next_shard": (0, 2, 0), "z_next_seed": 12345}
+    m.set_extra_state(st)
+    out[rank] = (m._z_next is not None, getattr(m, "_resume_seed", None))
+    dist.destroy_process_group()
+
+
+def test_checkpointed_prefetch_belongs_to_the_rank_that_wrote_it():
+    """every rank loads rank 0's checkpoint; only rank 0 may take the prefetched walkers in it, the other ranks
+    re-draw THEIR shard with the checkpointed Philox key."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_resume_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == (True, None)
+    assert out[1] == (False, 12345)
