@@ -1,14 +1,16 @@
 // ff_adj_wide.h -- adjoint of CNF.delta_logp (SolveIVP.backward, src/NeuralODE/nnModule.py:76-133) for walkers that do not fit
-// the one-wave-per-walker-group kernels of ff_cnf_adj.hip: ONE WALKER PER WAVE, particle number at run time (n <= 24,
-// n d <= 60; ff_wide.hip has the forward passes).  Included by ff_cnf_adj.hip.
+// the one-wave-per-walker-group kernels of ff_cnf_adj.hip: ONE WALKER PER WORKGROUP of W waves (W = 2 up to 128 radii, 4
+// beyond), particle number at run time (n <= 24, n d <= 60; ff_wide.hip has the forward passes).  Included by ff_cnf_adj.hip.
 //
 // Same augmented system (z, a_z, theta-quadrature), same two variants, exactly one of which runs (decided on the device
 // from the radial-table header, as for the narrow kernels):
-//   ff_wide_adjtab_kernel<D, NQ>  derivative heads from the radial table; per (stage, radius) a 4-number record, added with the
-//                                 Runge-Kutta weights into the workgroup-private deposit table when the step is accepted;
-//   ff_wide_adj_kernel<D, NQ>     direct evaluation: radius lanes evaluate all hidden units for the heads, and every lane
-//                                 integrates the parameter gradient of ITS hidden units (lane + 64 j) over all radii.
-// Lane l owns coordinate l (z_l, a_l) and the radii l, l + 64, ... (NQ slots).
+//   ff_wide_adjtab_kernel<D, W, NQ>  derivative heads from the radial table; per (stage, radius) a 4-number record, added with
+//                                    the Runge-Kutta weights into the workgroup-private deposit table when the step is accepted
+//                                    (wave after wave, lanes in order: a fixed summation order, bit-reproducible);
+//   ff_wide_adj_kernel<D, W, NQ>     direct evaluation: radius lanes evaluate all hidden units for the heads, and every lane
+//                                    integrates the parameter gradient of ITS hidden units (tid + 64 W j) over all radii.
+// Lane tid owns coordinate tid (z, a_z; tid < M) and the radii tid, tid + 64 W, ... (NQ slots: one radius per lane up to 22
+// particles -- a one-wave version with five radii per lane took 414 registers and 38 ms per 131 072 walkers at 20 particles).
 #pragma once
 #include "ff_dp5.h"
 
@@ -27,10 +29,16 @@ FF_D int ff_wadj_partner(int n, int P, int a, int j) {
   const int lo = j < a ? j : a, hi = j < a ? a : j;
   return (j == a) ? P + a : ff_pair_index(n, lo, hi);
 }
+template <int NTHR>
 FF_D double ff_wadj_sum(double* s_red, double* s_red2, int lane, double part) {
   s_red[lane] = part;
   __syncthreads();
-  if (lane < 16) s_red2[lane] = (s_red[lane] + s_red[lane + 16]) + (s_red[lane + 32] + s_red[lane + 48]);
+  if (lane < 16) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NTHR / 16; k++) t += s_red[lane + 16 * k];
+    s_red2[lane] = t;
+  }
   __syncthreads();
   double t = 0.0;
 #pragma unroll
@@ -49,22 +57,25 @@ FF_D void ff_wadj_seeds(const ff_adj_args& A, int64_t b, int M, int lane, bool o
   ad = ws ? -wb : ad0;
 }
 
-template <int D, int NQ>
-__global__ void __launch_bounds__(FF_WAVE)
+#ifndef FF_WADJ_WPS
+#define FF_WADJ_WPS 1      // waves per SIMD the tabulated kernel is compiled for
+#endif
+template <int D, int W, int NQ>
+__global__ void __launch_bounds__(FF_WAVE * W, FF_WADJ_WPS)
 ff_wide_adjtab_kernel(ff_adj_args A, int n) {
-  constexpr int NV = 2;
+  constexpr int NV = 2, NTHR = FF_WAVE * W;
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
 
-  __shared__ double s_z[FF_WAVE], s_kb[FF_WAVE], s_red[FF_WAVE], s_red2[16];
-  __shared__ double s_T[NQ * FF_WAVE][3 * D];                     // per radius: its contribution to particle a's rows of v, Dv^T[lambda], grad div
+  __shared__ double s_z[FF_WAVE], s_kb[FF_WAVE], s_red[NTHR], s_red2[16];
+  __shared__ double s_T[NQ * NTHR][3 * D];                     // per radius: its contribution to particle a's rows of v, Dv^T[lambda], grad div
   __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
   __shared__ int s_st[4];
 
   const int lane = threadIdx.x;
   const int M = n * D, P = n * (n - 1) / 2;
-  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += FF_WAVE) (&s_W[0][0][0])[e] = 0.0;
-  for (int e = lane; e < NQ * FF_WAVE * 3 * D; e += FF_WAVE) (&s_T[0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += NTHR) (&s_W[0][0][0])[e] = 0.0;
+  for (int e = lane; e < NQ * NTHR * 3 * D; e += NTHR) (&s_T[0][0])[e] = 0.0;
   if (lane < 4) s_st[lane] = 0;
   __syncthreads();
   const bool has_mu = A.net.Hm > 0;
@@ -72,7 +83,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   const double tab_inv_h = rtab[0], tab_h = rtab[1];
   int rq_id[NQ];
 #pragma unroll
-  for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * FF_WAVE, nrad);
+  for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * NTHR, nrad);
   const bool own = lane < M;
   const int ai = own ? lane / D : 0, ci = own ? lane % D : 0;
   bool off_any = false;
@@ -95,7 +106,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
     const double hwarm0 = C.hwarm;
     int s = -2, nev = 0;
     auto wgt = [&](int v) -> double { return 1.0; };
-    auto gsum = [&](double part) -> double { return ff_wadj_sum(s_red, s_red2, lane, part); };
+    auto gsum = [&](double part) -> double { return ff_wadj_sum<NTHR>(s_red, s_red2, lane, part); };
 
 #pragma unroll 1
     for (;;) {
@@ -107,40 +118,39 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
         s_kb[lane] = fma(g2, c2[1], fma(g1, c1[1], fma(g0, c0[1], gy * y[1])));
       }
       __syncthreads();
-      // ------------------------------------------------------------------ radius phase
+      // ------------------------------------------------------------------ radius phase (branch-free: a slot without a radius
+      // computes on particle 0 and writes row lane + 64 sl of s_T, which no coordinate reads -- see ff_opt_load, ff_common.h)
       ff_rec cur[NQ];
 #pragma unroll
       for (int sl = 0; sl < NQ; sl++) {
         const int id = rq_id[sl];
-        cur[sl].j = 0; cur[sl].dr = 0.0; cur[sl].ca = 0.0; cur[sl].cb = 0.0;
-        if (id >= 0) {
-          const int a = id & 31, bq0 = (id >> 5) & 31, pr = id >> 10;
-          const bool pair = bq0 != 31;
-          double rho[D], dl[D], r2 = 0.0, al = 0.0;
+        const bool act = id >= 0;
+        const int a = act ? (id & 31) : 0, bq0 = act ? ((id >> 5) & 31) : 31, pr = act ? (id >> 10) : lane + sl * NTHR;
+        const bool pair = bq0 != 31;
+        double rho[D], dl[D], r2 = 0.0, al = 0.0;
 #pragma unroll
-          for (int c = 0; c < D; c++) {
-            rho[c] = s_z[a * D + c] - (pair ? s_z[bq0 * D + c] : 0.0);
-            dl[c] = s_kb[a * D + c] - (pair ? s_kb[bq0 * D + c] : 0.0);
-            r2 = fma(rho[c], rho[c], r2);
-            al = fma(dl[c], rho[c], al);
-          }
-          double r, ri, hd[3] = {0.0, 0.0, 0.0};
-          ff_sqrt_rcp(r2, r, ri);
-          const bool ok = ff_heads_table<3>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd);
-          if (!ok) { hd[0] = 0.0; hd[1] = 0.0; hd[2] = 0.0; }
-          double jf = rint(r * FF_DEP_INVH);
-          if (!ok || !(jf <= (double)(FF_DEP_NTOT - 1))) off_any = true;   // beyond either table (or NaN): the direct kernel redoes the call
-          jf = fmin(jf, (double)(FF_DEP_NTOT - 1));
-          cur[sl].j = (r == r) ? (int)jf : 0;
-          cur[sl].dr = fma(-jf, 1.0 / FF_DEP_INVH, r);
-          cur[sl].ca = pair ? -(al - 2.0 * D * ad) : -(al - D * ad);
-          cur[sl].cb = pair ? 2.0 * ad * r : ad * r;
-          const double f0 = hd[0], f1 = hd[1], f2 = hd[2];
-          const double F1 = f1 * (al * ri), gq = (pair ? 2.0 : 1.0) * fma(f2, r, (1.0 + D) * f1) * ri;
-          double* Tq = &s_T[pr][0];
-#pragma unroll
-          for (int c = 0; c < D; c++) { Tq[c] = f0 * rho[c]; Tq[D + c] = fma(F1, rho[c], f0 * dl[c]); Tq[2 * D + c] = gq * rho[c]; }
+        for (int c = 0; c < D; c++) {
+          rho[c] = s_z[a * D + c] - (pair ? s_z[bq0 * D + c] : 0.0);
+          dl[c] = s_kb[a * D + c] - (pair ? s_kb[bq0 * D + c] : 0.0);
+          r2 = fma(rho[c], rho[c], r2);
+          al = fma(dl[c], rho[c], al);
         }
+        double r, ri, hd[3] = {0.0, 0.0, 0.0};
+        ff_sqrt_rcp(r2, r, ri);
+        const bool ok = ff_heads_table<3>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd);
+        hd[0] = ok ? hd[0] : 0.0; hd[1] = ok ? hd[1] : 0.0; hd[2] = ok ? hd[2] : 0.0;
+        double jf = rint(r * FF_DEP_INVH);
+        if (act && (!ok || !(jf <= (double)(FF_DEP_NTOT - 1)))) off_any = true;   // beyond either table (or NaN): the direct kernel redoes the call
+        jf = fmin(jf, (double)(FF_DEP_NTOT - 1));
+        cur[sl].j = (act && r == r) ? (int)jf : 0;
+        cur[sl].dr = act ? fma(-jf, 1.0 / FF_DEP_INVH, r) : 0.0;
+        cur[sl].ca = act ? (pair ? -(al - 2.0 * D * ad) : -(al - D * ad)) : 0.0;
+        cur[sl].cb = act ? (pair ? 2.0 * ad * r : ad * r) : 0.0;
+        const double f0 = hd[0], f1 = hd[1], f2 = hd[2];
+        const double F1 = f1 * (al * ri), gq = (pair ? 2.0 : 1.0) * fma(f2, r, (1.0 + D) * f1) * ri;
+        double* Tq = &s_T[pr][0];
+#pragma unroll
+        for (int c = 0; c < D; c++) { Tq[c] = f0 * rho[c]; Tq[D + c] = fma(F1, rho[c], f0 * dl[c]); Tq[2 * D + c] = gq * rho[c]; }
       }
       __syncthreads();
       nev++;
@@ -179,14 +189,21 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       }
       s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
       if (s_was == 6 && S.nacc != nacc_was) {     // accepted (workgroup-uniform): deposit the step, the record of k6 opens the next one
+#pragma unroll 1
+        for (int ww = 0; ww < W; ww++) {          // one wave at a time, lanes in order: a fixed summation order
+          if (lane / FF_WAVE == ww) {
 #pragma unroll
-        for (int sl = 0; sl < NQ; sl++) {
-          if (rq_id[sl] >= 0) {
-            const int t = ((rq_id[sl] >> 5) & 31) != 31 ? 0 : 1;
-            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], h_was);
-            r0[sl] = cur[sl];
+            for (int sl = 0; sl < NQ; sl++) {
+              if (rq_id[sl] >= 0) {
+                const int t = ((rq_id[sl] >> 5) & 31) != 31 ? 0 : 1;
+                ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], h_was);
+              }
+            }
           }
+          __syncthreads();
         }
+#pragma unroll
+        for (int sl = 0; sl < NQ; sl++) r0[sl] = cur[sl];
       }
       if (s == 99) break;
     }
@@ -203,7 +220,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   if (off_any) *A.off_table = 1.0;
   {   // flush the workgroup-private coefficient table
     double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
+    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += NTHR) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
   }
   __syncthreads();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
@@ -218,26 +235,25 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
 //   dtheta*/dt = ca df(r)/dtheta + cb df'(r)/dtheta   summed over the radii of that net,   (ca, cb) as in the tabulated kernel,
 // with the Runge-Kutta weights of accepted steps, and adds it to the workgroup's row of A.rows (its own entries only: plain
 // read-modify-writes); ff_rows_reduce_kernel sums the rows.
-template <int D, int NQ>
-__global__ void __launch_bounds__(FF_WAVE)
+template <int D, int W, int NQ>
+__global__ void __launch_bounds__(FF_WAVE * W)
 ff_wide_adj_kernel(ff_adj_args A, int n) {
-  constexpr int NV = 2, MAXU = FF_HMAX / FF_WAVE;
+  constexpr int NV = 2, NTHR = FF_WAVE * W, MAXU = (FF_HMAX + NTHR - 1) / NTHR;
   {
     const double* rt = A.net.radial_table;
     if (rt && rt[3] == 0.0 && rt[4] == 0.0 && *A.off_table == 0.0) return;   // the tabulated kernel served this call
   }
   __shared__ ff_wtab s_w[2][FF_HPAD];
   __shared__ double s_e2[64];
-  __shared__ double s_z[FF_WAVE], s_kb[FF_WAVE], s_red[FF_WAVE], s_red2[16];
-  __shared__ double s_T[NQ * FF_WAVE][3 * D];
-  __shared__ double s_q[NQ * FF_WAVE][3];        // r, ca, cb of every radius of the stage
+  __shared__ double s_z[FF_WAVE], s_kb[FF_WAVE], s_red[NTHR], s_red2[16];
+  __shared__ double s_T[NQ * NTHR][3 * D];
+  __shared__ double s_q[NQ * NTHR][3];        // r, ca, cb of every radius of the stage
   __shared__ int s_st[4];
 
   const int lane = threadIdx.x;
   const int M = n * D, P = n * (n - 1) / 2;
-  ff_load_weights(s_w, A.net, lane);
-  ff_fill_exp2_table(s_e2, lane);
-  for (int e = lane; e < NQ * FF_WAVE * 3 * D; e += FF_WAVE) (&s_T[0][0])[e] = 0.0;
+  if (lane < FF_WAVE) { ff_load_weights(s_w, A.net, lane); ff_fill_exp2_table(s_e2, lane); }
+  for (int e = lane; e < NQ * NTHR * 3 * D; e += NTHR) (&s_T[0][0])[e] = 0.0;
   if (lane < 4) s_st[lane] = 0;
   __syncthreads();
   const int He = A.net.He, Hm = A.net.Hm;
@@ -245,7 +261,7 @@ ff_wide_adj_kernel(ff_adj_args A, int n) {
   const int nrad = has_mu ? P + n : P;
   int rq_id[NQ];
 #pragma unroll
-  for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * FF_WAVE, nrad);
+  for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * NTHR, nrad);
   const bool own = lane < M;
   const int ai = own ? lane / D : 0, ci = own ? lane % D : 0;
   double* const myrow = A.rows + (int64_t)blockIdx.x * (3 * He + 3 * Hm);
@@ -274,7 +290,7 @@ ff_wide_adj_kernel(ff_adj_args A, int n) {
     const double hwarm0 = C.hwarm;
     int s = -2, nev = 0;
     auto wgt = [&](int v) -> double { return 1.0; };
-    auto gsum = [&](double part) -> double { return ff_wadj_sum(s_red, s_red2, lane, part); };
+    auto gsum = [&](double part) -> double { return ff_wadj_sum<NTHR>(s_red, s_red2, lane, part); };
 
 #pragma unroll 1
     for (;;) {
@@ -336,8 +352,8 @@ ff_wide_adj_kernel(ff_adj_args A, int n) {
 #pragma unroll
         for (int j = 0; j < MAXU; j++) {
           double aw1 = 0.0, ab1 = 0.0, aw2 = 0.0;
-          const int u = lane + FF_WAVE * j;
-          if (j * FF_WAVE < H) {      // wave-uniform
+          const int u = lane + NTHR * j;
+          if (j * NTHR < H) {      // workgroup-uniform
             const ff_wtab wt = s_w[t][u < H ? u : 0];
             for (int q = q0; q < q1; q++) {
               const double r = s_q[q][0], ca = s_q[q][1], cb = s_q[q][2];
@@ -375,7 +391,7 @@ ff_wide_adj_kernel(ff_adj_args A, int n) {
         for (int t = 0; t < 2; t++)
 #pragma unroll
           for (int j = 0; j < MAXU; j++) {
-            const int u = lane + FF_WAVE * j, H = t ? Hm : He;
+            const int u = lane + NTHR * j, H = t ? Hm : He;
             if (u < H) {
 #pragma unroll
               for (int c = 0; c < 3; c++) myrow[(t ? 3 * He : 0) + c * H + u] += h_was * tent[t][j][c];

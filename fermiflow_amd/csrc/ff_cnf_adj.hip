@@ -1092,12 +1092,12 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
   if (wide) {
-    // radius slots per lane: pairs + one-body radii over 64 lanes
-    const int nq = (n * (n + 1) / 2 + FF_WAVE - 1) / FF_WAVE;
+    // lanes per walker: two waves up to 128 radii (pairs + one-body), four beyond; one radius per lane up to 22 particles
+    const int nr = n * (n + 1) / 2, Wv = nr <= 128 ? 2 : 4, nq = (nr + 64 * Wv - 1) / (64 * Wv);
     const unsigned grid = adj_grid(a.B, 1);
-#define FF_WA(D_, Q_) if (d == D_ && nq <= Q_ && G == 0) { if (net->radial_table) FF_LAUNCH((ff_wide_adjtab_kernel<D_, Q_>), grid, FF_WAVE, stream, a, n); \
-                                                            FF_LAUNCH((ff_wide_adj_kernel<D_, Q_>), grid, FF_WAVE, stream, a, n); G = 1; }
-    FF_WA(2, 2) FF_WA(2, 4) FF_WA(2, 5) FF_WA(3, 2) FF_WA(3, 4) FF_WA(3, 5)
+#define FF_WA(D_, W_, Q_) if (d == D_ && Wv == W_ && nq == Q_) { if (net->radial_table) FF_LAUNCH((ff_wide_adjtab_kernel<D_, W_, Q_>), grid, FF_WAVE * W_, stream, a, n); \
+                                                                  FF_LAUNCH((ff_wide_adj_kernel<D_, W_, Q_>), grid, FF_WAVE * W_, stream, a, n); G = 1; }
+    FF_WA(2, 2, 1) FF_WA(2, 4, 1) FF_WA(2, 4, 2) FF_WA(3, 2, 1) FF_WA(3, 4, 1) FF_WA(3, 4, 2)
 #undef FF_WA
   } else
   // both variants are enqueued; on the device exactly one of them runs, chosen by the radial-table header

@@ -123,3 +123,39 @@ def test_rccl_single_rank_sweep_equals_plain_sweep():
     E2, Es2, g2, grads2, backend = rc[0]
     assert backend == "nccl"
     assert E2 == E and Es2 == Es and g2 == g and (grads2 == grads).all()
+
+
+def _bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = json.loads(ln)
+    return p.returncode, line, p.stderr
+
+
+def test_bench_gpus_2_refuses_a_one_gpu_box_and_runs_two_ranks_over_gloo():
+    """bench.py --gpus 2: with the production backend (nccl = RCCL, one GPU per rank) it must exit 2 on a
+    box with one device instead of reporting n_gpus it did not use; with FF_BENCH_BACKEND=gloo the self-launch path runs two
+    ranks on the one GPU -- weak scaling doubles the global batch, strong scaling (--scaling strong) splits the 1-rank batch,
+    and then E must equal the 1-rank E to reduction-order noise (same Philox streams by global walker index)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    common = ["--steps", "2", "--warmup", "1", "--no-extras", "--walkers-per-gpu", "4096"]
+    rc, line, err = _bench(["--gpus", "2"] + common)
+    assert rc == 2 and line is None and "device(s) visible" in err
+    rc1, one, _ = _bench(["--gpus", "1"] + common)
+    assert rc1 == 0 and one["n_gpus"] == 1 and one["scaling"] == "weak"
+    rc2, two, err2 = _bench(["--gpus", "2", "--scaling", "strong"] + common, {"FF_BENCH_BACKEND": "gloo"})
+    assert rc2 == 0, err2[-2000:]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["global_walkers"] == 4096
+    assert abs(two["E"] - one["E"]) < 1e-12 * abs(one["E"]) and abs(two["E_std"] - one["E_std"]) < 1e-10 * one["E_std"]
+    rc3, weak, err3 = _bench(["--gpus", "2"] + common, {"FF_BENCH_BACKEND": "gloo"})
+    assert rc3 == 0, err3[-2000:]
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["global_walkers"] == 8192

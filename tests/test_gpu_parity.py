@@ -290,7 +290,8 @@ def test_gsvmc_iteration_statistics_and_oracle(golden, dev):
 
 @pytest.mark.parametrize("name,rt,at,vtol,gtol", [("z2_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("z2_nt", 1e-6, 1e-8, 1e-5, 1e-5),
                                                   ("z05_nt", 1e-10, 1e-12, 1e-7, 1e-6), ("u6_nt", 1e-10, 1e-12, 1e-7, 1e-6),
-                                                  ("z2_nomu", 1e-10, 1e-12, 1e-7, 1e-6), ("u6d6_nt", 1e-10, 1e-12, 1e-7, 1e-6)])
+                                                  ("z2_nomu", 1e-10, 1e-12, 1e-7, 1e-6), ("u6d6_nt", 1e-10, 1e-12, 1e-7, 1e-6),
+                                                  ("u6d6_nt", 1e-6, 1e-8, 1e-5, 1e-5)])
 def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gtol):
     """GSVMC.forward -> .backward() END TO END (src/VMC.py:40-59, src/FermionHO2D.py:69-72) on the reference's base
     walkers z, through the production sweep (flow with cost classes, cost-ordered local-energy pass, step-size warm
@@ -306,7 +307,7 @@ def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gt
     cnf.rtol, cnf.atol = rt, at
     model = ff.GSVMC(nup, ndn, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
                      ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
-    assert model.warm_start
+    assert model.warm_start and model.sens_tol == 10.0      # the production settings: warm start + sensitivity-tolerance policy
     for sweep in range(2):      # the second sweep opens its flow pass with the first one's mean step (warm start across sweeps)
         gradE = model.forward_from(T(G[name + "_z"], dev))
         model.zero_grad()
@@ -320,8 +321,9 @@ def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gt
         np.testing.assert_allclose(got, ref, atol=gtol * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("tag", ["boltz", "hot", "rand"])
-def test_betavmc_forward_backward_vs_reference(golden, dev, tag):
+@pytest.mark.parametrize("tag,rt,at,vtol", [("boltz", 1e-10, 1e-12, 1e-7), ("hot", 1e-10, 1e-12, 1e-7), ("rand", 1e-10, 1e-12, 1e-7),
+                                            ("boltz", 1e-6, 1e-8, 1e-5)])
+def test_betavmc_forward_backward_vs_reference(golden, dev, tag, rt, at, vtol):
     """BetaVMC.forward -> both .backward()s END TO END (src/VMC.py:114-171, src/BetaFermionHO2D.py:72-79) on the
     reference's base walkers and state assignment: E, E_std, F, F_std, S, S_analytical, logp_states_all, gradF_phi,
     gradF_theta, d/d(log_state_weights) and the six flow-parameter gradients.  Values 1e-7 relative, gradients 1e-5 of
@@ -330,7 +332,7 @@ def test_betavmc_forward_backward_vs_reference(golden, dev, tag):
     G = golden["g6_betavmc"]
     eta, mu = net_arrays(G, "")
     cnf = make_flow(eta, mu, dev)
-    cnf.rtol, cnf.atol = 1e-10, 1e-12
+    cnf.rtol, cnf.atol = rt, at      # (1e-6 / 1e-8: the reference's default, with the sweep's tolerance policy and warm start on)
     model = ff.BetaVMC(float(G[tag + "_beta"]), 3, 0, float(G[tag + "_dE"]), tag != "rand", ff.HO2D(), ff.FreeFermion(device=dev), cnf,
                        ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
     model.to(dev)
@@ -340,14 +342,14 @@ def test_betavmc_forward_backward_vs_reference(golden, dev, tag):
     gphi, gtheta = model.forward_from(T(G[tag + "_z"], dev), ws)
     model.zero_grad()
     (gphi + gtheta).backward()
-    np.testing.assert_allclose(N(model.x), G[tag + "_x"], atol=1e-8)
+    np.testing.assert_allclose(N(model.x), G[tag + "_x"], atol=max(1e-8, 100 * rt))
     for k in ("E", "F", "S", "S_analytical"):
-        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=1e-7, err_msg=k)
+        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=vtol, err_msg=k)
     for k in ("E_std", "F_std"):
-        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=1e-6, err_msg=k)
+        np.testing.assert_allclose(getattr(model, k), float(G[f"{tag}_{k}"]), rtol=10 * vtol, err_msg=k)
     np.testing.assert_allclose(N(model.logp_states_all), G[tag + "_logp_states_all"], atol=1e-12)
-    np.testing.assert_allclose(gphi.item(), float(G[tag + "_gphi"]), rtol=1e-5, atol=1e-10)
-    np.testing.assert_allclose(gtheta.item(), float(G[tag + "_gtheta"]), rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(gphi.item(), float(G[tag + "_gphi"]), rtol=max(1e-5, 100 * vtol), atol=1e-10)
+    np.testing.assert_allclose(gtheta.item(), float(G[tag + "_gtheta"]), rtol=max(1e-5, 100 * vtol), atol=1e-10)
     ref = G[tag + "_pg_log_state_weights"]
     np.testing.assert_allclose(N(model.log_state_weights.grad), ref, atol=1e-5 * max(np.abs(ref).max(), 1e-12))
     ref = np.concatenate([G[f"{tag}_pg_{k}"] for k in GSVMC_PG])
@@ -631,7 +633,8 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     assert int(a["stats"][3]) == 0 and int(b["stats"][3]) == 0
     assert int(b["stats"][0]) < 0.8 * int(a["stats"][0]), (a["stats"][:3], b["stats"][:3])
     ra, rb = (a["eloc"] / tight - 1).abs(), (b["eloc"] / tight - 1).abs()
-    assert rb[loose].max().item() < 1e-6 and rb.max().item() < ELOC_RTOL / 2, (rb[loose].max(), rb.max())
+    # maximum over ALL walkers (set by the strict ones): 2.1e-7 at 6 particles, 1.3e-6 at 12 -- bar 1e-5
+    assert rb[loose].max().item() < 1e-6 and rb.max().item() < (1e-6 if nup + ndn <= 6 else 3e-6), (rb[loose].max(), rb.max())
     assert torch.equal(a["eloc"][~loose], b["eloc"][~loose]) or (rb[~loose].max() <= 2 * ra[~loose].max() + 1e-9)
     assert abs(b["eloc"].mean().item() / a["eloc"].mean().item() - 1) < 1e-7
     Es = []
@@ -911,15 +914,17 @@ def test_three_local_energy_kernels_agree_on_the_gpu(kind):
 
 
 # ------------------------------------------------------------------------------------------------ configs 3 and 4 at BASELINE size
-def test_config3_betavmc_full_size_known_answer(dev):
+@pytest.mark.parametrize("beta", [10.0, 1.0])
+def test_config3_betavmc_full_size_known_answer(dev, beta):
     """BASELINE.json configs[2] (beta = 10, nup = 3, boltzmann) at 65536 walkers with the driver's zero-initialised flow
     and Z = 0: every walker's local energy is exactly the energy of the many-body state it was drawn in, so
-    E = sum_s p_s E_s up to the sampling of the states, F = E - S/beta, and S agrees with the analytic entropy."""
+    E = sum_s p_s E_s up to the sampling of the states, F = E - S/beta, and S agrees with the analytic entropy.
+    beta = 10 is the BASELINE configuration (the ground state holds almost every walker); beta = 1 populates all 21 states."""
     import fermiflow_amd as ff
     eta, mu = ff.MLP(1, 50), ff.MLP(1, 50)
     eta.init_zeros(); mu.init_zeros()
     cnf = ff.CNF(ff.Backflow(eta, mu=mu), (0.0, 1.0))
-    model = ff.BetaVMC(1.0, 3, 0, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), cnf, ff.CoulombPairPotential(0.0), sp_potential=ff.HO())
+    model = ff.BetaVMC(beta, 3, 0, 2.0, True, ff.HO2D(), ff.FreeFermion(device=dev), cnf, ff.CoulombPairPotential(0.0), sp_potential=ff.HO())
     model.to(dev)
     torch.manual_seed(1)
     B = 65536

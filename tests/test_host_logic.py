@@ -48,8 +48,10 @@ def test_abi_argument_errors_without_gpu():
     assert b"FF_MAX_NS" in lib.ff_last_error()
     net = _lib.FFNet(50, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, None, None, None)
     ode = _lib.FFOde(0.0, 1.0, 1e-6, 1e-8, 0)
-    # (n, d) without a fused instantiation -> 2; negative tolerance -> 1
-    assert lib.ff_cnf_generate(None, C.c_int64(4), 13, 2, C.byref(net), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
+    # (n, d) beyond the fused kernels (n <= 24, n d <= 60) -> 2; negative tolerance -> 1
+    assert lib.ff_cnf_generate(None, C.c_int64(4), 25, 2, C.byref(net), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
+    assert lib.ff_cnf_generate(None, C.c_int64(4), 21, 3, C.byref(net), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
+    assert lib.ff_cnf_adjoint_workspace_bytes(C.c_int64(4), 20, 3, 50, 50) > 0      # BASELINE configs[4]: one walker per wave
     wide = _lib.FFNet(300, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, None, None, None)      # hidden width > 256
     assert lib.ff_cnf_generate(None, C.c_int64(4), 6, 2, C.byref(wide), C.byref(ode), C.c_void_p(8), C.c_void_p(8), None) == 2
     bad = _lib.FFOde(0.0, 1.0, -1.0, 1e-8, 0)
@@ -158,3 +160,28 @@ def test_no_agpr_copy_in_front_of_an_exec_restore():
     wrong = {k: [h for h in mod.masked_prologue_writes(v) if not h[2].startswith("harmless")] for k, v in funcs.items()}
     wrong = {k: v for k, v in wrong.items() if v}
     assert not wrong, wrong
+
+
+def test_plain_parameter_state_dict_loads_as_a_cold_sweep_state():
+    """weights trained with the reference (or another model's state_dict) carry no "_extra_state"; strict loading
+    must accept them -- the sweep state (warm start, reduction shifts, prefetched walkers) then simply starts cold."""
+    import torch
+    import fermiflow_amd as ff
+
+    def build():
+        eta, mu = ff.MLP(1, 6), ff.MLP(1, 6)
+        eta.init_gaussian(1); mu.init_gaussian(2)
+        return ff.GSVMC(3, 3, ff.HO2D(), ff.FreeFermion(), ff.CNF(ff.Backflow(eta, mu=mu), (0.0, 1.0)), ff.CoulombPairPotential(2.0),
+                        sp_potential=ff.HO())
+    a, b = build(), build()
+    with torch.no_grad():
+        for p in a.parameters():
+            p.mul_(3.0)
+    bare = {k: v for k, v in a.state_dict().items() if not k.endswith("_extra_state")}
+    assert len(bare) == 6 and len(a.state_dict()) == 7
+    b._h_flow = torch.ones(1)
+    b.load_state_dict(bare)          # strict
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    assert b._h_flow is None and b._dev == {}
+    assert "_extra_state" not in bare
+    b.load_state_dict(a.state_dict())      # and the full one still loads
