@@ -890,10 +890,7 @@ extern int ff_wide_supported(int n, int d);
 #include "ff_adj_wide.h"   // one walker per wave, run-time particle number (n > 12 in d = 2, n > 4 in d = 3)
 
 // Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
-#ifdef FF_HOSTSIM          // (host simulator: four threads per workgroup, as FF_RBLOCK)
-#define FF_DEPR_EX 2
-#define FF_DEPR_TY 2
-#else
+#ifndef FF_DEPR_EX
 #define FF_DEPR_EX 16      // entries per workgroup of ff_dep_reduce_kernel (consecutive: one 128-byte segment per table)
 #define FF_DEPR_TY 16      // table subsets summed side by side
 #endif

@@ -1473,13 +1473,8 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
               (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
   }
   FF_LAUNCH_CHECK();
-#ifdef FF_HOSTSIM
-  if (z_out) memcpy(z_out, w.z0, sizeof(double) * (size_t)B * M);
-  if (dlogp_out) memcpy(dlogp_out, w.dl, sizeof(double) * (size_t)B);
-#else
   if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
-#endif
   return FF_OK;
 }
 

@@ -5,9 +5,11 @@
 // hold another wave back.
 //
 // FF_HOSTSIM: a TEST-ONLY build mode (tests/hostsim/) in which the very same kernel sources are compiled
-// with g++ and each workgroup is run by 64 host threads with a real barrier.  It exists because the
+// with g++ and each workgroup is run by host threads with a real barrier.  It exists because the
 // build container has no GPU; it is never built by __graft_entry__.build(), never loaded by the
-// fermiflow_amd package, and is not a fallback path.
+// fermiflow_amd package, and is not a fallback path.  This include switch is the ONLY place the product
+// sources know about it: tests/hostsim/hip_shim.h emulates the HIP subset and the gfx950 builtins the
+// kernels use (and pre-defines the few FF_* macros below that carry an #ifndef).
 #pragma once
 #include <stdint.h>
 #include <math.h>
@@ -31,25 +33,17 @@
 #endif
 
 // a value the program knows to be wave-uniform -> scalar register (lets loops on it be scalar loops)
-#ifdef FF_HOSTSIM
-#define FF_UNIFORM(x) (x)
-#else
 #define FF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#endif
 
-// reduction kernels run with blockDim-generic trees; the host simulator uses tiny workgroups (thread creation cost)
-#ifdef FF_HOSTSIM
-#define FF_RBLOCK(n) 4
-#else
+// block size of the reduction kernels (blockDim-generic trees)
+#ifndef FF_RBLOCK
 #define FF_RBLOCK(n) (n)
 #endif
 
 // An integer the compiler must treat as freshly computed here: blocks the hoisting of everything derived from it (LDS
 // addresses, decoded indices) out of the enclosing loop.  hipcc otherwise precomputes dozens of loop-invariant addresses
 // in the prologue of the fused ODE kernels and spills them -- recomputing them costs one or two integer ops each.
-#ifdef FF_HOSTSIM
-#define FF_OPAQUE(x) asm volatile("" : "+r"(x))
-#else
+#ifndef FF_OPAQUE
 #define FF_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
@@ -64,76 +58,49 @@
 
 // --- reciprocal: v_rcp_f64 + two Newton steps (full double precision for normal inputs) ----------
 FF_D double ff_rcp(double x) {
-#ifdef FF_HOSTSIM
-  return 1.0 / x;
-#else
   double y = __builtin_amdgcn_rcp(x);
   y = fma(fma(-x, y, 1.0), y, y);
   y = fma(fma(-x, y, 1.0), y, y);
   return y;
-#endif
 }
 
 // r = sqrt(r2) and 1/r from one v_rsq_f64 + two Newton steps (r within ~1 ulp; r2 = 0 gives r = 0, 1/r = inf)
 FF_D void ff_sqrt_rcp(double r2, double& r, double& ri) {
-#ifdef FF_HOSTSIM
-  r = sqrt(r2);
-  ri = 1.0 / r;
-#else
   double y = __builtin_amdgcn_rsq(r2);
   const double hx = 0.5 * r2;
   y = fma(fma(-hx * y, y, 0.5), y, y);
   y = fma(fma(-hx * y, y, 0.5), y, y);
   ri = y;
   r = r2 > 0.0 ? r2 * y : 0.0;
-#endif
 }
 
 // value held by the neighbouring lane (lane ^ 1): one DPP quad permutation per 32-bit half, no LDS
 FF_D double ff_swap1(double v) {
-#ifdef FF_HOSTSIM
-  return ff_sim_swap1(v);
-#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
-#endif
 }
 
 // value held by lane ^ 2 of the same quad (DPP quad_perm [2,3,0,1])
 FF_D double ff_swap2(double v) {
-#ifdef FF_HOSTSIM
-  return ff_sim_lane_xor(v, 2);
-#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
   hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
-#endif
 }
 
 // value of v on lane src (any lane of the wave; two ds_bpermute_b32: the LDS crossbar, no LDS memory)
 FF_D double ff_lane_read(double v, int src) {
-#ifdef FF_HOSTSIM
-  return ff_sim_lane_read(v, src);
-#else
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
   return __hiloint2double(hi, lo);
-#endif
 }
 
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per wave, D = A B + C, one f64 per lane and operand.
 // Lane l = 16 k + 4 blk + i supplies A_blk[i][k]; lane 16 k + 4 blk + j supplies B_blk[k][j]; lane 16 i + 4 blk + j holds
 // C/D_blk[i][j] (measured on gfx950: tools/probes/mfma_f64.hip) -- the block is (l / 4) % 4, NOT l / 16.
-FF_D double ff_mfma4(double a, double b, double c) {
-#ifdef FF_HOSTSIM
-  return ff_sim_mfma4(a, b, c);
-#else
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-#endif
-}
+FF_D double ff_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 // v_mfma_f64_16x16x4_f64: D (16x16) = A (16x4) B (4x16) + C per wave.  Lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16];
 // register v of lane l holds C/D[4 v + l / 16][l % 16] (measured on gfx950: tools/probes/mfma_f64.hip, wide_probe.hip).
@@ -208,11 +175,7 @@ FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
 // --- NV sigmoids side by side.  Written step by step over the NV lanes-of-work with scheduling fences in between:
 //     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
 //     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
-#ifdef FF_HOSTSIM
-#define FF_SCHED_FENCE() do { } while (0)
-#else
 #define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 template <int NV, bool TAB>
 FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict__ tab) {
   const double MAGIC = 6755399441055744.0;
@@ -278,10 +241,6 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
 #pragma unroll
   for (int q = 0; q < NV; q++) p[q] += 1.0;
   FF_SCHED_FENCE();
-#ifdef FF_HOSTSIM
-#pragma unroll
-  for (int q = 0; q < NV; q++) sg[q] = 1.0 / p[q];
-#else
 #pragma unroll
   for (int q = 0; q < NV; q++) t[q] = __builtin_amdgcn_rcp(p[q]);
   FF_SCHED_FENCE();
@@ -296,7 +255,6 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
   FF_SCHED_FENCE();
 #pragma unroll
   for (int q = 0; q < NV; q++) sg[q] = fma(r[q], t[q], t[q]);
-#endif
   FF_SCHED_FENCE();
 }
 

@@ -14,9 +14,6 @@
 #include "ff_rng.h"
 #include "ff_eloc_ws.h"
 
-#ifdef FF_HOSTSIM
-#define __expf expf
-#endif
 #define FF_HO3D_NORB 120        // shells 0..7 (Hermite degrees 0..7)
 #define FF_PI_M34 0.42377720812375763   // pi^(-3/4)
 
@@ -148,14 +145,9 @@ ff_logprob3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
   if (lap) lap[b] = lsum;
 }
 
-#ifdef FF_HOSTSIM
-static double ff3_mul_rn(double a, double b) { volatile double r = a * b; return r; }
-static double ff3_add_rn(double a, double b) { volatile double r = a + b; return r; }
-#else
 // two roundings, as torch evaluates x + tau * g (the backend must not contract them into one fma)
-FF_D double ff3_mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
-FF_D double ff3_add_rn(double a, double b) { double r = a + b; asm volatile("" : "+v"(r)); return r; }
-#endif
+FF_D double ff3_mul_rn(double a, double b) { double r = a * b; FF_OPAQUE(r); return r; }
+FF_D double ff3_add_rn(double a, double b) { double r = a + b; FF_OPAQUE(r); return r; }
 
 // FreeFermion.sample in d = 3: N(0,1) start, `steps` Metropolis steps with proposal x + tau g, accept iff u < exp(dlogp).
 // NOISE: explicit g0 (B,n,3), g (S,B,n,3), u (S,B); otherwise Philox counters (seed, woff + b) as in the 2-D sampler.
@@ -512,13 +504,8 @@ int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* t
                   (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
   }
   FF_LAUNCH_CHECK();
-#ifdef FF_HOSTSIM
-  if (z_out) memcpy(z_out, w.z0, sizeof(double) * (size_t)B * M);
-  if (dlogp_out) memcpy(dlogp_out, w.dl, sizeof(double) * (size_t)B);
-#else
   if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
-#endif
   return FF_OK;
 }
 

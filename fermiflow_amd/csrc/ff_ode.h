@@ -149,12 +149,8 @@ FF_D void ff_heads(const ff_wtab* __restrict__ tab, const double* __restrict__ e
 // ~200 for the fp64 pow); 1e-6 relative accuracy is irrelevant for a step-size factor, and every lane of a
 // walker's group computes the identical value.
 FF_D double ff_pow02(double x, float e) {
-#ifdef FF_HOSTSIM
-  return (double)powf((float)x, e);
-#else
   // v_log_f32 / v_exp_f32 (base 2, ~1e-7 relative): six instructions where the library powf is ~90
   return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x));
-#endif
 }
 
 // The tableau as a table, one row per stage index of the RHS loops (s = -2..6 -> row s + 2), for kernels whose state is
@@ -174,23 +170,16 @@ __constant__ double FF_ATAB[10][6] = {
     {FF_E0, 0, FF_E2, FF_E3, FF_E4, FF_E5}};
 
 // Wave-wide OR of per-lane flag words (bit 0: still integrating, bit 1: just rejected a step); wave-uniform result.
-// On the GPU two ballots -- no LDS traffic, no barrier (64 lanes OR-ing into one LDS word serialise: that cost ~10 % of
-// the local-energy kernel).  The host simulator (one thread per lane) goes through the shared word.
+// Two ballots -- no LDS traffic, no barrier (64 lanes OR-ing into one LDS word serialise: that cost ~10 % of the
+// local-energy kernel).
 FF_D int ff_wave_or(int* s_any, int lane, int flags) {
-#ifdef FF_HOSTSIM
-  if (lane == 0) *s_any = 0;
-  __syncthreads();
-  if (flags) atomicOr(s_any, flags);
-  __syncthreads();
-  const int any = *s_any;
-  __syncthreads();
-  return any;
-#else
   const unsigned long long b1 = __ballot((flags & 1) != 0), b2 = __ballot((flags & 2) != 0);
   return (b1 ? 1 : 0) | (b2 ? 2 : 0);
-#endif
 }
 
+#ifndef FF_STEP_TRACE
+#define FF_STEP_TRACE(t, h, err, acc) do { } while (0)
+#endif
 // per-walker step-size bookkeeping (identical on all lanes of a walker's group)
 struct ff_stepper {
   double t, tb, dir, interval, habs, h, tnew;
@@ -223,9 +212,7 @@ struct ff_stepper {
     if (done) return false;
     natt++;
     bool acc = err < 1.0;
-#ifdef FF_HOSTSIM_TRACE   // host-simulator builds with -DFF_HOSTSIM_TRACE: FF_TRACE_STEPS=1 prints every step decision
-    if (getenv("FF_TRACE_STEPS")) fprintf(stderr, "step t=%.6f h=%.3e err=%.3e %s\n", t, h, err, acc ? "acc" : "REJ");
-#endif
+    FF_STEP_TRACE(t, h, err, acc);   // (a no-op; tests/hostsim/hip_shim.h prints every step decision when built with -DFF_HOSTSIM_TRACE)
     if (acc) {
       double f = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * ff_pow02(err, -0.2f));
 #ifndef FF_NO_PREDICTIVE

@@ -14,14 +14,9 @@
 
 // x + tau*g exactly as torch computes it (two roundings): hipcc's default -ffp-contract=fast would fuse
 // the pair into one FMA and the walkers would no longer be bit-identical to the reference's.
-#ifdef FF_HOSTSIM
-FF_D double ff_mul_rn(double a, double b) { volatile double r = a * b; return r; }
-FF_D double ff_add_rn(double a, double b) { volatile double r = a + b; return r; }
-#else
 // the empty asm makes the product opaque, so the backend cannot contract mul+add into v_fma_f64
-FF_D double ff_mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
-FF_D double ff_add_rn(double a, double b) { double r = a + b; asm volatile("" : "+v"(r)); return r; }
-#endif
+FF_D double ff_mul_rn(double a, double b) { double r = a * b; FF_OPAQUE(r); return r; }
+FF_D double ff_add_rn(double a, double b) { double r = a + b; FF_OPAQUE(r); return r; }
 
 // ---------------------------------------------------------------------------------------------------
 // FreeFermion.sample (src/base_dist.py:58-71).  NU/ND > 0: compile-time spin sizes, everything in VGPRs.
@@ -681,10 +676,8 @@ ff_moments_kernel(int64_t B, const double* __restrict__ e, double shift_host, co
 // One idle wave that returns after `ticks` of the 100 MHz constant clock: holds a side stream back for a few microseconds
 // so that the kernel the main stream launches at the same moment gets its waves placed first (ff_stream_delay)
 __global__ void ff_delay_kernel(unsigned long long ticks) {
-#ifndef FF_HOSTSIM
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-#endif
 }
 
 // Ground-state estimator sums in one pass (src/VMC.py:56-59): with c = shift[0] (any number every rank agrees on, e.g. the

@@ -7,9 +7,22 @@
 #pragma once
 #include <pthread.h>
 #include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
+
+// ---- the FF_* macros of ff_common.h / ff_ode.h / ff_cnf_adj.hip that carry an #ifndef (host forms)
+#define FF_RBLOCK(n) 4                                       // tiny reduction workgroups: thread creation is what costs here
+#define FF_OPAQUE(x) asm volatile("" : "+m"(x))              // an opaque value of any type ("+v" is a GPU register class)
+#define FF_DEPR_EX 2
+#define FF_DEPR_TY 2
+#ifdef FF_HOSTSIM_TRACE      // FF_TRACE_STEPS=1 prints every accept / reject decision of ff_stepper
+#define FF_STEP_TRACE(t, h, err, acc) do { if (getenv("FF_TRACE_STEPS")) fprintf(stderr, "step t=%.6f h=%.3e err=%.3e %s\n", t, h, err, (acc) ? "acc" : "REJ"); } while (0)
+#endif
 
 struct ff_sim_dim3 { unsigned x = 1, y = 1, z = 1; };
 inline thread_local ff_sim_dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -31,6 +44,8 @@ typedef int hipError_t;
 inline int hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(int) { return "hostsim"; }
 inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+inline int hipMemcpyAsync(void* dst, const void* src, size_t n, int, void*) { memcpy(dst, src, n); return 0; }
 #define hipDeviceAttributeMultiprocessorCount 0
 inline int hipGetDevice(int* d) { *d = 0; return 0; }
 inline int hipDeviceGetAttribute(int* v, int, int) { *v = 2; return 0; }   // the simulator pretends to have two CUs
@@ -60,27 +75,51 @@ inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (in
 inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &b, 8); return d; }
 inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 
-// lane ^ 1 exchange (DPP on the GPU): through a static array and the workgroup barrier; every lane must call it
-static double ff_sim_swap_buf[1024];
-inline double ff_sim_swap1(double v) {
-  ff_sim_swap_buf[threadIdx.x] = v;
+// ---- gfx950 builtins, emulated.  Cross-lane ones go through a static buffer and the workgroup barrier: EVERY lane of the
+// workgroup must call them (the kernels call them in workgroup-uniform control flow).
+template <class T> inline T __builtin_amdgcn_readfirstlane(T x) { return x; }      // (callers pass wave-uniform values)
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long wall_clock64() {      // 100 MHz, as the GPU's constant clock
+  return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+#define __expf expf
+static int ff_sim_xlane_buf[1024];
+// v_mov_b32 with a DPP quad permutation (ctrl < 0x100: two bits per lane of the quad)
+inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) {
+  const unsigned t = threadIdx.x;
+  ff_sim_xlane_buf[t] = v;
   __syncthreads();
-  const double o = ff_sim_swap_buf[threadIdx.x ^ 1];
+  const int o = ff_sim_xlane_buf[(t & ~3u) | ((ctrl >> (2 * (t & 3))) & 3)];
   __syncthreads();
   return o;
 }
-
-// generic cross-lane reads and the fp64 4x4x4 (four blocks) matrix instruction, same mechanism; every lane must call them
-inline double ff_sim_lane_read(double v, int src) {
-  ff_sim_swap_buf[threadIdx.x] = v;
+// ds_bpermute_b32: lane (addr / 4) % 64 of the caller's own wave
+inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
+  const unsigned t = threadIdx.x;
+  ff_sim_xlane_buf[t] = v;
   __syncthreads();
-  const double o = ff_sim_swap_buf[(threadIdx.x & ~63u) | (src & 63)];   // lanes of the caller's own wave
+  const int o = ff_sim_xlane_buf[(t & ~63u) | ((addr >> 2) & 63)];
   __syncthreads();
   return o;
 }
-inline double ff_sim_lane_xor(double v, int m) { return ff_sim_lane_read(v, (int)threadIdx.x ^ m); }
+// wave vote (the kernels only ask whether any lane of a single-wave workgroup voted yes)
+static std::atomic<int> ff_sim_vote{0};
+inline unsigned long long __ballot(bool pred) {
+  __syncthreads();
+  if (threadIdx.x == 0) ff_sim_vote.store(0);
+  __syncthreads();
+  if (pred) ff_sim_vote.fetch_or(1);
+  __syncthreads();
+  return (unsigned long long)ff_sim_vote.load();
+}
+// v_mfma_f64_4x4x4_4b_f64 (one f64 per lane and operand; block = (lane / 4) % 4, ff_common.h)
 static double ff_sim_mfma_a[64], ff_sim_mfma_b[64];
-inline double ff_sim_mfma4(double a, double b, double c) {
+inline double __builtin_amdgcn_mfma_f64_4x4x4f64(double a, double b, double c, int, int, int) {
   const int l = threadIdx.x;
   ff_sim_mfma_a[l] = a; ff_sim_mfma_b[l] = b;
   __syncthreads();

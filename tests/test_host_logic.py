@@ -178,7 +178,7 @@ def test_plain_parameter_state_dict_loads_as_a_cold_sweep_state():
         for p in a.parameters():
             p.mul_(3.0)
     bare = {k: v for k, v in a.state_dict().items() if not k.endswith("_extra_state")}
-    assert len(bare) == 6 and len(a.state_dict()) == 7
+    assert len(bare) == len(a.state_dict()) - 1 and "_extra_state" in a.state_dict()
     b._h_flow = torch.ones(1)
     b.load_state_dict(bare)          # strict
     assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
