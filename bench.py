@@ -75,7 +75,8 @@ def self_launch(n):
 def eloc_kernel_name(n, d=2):
     """The local-energy kernel the dispatcher picks (csrc/ff_cnf_fwd.hip, dispatch_fwd; csrc/ff_wide.hip beyond 12 / 4 particles)."""
     kind = os.environ.get("FF_ELOC_KERNEL", "auto")
-    if os.environ.get("FF_WIDE") == "1" or (d == 2 and n > 12) or (d == 3 and n > 4):
+    if os.environ.get("FF_WIDE") == "1" or kind == "wide" or (d == 2 and n >= int(os.environ.get("FF_WIDE_ELOC_FROM", "11")) and kind == "auto") \
+            or (d == 2 and n > 12) or (d == 3 and n > 4):
         return "wide", f"ff_wide_eloc_kernel<{d}, {(n * d + 4 + 15) // 16}, true>"
     if kind == "mfma" and n <= 6:
         return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 1>"

@@ -1328,8 +1328,13 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   if (ff_wide_forced() && ff_wide_supported(n, d)) return ff_wide_dispatch_fwd(MODE, stream, n, d, a);   // FF_WIDE=1: A/B and parity testing
   static const int eloc_kind = [] {
     const char* e = getenv("FF_ELOC_KERNEL");
-    return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : 0)));
+    return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : (!strcmp(e, "wide") ? 4 : 0))));
   }();
+  // one walker per workgroup, both products on v_mfma_f64_16x16x4 (ff_wide.hip): measured faster than the row layout from
+  // FF_WIDE_ELOC_FROM particles on (tools/probes/wide_c5.py; 16 384 walkers: 11 particles 2.12 against 2.68 ms, 12 particles 2.25 against 2.91; 10 particles 2.04 against 1.88)
+  static const int wide_from = [] { const char* e = getenv("FF_WIDE_ELOC_FROM"); return e ? atoi(e) : 11; }();
+  if (MODE == 2 && d == 2 && (eloc_kind == 4 || (eloc_kind == 0 && n >= wide_from)) && ff_wide_supported(n, d))
+    return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
   if (MODE == 2 && eloc_kind == 1) {
 #define FF_MF(N_, D_) if (n == N_ && d == D_) { launch_mfma<N_, D_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)

@@ -179,10 +179,11 @@ def test_radii_beyond_the_table_fall_back_to_direct_evaluation(golden):
     np.testing.assert_array_equal(gx_t, gx_e)
 
 
-@pytest.mark.parametrize("nup,ndn,B", [(4, 4, 5), (6, 6, 3)])
+@pytest.mark.parametrize("nup,ndn,B", [(4, 4, 5), (6, 6, 1)])
 def test_split_column_eloc_kernel(nup, ndn, B):
-    """ff_eloc_split_kernel (n >= 8: two lanes per direction, half columns exchanged through LDS) against the oracle,
-    with direct and tabulated radial functions; B is chosen ragged (G = 2 walkers per wave for n = 8, 1 for n = 12)."""
+    """The default local-energy kernels of 8 and 12 particles against the oracle, with direct and tabulated radial functions:
+    ff_eloc_split_kernel at n = 8 (two lanes per direction, half columns exchanged through LDS; B ragged: G = 2 walkers per
+    wave), the one-walker-per-workgroup matrix-core kernel at n = 12 (the dispatcher's choice from 11 particles on)."""
     rng = np.random.default_rng(5 + nup)
     He, Hm = 16, 12
     eta = [rng.normal(size=He) * 0.5, rng.normal(size=He) * 0.3, rng.normal(size=He) * 0.05]
