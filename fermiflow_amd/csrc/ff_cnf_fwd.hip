@@ -1082,41 +1082,14 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 //   grad_i = g0 . u_i - dDelta_i
 //   lap    = sum_i u_i^T H0 u_i + g0 . kbar - sum_i L_i
 //   E_loc  = -lap/4 - |grad|^2/8 + V(x)            (src/VMC.py:49-55)
-// Two launches.  (1) ff_eloc_slater_kernel, one lane per walker: the Slater quantities of z(t0) (runtime determinant
-// sizes, private arrays -- serial per walker, so 64 walkers per wave) into a table Q[walker][slot].  (2) ff_eloc_contract_kernel, M = 2n lanes per walker as in the sensitivity kernels: the wave's G*M*M
+// Two launches.  (1) the Slater quantities of z(t0) into a table Q[walker][slot]: ff_eloc_slater_fixed_kernel (determinants up
+// to 4 x 4 of one size: everything in registers, one lane per (walker, spin)) or ff_eloc_slater_rows_kernel (ff_ho3d.hip: sixteen
+// lanes per determinant, any sizes up to 12).  (2) ff_eloc_contract_kernel, M = 2n lanes per walker as in the sensitivity kernels: the wave's G*M*M
 // block of J^T is ONE contiguous read (the one-lane-per-walker version of this contraction fetched every cache line
 // ~8 times: 730 MB per launch against 100 MB of sensitivities), each lane contracts its own direction, three LDS sums
 // finish the walker.
 // slots of Q: [0,M) g0 | [M, M+3n) S (particle-major) | then T_up (2 nup^2), T_dn (2 ndn^2) | last two: 2 log|det| per spin
-// (one lane per (walker, spin species): twice the waves for a latency-bound serial routine)
-__global__ void __launch_bounds__(128)
-ff_eloc_slater_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
-                      const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t b = gid >> 1;
-  const int sp = (int)(gid & 1);
-  if (b >= B) return;
-  const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
-  const int64_t nqs = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;   // slots per walker
-  double zl[2 * FF_MAX_NS], T[2 * FF_MAX_NS * FF_MAX_NS], S[3 * FF_MAX_NS];
-  double lp0 = 0.0;
-  int tq = M + 3 * n + (sp ? 2 * nup * nup : 0);
-  {
-    const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-    if (!ns) { Q[b * nqs + (M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp)] = 0.0; return; }
-    for (int k = 0; k < 2 * ns; k++) zl[k] = z0[b * M + 2 * off + k];
-    lp0 += ff_slater_general(ns, (sp ? tab_dn : tab_up) + st * ns, zl, T, S);
-    for (int a = 0; a < ns; a++) {
-      Q[b * nqs + (2 * (off + a))] = 2.0 * T[a * ns + a];
-      Q[b * nqs + (2 * (off + a) + 1)] = 2.0 * T[ns * ns + a * ns + a];
-      for (int k = 0; k < 3; k++) Q[b * nqs + (M + 3 * (off + a) + k)] = S[3 * a + k];
-    }
-    for (int k = 0; k < 2 * ns * ns; k++) Q[b * nqs + (tq + k)] = T[k];
-  }
-  Q[b * nqs + (M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp)] = 2.0 * lp0;
-}
-
-// the same for equal (or single) determinant sizes known at compile time: everything in registers (ff_slater_fixed)
+// equal (or single) determinant sizes known at compile time: everything in registers (ff_slater_fixed)
 template <int NS>
 __global__ void __launch_bounds__(128)
 ff_eloc_slater_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
@@ -1239,6 +1212,8 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
 
 // =================================================================================================
 extern void ff_set_error(const char* msg);
+extern int ff_slater_rows_launch(void* stream, int d, int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                                 const double* z0, double* Q);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 
@@ -1464,8 +1439,8 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
 #define FF_SF(NS_) case NS_: FF_LAUNCH((ff_eloc_slater_fixed_kernel<NS_>), sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q); break;
     switch (nsf) {
       FF_SF(1) FF_SF(2) FF_SF(3) FF_SF(4)
-      default:
-        FF_LAUNCH(ff_eloc_slater_kernel, sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q);
+      default:      // larger or unequal determinants: sixteen lanes per determinant (ff_ho3d.hip)
+        if (ff_slater_rows_launch(stream, 2, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q) != FF_OK) return FF_ELAUNCH;
     }
 #undef FF_SF
   }

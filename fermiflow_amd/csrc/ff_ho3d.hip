@@ -271,71 +271,143 @@ FF_D void ff_orbital3d_hess(int k, const double* r, double gauss, double& v, dou
   hs[3] = gauss * h[0] * p2[1] * h[2]; hs[4] = gauss * h[0] * p1[1] * p1[2]; hs[5] = gauss * h[0] * h[1] * p2[2];
 }
 
-__global__ void __launch_bounds__(64)
-ff_eloc_slater3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
-                        const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Slater table of the local-energy finish, SIXTEEN LANES PER DETERMINANT (two walkers x two spin species per wave): lane r
+// of a group owns particle r of its species -- row r of D_ij = phi_j(r_i) and of the unit matrix beside it.  Gauss-Jordan
+// with partial pivoting, without moving rows: per column the unused lane with the largest entry becomes the pivot (16-lane
+// butterfly), normalises its row, publishes it through LDS, everyone else eliminates; the lane that was the pivot of column c
+// ends up holding row c of D^-1.  Then lane a forms its particle's rows of T[comp][a][b] = sum_j d_comp phi_j(r_a) Dinv[j][b]
+// and the same-particle Hessian sums S.  Everything is statically indexed (loops over FF_MAX_NS with a
+// predicate): no private-memory arrays -- the one-lane-per-determinant kernel this replaces kept two 12 x 12 matrices in
+// scratch and took 30 ms per 131 072 walkers of 20 particles.  Q layout: see ff_eloc_contract3d_kernel / ff_eloc_contract_kernel.
+template <int D>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_eloc_slater_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                           const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
+  constexpr int NS = FF_MAX_NS, NH2 = D * (D + 1) / 2;
+  __shared__ double s_row[4][2 * NS];           // the pivot row of the step: [A | Inv]
+  __shared__ double s_inv[4][NS][NS + 1];       // D^-1 by rows
+  __shared__ int s_orb[4][NS];
+  const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
+  const int64_t gid = (int64_t)blockIdx.x * 4 + grp;
   const int64_t b = gid >> 1;
   const int sp = (int)(gid & 1);
-  if (b >= B) return;
-  const int n = nup + ndn, M = 3 * n, st = wstate ? wstate[b] : 0;
-  const int64_t nq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + 2;
-  double* q = Q + b * nq;
-  const int ns = sp ? ndn : nup, off = sp ? nup : 0;
-  const int lpq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + sp;
-  if (!ns) { q[lpq] = 0.0; return; }
-  const int* orb = (sp ? tab_dn : tab_up) + st * ns;
-  double x[3 * FF_MAX_NS], A[FF_MAX_NS * FF_MAX_NS], Inv[FF_MAX_NS * FF_MAX_NS];
-  for (int k = 0; k < 3 * ns; k++) x[k] = z0[b * M + 3 * off + k];
-  for (int i = 0; i < ns; i++) {
-    const double gs = ff_gauss3d(x + 3 * i);
-    for (int j = 0; j < ns; j++) {
-      double v, lp;
-      ff_orbital3d<false>(orb[j], x + 3 * i, gs, v, nullptr, lp);
-      A[i * ns + j] = v; Inv[i * ns + j] = (i == j) ? 1.0 : 0.0;
+  const bool live = b < B;
+  const int n = nup + ndn, M = D * n;
+  const int ns = live ? (sp ? ndn : nup) : 0, off = sp ? nup : 0;
+  const int st = (live && wstate) ? wstate[b] : 0;
+  const int64_t nq = M + NH2 * n + D * (nup * nup + ndn * ndn) + 2;
+  double* q = Q + (live ? b : 0) * nq;
+  const bool mine = r < ns;
+  if (mine) s_orb[grp][r] = ((sp ? tab_dn : tab_up) + st * ns)[r];
+  __syncthreads();
+  double x[D];
+#pragma unroll
+  for (int c = 0; c < D; c++) x[c] = mine ? z0[b * M + D * (off + r) + c] : 0.25 * (c + 1 + r);
+  double gs;
+  if constexpr (D == 2) gs = ff_gauss2d(x[0], x[1]); else gs = ff_gauss3d(x);
+  double A[NS], Inv[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    double v = (j == r) ? 1.0 : 0.0;      // rows / columns beyond ns: the unit matrix (never chosen as pivots, eliminated with f = 0)
+    if (j < ns && mine) {
+      if constexpr (D == 2) ff_orbital<false>(s_orb[grp][j], x[0], x[1], gs, v, nullptr, nullptr);
+      else { double lp; ff_orbital3d<false>(s_orb[grp][j], x, gs, v, nullptr, lp); }
     }
+    A[j] = v;
+    Inv[j] = (j == r) ? 1.0 : 0.0;
   }
   double acc = 0.0;
-  for (int c = 0; c < ns; c++) {
-    int p = c;
-    double best = fabs(A[c * ns + c]);
-    for (int r = c + 1; r < ns; r++) { const double a = fabs(A[r * ns + c]); if (a > best) { best = a; p = r; } }
-    if (p != c)
-      for (int j = 0; j < ns; j++) {
-        double t = A[c * ns + j]; A[c * ns + j] = A[p * ns + j]; A[p * ns + j] = t;
-        t = Inv[c * ns + j]; Inv[c * ns + j] = Inv[p * ns + j]; Inv[p * ns + j] = t;
-      }
-    const double piv = A[c * ns + c];
-    acc += log(fabs(piv));
-    const double ip = 1.0 / piv;
-    for (int j = 0; j < ns; j++) { A[c * ns + j] *= ip; Inv[c * ns + j] *= ip; }
-    for (int r = 0; r < ns; r++) {
-      if (r == c) continue;
-      const double f = A[r * ns + c];
-      for (int j = 0; j < ns; j++) { A[r * ns + j] = fma(-f, A[c * ns + j], A[r * ns + j]); Inv[r * ns + j] = fma(-f, Inv[c * ns + j], Inv[r * ns + j]); }
+  bool used = !mine;
+  int myrow = -1;
+#pragma unroll
+  for (int c = 0; c < NS; c++) {
+    const bool act = c < ns;      // (uniform within the group)
+    // pivot: the unused lane with the largest |A[c]| (ties: the lower lane)
+    double best = (!used && act) ? fabs(A[c]) : -1.0;
+    int who = r;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      const double ob = ff_lane_read(best, lane ^ m);
+      const int ow = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, who);
+      const bool take = ob > best || (ob == best && ow < who);
+      best = take ? ob : best;
+      who = take ? ow : who;
     }
+    const bool ispiv = act && who == r && !used;
+    if (ispiv) {
+      const double ip = 1.0 / A[c];
+      acc = log(fabs(A[c]));
+#pragma unroll
+      for (int j = 0; j < NS; j++) { A[j] *= ip; Inv[j] *= ip; s_row[grp][j] = A[j]; s_row[grp][NS + j] = Inv[j]; }
+      used = true;
+      myrow = c;
+    }
+    __syncthreads();
+    if (act && !ispiv) {
+      const double f = A[c];
+#pragma unroll
+      for (int j = 0; j < NS; j++) { A[j] = fma(-f, s_row[grp][j], A[j]); Inv[j] = fma(-f, s_row[grp][NS + j], Inv[j]); }
+    }
+    __syncthreads();
   }
-  double* T = q + M + 6 * n + (sp ? 3 * nup * nup : 0);     // [comp][a][b]
-  for (int a = 0; a < ns; a++) {
-    const double gs = ff_gauss3d(x + 3 * a);
-    double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int bb = 0; bb < ns; bb++) { T[a * ns + bb] = 0.0; T[ns * ns + a * ns + bb] = 0.0; T[2 * ns * ns + a * ns + bb] = 0.0; }
+  if (myrow >= 0) {
+#pragma unroll
+    for (int j = 0; j < NS; j++) s_inv[grp][myrow][j] = Inv[j];
+  }
+  // log|det| = sum of the pivots' logs (each pivot lane holds one of them)
+  double lsum = (myrow >= 0) ? acc : 0.0;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) lsum += ff_lane_read(lsum, lane ^ m);
+  __syncthreads();
+  if (live && ns == 0 && r == 0) q[nq - 2 + sp] = 0.0;
+  if (mine) {
+    double T[D][NS], S[NH2], gd[D];
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      gd[c] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NS; j++) T[c][j] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < NH2; e++) S[e] = 0.0;
     for (int j = 0; j < ns; j++) {
-      double v, gj[3], hj[6];
-      ff_orbital3d_hess<true>(orb[j], x + 3 * a, gs, v, gj, hj);
-      for (int bb = 0; bb < ns; bb++) {
-        const double di = Inv[j * ns + bb];
-        T[a * ns + bb] = fma(gj[0], di, T[a * ns + bb]);
-        T[ns * ns + a * ns + bb] = fma(gj[1], di, T[ns * ns + a * ns + bb]);
-        T[2 * ns * ns + a * ns + bb] = fma(gj[2], di, T[2 * ns * ns + a * ns + bb]);
+      double v, g[D], hs[NH2];
+      if constexpr (D == 2) ff_orbital<true>(s_orb[grp][j], x[0], x[1], gs, v, g, hs);
+      else ff_orbital3d_hess<true>(s_orb[grp][j], x, gs, v, g, hs);
+      const double da = s_inv[grp][j][r];
+#pragma unroll
+      for (int bb = 0; bb < NS; bb++) {
+        const double di = s_inv[grp][j][bb];
+#pragma unroll
+        for (int c = 0; c < D; c++) T[c][bb] = fma(g[c], di, T[c][bb]);
       }
-      const double da = Inv[j * ns + a];
-      for (int e = 0; e < 6; e++) S[e] = fma(hj[e], da, S[e]);
+#pragma unroll
+      for (int c = 0; c < D; c++) gd[c] = fma(g[c], da, gd[c]);
+#pragma unroll
+      for (int e = 0; e < NH2; e++) S[e] = fma(hs[e], da, S[e]);
     }
-    for (int c = 0; c < 3; c++) q[3 * (off + a) + c] = 2.0 * T[c * ns * ns + a * ns + a];     // g0 = 2 grad log|det|
-    for (int e = 0; e < 6; e++) q[M + 6 * (off + a) + e] = S[e];
+#pragma unroll
+    for (int c = 0; c < D; c++) q[D * (off + r) + c] = 2.0 * gd[c];        // g0 = 2 grad log|det|
+#pragma unroll
+    for (int e = 0; e < NH2; e++) q[M + NH2 * (off + r) + e] = S[e];
+    double* Tq = q + M + NH2 * n + (sp ? D * nup * nup : 0);                // [comp][a][b]
+#pragma unroll
+    for (int c = 0; c < D; c++)
+#pragma unroll
+      for (int bb = 0; bb < NS; bb++) {
+        if (bb < ns) Tq[c * ns * ns + r * ns + bb] = T[c][bb];
+      }
+    if (r == 0) q[nq - 2 + sp] = 2.0 * lsum;
   }
-  q[lpq] = 2.0 * acc;
+}
+
+// launch for both dimensions (the d = 2 finish of ff_cnf_fwd.hip uses it beyond the register-resident 4 x 4 determinants)
+int ff_slater_rows_launch(void* stream, int d, int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
+                          const double* z0, double* Q) {
+  const unsigned grid = (unsigned)((2 * B + 3) / 4);
+  if (d == 2) FF_LAUNCH((ff_eloc_slater_rows_kernel<2>), grid, FF_WAVE, stream, B, nup, ndn, tab_up, tab_dn, wstate, z0, Q);
+  else FF_LAUNCH((ff_eloc_slater_rows_kernel<3>), grid, FF_WAVE, stream, B, nup, ndn, tab_up, tab_dn, wstate, z0, Q);
+  return hipGetLastError() == hipSuccess ? FF_OK : FF_ELAUNCH;
 }
 
 static size_t ff_contract3d_lds_bytes(int nup, int ndn) {
@@ -494,8 +566,7 @@ int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* t
   if (B == 0) return FF_OK;
   const size_t M = (size_t)n * 3;
   ff_eloc_ws w = ff_eloc_carve((void*)workspace, B, (size_t)n, 3);
-  FF_LAUNCH(ff_eloc_slater3d_kernel, ff3_grid(2 * B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q);
-  FF_LAUNCH_CHECK();
+  if (ff_slater_rows_launch(stream, 3, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q) != FF_OK) return FF_ELAUNCH;
   {
     const int Gf = FF_WAVE / (3 * n);
     const int64_t ng = (B + Gf - 1) / Gf;
