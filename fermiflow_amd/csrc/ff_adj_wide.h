@@ -57,25 +57,40 @@ FF_D void ff_wadj_seeds(const ff_adj_args& A, int64_t b, int M, int lane, bool o
   ad = ws ? -wb : ad0;
 }
 
-#ifndef FF_WADJ_WPS
-#define FF_WADJ_WPS 1      // waves per SIMD the tabulated kernel is compiled for
-#endif
+// Tabulated kernel.  Everything a radius leaves behind per stage lives in LDS, not in registers:
+//   s_T[q]      its contributions to particle a's rows of v, (dv/dz)^T a_z and grad div (partner b reads them with the sign flipped);
+//   s_dep[.][q] its deposit record (dr, ca, cb, node | net): buffer `cur` of the stage just evaluated, buffer `k0` of the
+//               step's first stage (FSAL: the stage-6 record of an accepted step);
+//   s_Tt        the TENTATIVE coefficient table of the step under way: stage s adds its records with weight h B_s as soon as it is
+//               evaluated (B_1 = 0; the k0 records go in at stage 1, when h is known); an accepted step adds s_Tt to the
+//               workgroup's permanent table -- a private region of A.trows in global memory (L2-resident: plain read-modify-writes
+//               of the owning workgroup) -- a rejected one just clears it.
+// Deposits are partitioned by NODE: wave w adds the records whose node j has j % W == w, every wave scanning all radii
+// -- no two waves touch the same row, lanes of a wave add in lane order: a fixed summation order, bit-reproducible.
+// A radius beyond the LDS table (r >= 8) raises off_table: the direct kernel redoes the call (tail of |psi|^2: ~never).
+// ~100 registers and 66 KB of LDS: two workgroups per CU (the register-resident version: 416 registers, one workgroup, 52 ms
+// per 131 072 walkers of 20 particles).
+struct __attribute__((aligned(16))) ff_wdep { double dr, ca, cb; int j, t; };
+
 template <int D, int W, int NQ>
-__global__ void __launch_bounds__(FF_WAVE * W, FF_WADJ_WPS)
+__global__ void __launch_bounds__(FF_WAVE * W, 2)
 ff_wide_adjtab_kernel(ff_adj_args A, int n) {
-  constexpr int NV = 2, NTHR = FF_WAVE * W;
+  constexpr int NV = 2, NTHR = FF_WAVE * W, RCAP = NQ * NTHR;
+  constexpr int NE = 2 * FF_DEP_NLDS * FF_DEP_ROW;          // entries of a coefficient table
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
 
   __shared__ double s_z[FF_WAVE], s_kb[FF_WAVE], s_red[NTHR], s_red2[16];
-  __shared__ double s_T[NQ * NTHR][3 * D];                     // per radius: its contribution to particle a's rows of v, Dv^T[lambda], grad div
-  __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
+  __shared__ double s_T[RCAP][3 * D];
+  __shared__ ff_wdep s_dep[2][RCAP];
+  __shared__ double s_Tt[2][FF_DEP_NLDS][FF_DEP_LROW];
   __shared__ int s_st[4];
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, wv = lane / FF_WAVE;
   const int M = n * D, P = n * (n - 1) / 2;
-  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += NTHR) (&s_W[0][0][0])[e] = 0.0;
-  for (int e = lane; e < NQ * NTHR * 3 * D; e += NTHR) (&s_T[0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += NTHR) (&s_Tt[0][0][0])[e] = 0.0;
+  for (int e = lane; e < RCAP * 3 * D; e += NTHR) (&s_T[0][0])[e] = 0.0;
+  for (int e = lane; e < 2 * RCAP; e += NTHR) { ff_wdep z = {0.0, 0.0, 0.0, 0, -1}; (&s_dep[0][0])[e] = z; }
   if (lane < 4) s_st[lane] = 0;
   __syncthreads();
   const bool has_mu = A.net.Hm > 0;
@@ -84,18 +99,20 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   int rq_id[NQ];
 #pragma unroll
   for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * NTHR, nrad);
-  const bool own = lane < M;
-  const int ai = own ? lane / D : 0, ci = own ? lane % D : 0;
+  // coordinate p = lane / 4: its four lanes split the partners of p's particle (quad reduction); lane 4 p owns z_p, a_p
+  const int rp = lane >> 2, rs = lane & 3;
+  const bool rowlane = rp < M;
+  const bool own = rowlane && rs == 0;
+  const int ai = rowlane ? rp / D : 0, ci = rowlane ? rp % D : 0;
   bool off_any = false;
-  double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
+  double* const Wg = A.trows + (size_t)blockIdx.x * NE;      // this workgroup's permanent table [2][NLDS][ROW]
 
   for (int64_t bq = blockIdx.x; bq < A.B; bq += gridDim.x) {
     const int64_t b = ff_opt_load(A.order, true, bq, A.z_in, (int32_t)bq);
     double y[NV] = {0.0, 0.0}, c0[NV] = {0.0, 0.0}, c1[NV] = {0.0, 0.0}, c2[NV] = {0.0, 0.0}, c3[NV] = {0.0, 0.0};
     double ad;
-    y[0] = ff_opt_load(A.z_in, own, b * M + lane, A.z_in, 0.0);
-    ff_wadj_seeds(A, b, M, lane, own, y[1], ad);
-    ff_rec r0[NQ], r2[NQ], r3[NQ], r4[NQ], r5[NQ];
+    y[0] = ff_opt_load(A.z_in, own, b * M + rp, A.z_in, 0.0);
+    ff_wadj_seeds(A, b, M, rp, own, y[1], ad);
     ff_stepper S;
     S.begin(A.ta, A.tb, true);
     ff_dp5_ctl C;
@@ -104,9 +121,28 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
     if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
     C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
     const double hwarm0 = C.hwarm;
-    int s = -2, nev = 0;
+    int s = -2, nev = 0, cur = 0;          // s_dep[cur]: records of the stage being evaluated; s_dep[cur ^ 1]: the k0 records
     auto wgt = [&](int v) -> double { return 1.0; };
     auto gsum = [&](double part) -> double { return ff_wadj_sum<NTHR>(s_red, s_red2, lane, part); };
+    // adds the records of buffer `buf` into the tentative table with weight w: this wave takes the nodes j % W == wv
+    auto deposit = [&](int buf, double w) {
+      for (int q0 = 0; q0 < nrad; q0 += FF_WAVE) {
+        const int q = q0 + (lane & (FF_WAVE - 1));
+        if (q < nrad) {
+          const ff_wdep rc = s_dep[buf][q];
+          if (rc.t >= 0 && (rc.j % W) == wv) {
+            double pk = 1.0, pm = 0.0;
+            double* row = &s_Tt[rc.t][rc.j][0];
+#pragma unroll
+            for (int k = 0; k < FF_DEP_ROW; k++) {
+              atomicAdd(row + k, w * fma(rc.ca, pk, rc.cb * pm));
+              pm = pk;
+              pk = pk * rc.dr * (1.0 / (k + 1));
+            }
+          }
+        }
+      }
+    };
 
 #pragma unroll 1
     for (;;) {
@@ -114,13 +150,12 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       __syncthreads();
       if (own) {
-        s_z[lane] = fma(g2, c2[0], fma(g1, c1[0], fma(g0, c0[0], gy * y[0])));
-        s_kb[lane] = fma(g2, c2[1], fma(g1, c1[1], fma(g0, c0[1], gy * y[1])));
+        s_z[rp] = fma(g2, c2[0], fma(g1, c1[0], fma(g0, c0[0], gy * y[0])));
+        s_kb[rp] = fma(g2, c2[1], fma(g1, c1[1], fma(g0, c0[1], gy * y[1])));
       }
       __syncthreads();
-      // ------------------------------------------------------------------ radius phase (branch-free: a slot without a radius
-      // computes on particle 0 and writes row lane + 64 sl of s_T, which no coordinate reads -- see ff_opt_load, ff_common.h)
-      ff_rec cur[NQ];
+      // ------------------------------------------------------------------ radius phase (branch-free; a slot without a radius
+      // works on particle 0 and writes row lane + NTHR sl, which nobody reads)
 #pragma unroll
       for (int sl = 0; sl < NQ; sl++) {
         const int id = rq_id[sl];
@@ -140,12 +175,15 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
         const bool ok = ff_heads_table<3>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd);
         hd[0] = ok ? hd[0] : 0.0; hd[1] = ok ? hd[1] : 0.0; hd[2] = ok ? hd[2] : 0.0;
         double jf = rint(r * FF_DEP_INVH);
-        if (act && (!ok || !(jf <= (double)(FF_DEP_NTOT - 1)))) off_any = true;   // beyond either table (or NaN): the direct kernel redoes the call
-        jf = fmin(jf, (double)(FF_DEP_NTOT - 1));
-        cur[sl].j = (act && r == r) ? (int)jf : 0;
-        cur[sl].dr = act ? fma(-jf, 1.0 / FF_DEP_INVH, r) : 0.0;
-        cur[sl].ca = act ? (pair ? -(al - 2.0 * D * ad) : -(al - D * ad)) : 0.0;
-        cur[sl].cb = act ? (pair ? 2.0 * ad * r : ad * r) : 0.0;
+        const bool on = jf <= (double)(FF_DEP_NLDS - 1);           // (false for NaN too)
+        if (act && (!ok || !on)) off_any = true;                    // beyond either table: the direct kernel redoes the call
+        ff_wdep rc;
+        rc.j = on ? (int)jf : 0;
+        rc.t = (act && on) ? (pair ? 0 : 1) : -1;
+        rc.dr = fma(-(double)rc.j, 1.0 / FF_DEP_INVH, r);
+        rc.ca = pair ? -(al - 2.0 * D * ad) : -(al - D * ad);
+        rc.cb = pair ? 2.0 * ad * r : ad * r;
+        s_dep[cur][pr] = rc;
         const double f0 = hd[0], f1 = hd[1], f2 = hd[2];
         const double F1 = f1 * (al * ri), gq = (pair ? 2.0 : 1.0) * fma(f2, r, (1.0 + D) * f1) * ri;
         double* Tq = &s_T[pr][0];
@@ -154,63 +192,47 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       }
       __syncthreads();
       nev++;
-      // ------------------------------------------------------------------ component phase
-      double out[NV] = {0.0, 0.0};
-      if (own) {
-        double vi = 0.0, dvk = 0.0, gdi = 0.0;
-        for (int j = 0; j < n; j++) {
+      // ------------------------------------------------------------------ component phase: four lanes per coordinate
+      double vi = 0.0, dvk = 0.0, gdi = 0.0;
+      if (rowlane) {
+        for (int j = rs; j < n; j += 4) {
           if (j == ai && !has_mu) continue;
           const double* Tq = &s_T[ff_wadj_partner(n, P, ai, j)][ci];
           const double sg = j < ai ? -1.0 : 1.0;
           vi = fma(sg, Tq[0], vi); dvk = fma(sg, Tq[D], dvk); gdi = fma(sg, Tq[2 * D], gdi);
         }
-        out[0] = vi;
-        out[1] = fma(ad, gdi, -dvk);
       }
-      // ------------------------------------------------------------------ records of the stage, then the stage machine
+      vi += ff_swap1(vi); vi += ff_swap2(vi);
+      dvk += ff_swap1(dvk); dvk += ff_swap2(dvk);
+      gdi += ff_swap1(gdi); gdi += ff_swap2(gdi);
+      double out[NV] = {0.0, 0.0};
+      if (own) { out[0] = vi; out[1] = fma(ad, gdi, -dvk); }
+      // ------------------------------------------------------------------ this stage's share of the step's quadrature
       const int s_was = s;
       const double h_was = S.h;
       const int nacc_was = S.nacc;
-      if (s_was == -2 || s_was == 0) {
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r0[sl] = cur[sl];
-      } else if (s_was == 2) {
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r2[sl] = cur[sl];
-      } else if (s_was == 3) {
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r3[sl] = cur[sl];
-      } else if (s_was == 4) {
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r4[sl] = cur[sl];
-      } else if (s_was == 5) {
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r5[sl] = cur[sl];
-      }
-      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
-      if (s_was == 6 && S.nacc != nacc_was) {     // accepted (workgroup-uniform): deposit the step, the record of k6 opens the next one
-#pragma unroll 1
-        for (int ww = 0; ww < W; ww++) {          // one wave at a time, lanes in order: a fixed summation order
-          if (lane / FF_WAVE == ww) {
-#pragma unroll
-            for (int sl = 0; sl < NQ; sl++) {
-              if (rq_id[sl] >= 0) {
-                const int t = ((rq_id[sl] >> 5) & 31) != 31 ? 0 : 1;
-                ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], h_was);
-              }
-            }
-          }
-          __syncthreads();
+      if (s_was == 1) deposit(cur ^ 1, h_was * FF_B0);            // the step starts: its k0 records, now that h is known
+      else if (s_was == 2) deposit(cur, h_was * FF_B2);
+      else if (s_was == 3) deposit(cur, h_was * FF_B3);
+      else if (s_was == 4) deposit(cur, h_was * FF_B4);
+      else if (s_was == 5) deposit(cur, h_was * FF_B5);
+      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);      // (its reductions are workgroup barriers)
+      if (s_was == -2 || s_was == 0) cur ^= 1;                      // f(y): these records are the step's k0
+      if (s_was == 6) {
+        const bool acc = S.nacc != nacc_was;                         // workgroup-uniform
+        for (int e = lane; e < NE; e += NTHR) {
+          double* tt = &(&s_Tt[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
+          if (acc) Wg[e] += *tt;
+          *tt = 0.0;
         }
-#pragma unroll
-        for (int sl = 0; sl < NQ; sl++) r0[sl] = cur[sl];
+        if (acc) cur ^= 1;                                           // FSAL: the stage-6 records open the next step
       }
       if (s == 99) break;
     }
     const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN gradients
-    if (own && A.gx_out) A.gx_out[b * M + lane] = y[1] + bad;
+    if (own && A.gx_out) A.gx_out[b * M + rp] = y[1] + bad;
     if (lane == 0) {
-      if (S.fail) atomicAdd(&s_W[0][0][0], bad);
+      if (S.fail) Wg[0] += bad;
       if (A.h_out) A.h_out[b] = C.hmax_acc > 0.0 ? C.hmax_acc : hwarm0;
       if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
       if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
@@ -218,10 +240,6 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
     __syncthreads();
   }
   if (off_any) *A.off_table = 1.0;
-  {   // flush the workgroup-private coefficient table
-    double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += NTHR) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
-  }
   __syncthreads();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
     atomicAdd(&A.stats[0], s_st[0]);
@@ -230,6 +248,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
     if (s_st[3]) atomicMax(&A.stats[3], 1);
   }
 }
+
 
 // Direct evaluation.  Parameter gradient: lane l integrates, for its hidden units u = l + 64 j of eta and mu, the quadrature
 //   dtheta*/dt = ca df(r)/dtheta + cb df'(r)/dtheta   summed over the radii of that net,   (ca, cb) as in the tabulated kernel,

@@ -149,57 +149,173 @@ ff_logprob3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
 FF_D double ff3_mul_rn(double a, double b) { double r = a * b; FF_OPAQUE(r); return r; }
 FF_D double ff3_add_rn(double a, double b) { double r = a + b; FF_OPAQUE(r); return r; }
 
-// FreeFermion.sample in d = 3: N(0,1) start, `steps` Metropolis steps with proposal x + tau g, accept iff u < exp(dlogp).
-// NOISE: explicit g0 (B,n,3), g (S,B,n,3), u (S,B); otherwise Philox counters (seed, woff + b) as in the 2-D sampler.
-template <bool NOISE>
-__global__ void __launch_bounds__(64)
-ff_mcmc3d_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
-                 const int* __restrict__ wstate, int steps, double tau, const double* __restrict__ g0,
-                 const double* __restrict__ g, const double* __restrict__ u, uint64_t seed, int64_t woff,
-                 double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int n = nup + ndn, M = 3 * n, st = wstate ? wstate[b] : 0;
-  const int* ou = tab_up + (nup ? st * nup : 0);
-  const int* od = tab_dn + (ndn ? st * ndn : 0);
-  double x[3 * 2 * FF_MAX_NS], nx[3 * 2 * FF_MAX_NS];
+// FreeFermion.sample with SIXTEEN LANES PER DETERMINANT (two walkers x two spin species per wave), for every shape the
+// register-resident samplers of ff_walkers.hip do not cover: d = 3 (BASELINE configs[4]: two 10 x 10 determinants per step) and the
+// d = 2 systems beyond their template list.  Lane r of a group owns particle r of its species: it draws that particle's
+// proposal, evaluates its row of D_ij = phi_j(r_i), and the LU with partial pivoting runs without moving rows -- per column the
+// unused lane with the largest entry is the pivot (16-lane butterfly), publishes its row through LDS, the other unused lanes
+// eliminate.  Every arithmetic operation is the one the one-lane-per-walker kernels perform (ff_slater_general in d = 2,
+// ff_ho3d_logabsdet in d = 3: same pivots, same multipliers, log|det| summed column by column), so chains, accept masks and
+// log-densities are bit-identical to theirs and to the oracle's -- only who computes what changed.  (One lane per walker kept two
+// 12 x 12 matrices in scratch: 85 ms per 131 072 walkers x 100 steps at 20 particles.)
+// NOISE: explicit g0 (B,n,D), g (S,B,n,D), u (S,B); otherwise Philox counters (seed, woff + b) with the quad / uniform slots of
+// the respective one-lane kernel.  g0 without NOISE: the walkers to continue from (ff_mcmc_continue).
+template <int D, bool NOISE>
+__global__ void __launch_bounds__(FF_WAVE)
+ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
+                    const int* __restrict__ wstate, int steps, double tau, const double* __restrict__ g0,
+                    const double* __restrict__ g, const double* __restrict__ u, uint64_t seed, int64_t woff,
+                    double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
+  constexpr int NS = FF_MAX_NS;
+  __shared__ double s_row[4][NS];
+  __shared__ int s_orb[4][NS];
+  const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
+  const int64_t gid = (int64_t)blockIdx.x * 4 + grp;
+  int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1);
+  const bool live = b < B;
+  if (!live) b = B - 1;          // idle groups shadow the last walker (they take part in the barriers and lane exchanges)
+  const int n = nup + ndn, M = D * n;
+  const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+  const int st = wstate ? wstate[b] : 0;
+  const bool mine = r < ns;
+  if (mine) s_orb[grp][r] = ((sp ? tab_dn : tab_up) + st * ns)[r];
+  __syncthreads();
   const uint64_t wid = (uint64_t)(woff + b);
-  auto normals = [&](uint32_t step, double* dst) {   // M normals of (walker, step): quads of four per Philox block
-    for (int q = 0; 4 * q < M; q++) {
-      double z4[4];
-      ff_normal_quad(seed, wid, step, (uint32_t)q, z4);
-      for (int k = 0; k < 4 && 4 * q + k < M; k++) dst[4 * q + k] = z4[k];
+  const int i0 = D * (off + (mine ? r : 0));      // this lane's first coordinate
+  const int nsmax = nup > ndn ? nup : ndn;
+
+  // log|det| of the species' matrix at the positions xx (this lane's particle); identical on all lanes of the group
+  auto logabsdet = [&](const double* xx) -> double {
+    double A[NS];
+    double gs;
+    if constexpr (D == 2) gs = ff_gauss2d(xx[0], xx[1]); else gs = ff_gauss3d(xx);
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      double v = 0.0;
+      if (j < ns) {
+        if constexpr (D == 2) ff_orbital<false>(s_orb[grp][j], xx[0], xx[1], gs, v, nullptr, nullptr);
+        else { double lp; ff_orbital3d<false>(s_orb[grp][j], xx, gs, v, nullptr, lp); }
+      }
+      A[j] = v;
+    }
+    double acc = 0.0;
+    bool used = !mine;
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+      if (c >= nsmax) break;        // (kernel-uniform)
+      const bool act = c < ns;      // (uniform within the group)
+      double best = (!used && act) ? fabs(A[c]) : -1.0;
+      int who = r;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const double ob = ff_lane_read(best, lane ^ m);
+        const int ow = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, who);
+        const bool take = ob > best || (ob == best && ow < who);
+        best = take ? ob : best;
+        who = take ? ow : who;
+      }
+      const double piv = ff_lane_read(A[c], (lane & ~15) | who);
+      if (act) acc += log(fabs(piv));
+      const bool ispiv = act && who == r && !used;
+      if (ispiv) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) s_row[grp][j] = A[j];
+        used = true;
+      }
+      __syncthreads();
+      if (act && !used) {
+        if constexpr (D == 2) {
+          const double ip = 1.0 / piv, f = A[c] * ip;
+#pragma unroll
+          for (int j = 0; j < NS; j++) { if (j > c) A[j] = fma(-f, s_row[grp][j], A[j]); }
+        } else {
+          const double f = A[c] / piv;
+#pragma unroll
+          for (int j = 0; j < NS; j++) { if (j > c) A[j] = A[j] - f * s_row[grp][j]; }
+        }
+      }
+      __syncthreads();
+    }
+    return acc;
+  };
+  // log p of the walker = 2 (log|det up| + log|det down|): the two groups of a walker exchange their sums
+  auto logprob = [&](const double* xx) -> double {
+    const double mysum = logabsdet(xx);
+    const double other = ff_lane_read(mysum, lane ^ 16);
+    const double up = sp ? other : mysum, dn = sp ? mysum : other;
+    double sacc = 0.0;
+    if (nup) sacc += up;
+    if (ndn) sacc += dn;
+    return 2.0 * sacc;
+  };
+  // this lane's D normals of (walker, step)
+  auto normals = [&](uint32_t step, double* z) {
+    double z4[4] = {0.0, 0.0, 0.0, 0.0};
+    int have = -1;
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      const int q = (i0 + c) >> 2;
+      if (q != have) { ff_normal_quad(seed, wid, step, (uint32_t)q, z4); have = q; }
+      const int e = (i0 + c) & 3;
+      z[c] = e == 0 ? z4[0] : (e == 1 ? z4[1] : (e == 2 ? z4[2] : z4[3]));
     }
   };
-  auto logprob = [&](const double* r) -> double {
-    double lp = 0.0, dum;
-    if (nup) lp += ff_ho3d_logabsdet(nup, ou, r, nullptr, &dum);
-    if (ndn) lp += ff_ho3d_logabsdet(ndn, od, r + 3 * nup, nullptr, &dum);
-    return 2.0 * lp;
-  };
-  if (NOISE) { for (int i = 0; i < M; i++) x[i] = g0[b * M + i]; }
-  else normals(0u, x);
+
+  double x[D], nx[D];
+  if (NOISE || g0 != nullptr) {
+#pragma unroll
+    for (int c = 0; c < D; c++) x[c] = g0[b * M + i0 + c];
+  } else {
+    normals(0u, x);
+  }
   double logp = logprob(x);
   int nacc = 0;
   for (int s = 0; s < steps; s++) {
-    double gq[3 * 2 * FF_MAX_NS], uu;
+    double z[D], uu;
     if (NOISE) {
-      for (int i = 0; i < M; i++) gq[i] = g[((int64_t)s * B + b) * M + i];
+#pragma unroll
+      for (int c = 0; c < D; c++) z[c] = g[((int64_t)s * B + b) * M + i0 + c];
       uu = u[(int64_t)s * B + b];
     } else {
-      normals((uint32_t)(s + 1), gq);
-      uu = ff_uniform(seed, wid, (uint32_t)(s + 1), 0xffffu);
+      normals((uint32_t)(s + 1), z);
+      uu = ff_uniform(seed, wid, (uint32_t)(s + 1), D == 2 ? (uint32_t)n : 0xffffu);
     }
-    for (int i = 0; i < M; i++) nx[i] = ff3_add_rn(x[i], ff3_mul_rn(tau, gq[i]));
+#pragma unroll
+    for (int c = 0; c < D; c++) nx[c] = ff3_add_rn(x[c], ff3_mul_rn(tau, z[c]));
     const double nl = logprob(nx);
     const double p = exp(nl - logp);
     const bool acc = uu < p;          // IEEE comparison: NaN rejects, +inf accepts (src/base_dist.py:67-68)
-    if (acc) { for (int i = 0; i < M; i++) x[i] = nx[i]; logp = nl; nacc++; }
-    if (accept) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+    if (acc) {
+#pragma unroll
+      for (int c = 0; c < D; c++) x[c] = nx[c];
+      logp = nl;
+      nacc++;
+    }
+    if (accept && live && sp == 0 && r == 0) accept[(int64_t)s * B + b] = acc ? 1 : 0;
   }
-  for (int i = 0; i < M; i++) x_out[b * M + i] = x[i];
-  if (logp_out) logp_out[b] = logp;
-  if (acc_count) acc_count[b] = nacc;
+  if (!live) return;
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < D; c++) x_out[b * M + i0 + c] = x[c];
+  }
+  if (sp == 0 && r == 0) {
+    if (logp_out) logp_out[b] = logp;
+    if (acc_count) acc_count[b] = nacc;
+  }
+}
+
+// launch for both dimensions (ff_walkers.hip hands its general d = 2 shapes over)
+int ff_mcmc_rows_launch(void* stream, int d, bool noise, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws, int steps,
+                        double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff, double* x_out,
+                        double* logp_out, uint8_t* accept, int* acc_count) {
+  const unsigned grid = (unsigned)((2 * B + 3) / 4);
+#define FF_MR(D_, N_) FF_LAUNCH((ff_mcmc_rows_kernel<D_, N_>), grid, FF_WAVE, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, \
+                                x_out, logp_out, accept, acc_count)
+  if (d == 2) { if (noise) FF_MR(2, true); else FF_MR(2, false); }
+  else { if (noise) FF_MR(3, true); else FF_MR(3, false); }
+#undef FF_MR
+  return hipGetLastError() == hipSuccess ? FF_OK : FF_ELAUNCH;
 }
 
 // ---- fp32: Backflow.forward / .divergence with the sigmoid sums, radii and accumulations in single precision
@@ -319,8 +435,10 @@ ff_eloc_slater_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ 
   double acc = 0.0;
   bool used = !mine;
   int myrow = -1;
+  const int nsmax = nup > ndn ? nup : ndn;      // (kernel-uniform: columns beyond both determinants are skipped by a scalar branch)
 #pragma unroll
   for (int c = 0; c < NS; c++) {
+    if (c >= nsmax) break;
     const bool act = c < ns;      // (uniform within the group)
     // pivot: the unused lane with the largest |A[c]| (ties: the lower lane)
     double best = (!used && act) ? fabs(A[c]) : -1.0;
@@ -523,10 +641,8 @@ int ff_mcmc_sample_noise3d(void* stream, int64_t B, int nup, int ndn, const int3
   FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_mcmc_sample_noise3d: null orbital table");
   FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_mcmc_sample_noise3d: determinant larger than FF_MAX_NS");
   if (B == 0) return FF_OK;
-  FF_LAUNCH((ff_mcmc3d_kernel<true>), ff3_grid(B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, g0, g, u,
-            (uint64_t)0, (int64_t)0, x_out, logp_out, accept, (int*)nullptr);
-  FF_LAUNCH_CHECK();
-  return FF_OK;
+  return ff_mcmc_rows_launch(stream, 3, true, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, g0, g, u, (uint64_t)0, (int64_t)0, x_out,
+                             logp_out, accept, (int*)nullptr);
 }
 
 int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
@@ -536,11 +652,8 @@ int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* t
   FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_mcmc_sample3d: null orbital table");
   FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_mcmc_sample3d: determinant larger than FF_MAX_NS");
   if (B == 0) return FF_OK;
-  FF_LAUNCH((ff_mcmc3d_kernel<false>), ff3_grid(B, 64), 64, stream, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau,
-            (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, seed, walker_offset, x_out, logp_out,
-            (uint8_t*)nullptr, accept_count);
-  FF_LAUNCH_CHECK();
-  return FF_OK;
+  return ff_mcmc_rows_launch(stream, 3, false, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, (const double*)nullptr,
+                             (const double*)nullptr, (const double*)nullptr, seed, walker_offset, x_out, logp_out, (uint8_t*)nullptr, accept_count);
 }
 
 int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div) {

@@ -909,6 +909,10 @@ static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, c
               x_out, logp_out, accept, acc_count);
 }
 
+extern int ff_mcmc_rows_launch(void* stream, int d, bool noise, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
+                               int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
+                               double* x_out, double* logp_out, uint8_t* accept, int* acc_count);
+
 static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
                          int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
                          double* x_out, double* logp_out, uint8_t* accept, int* acc_count) {
@@ -921,9 +925,8 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
   FF_MC(3, 3) FF_MC(3, 0) FF_MC(6, 0) FF_MC(6, 6) FF_MC(1, 0) FF_MC(2, 0) FF_MC(4, 0)
   FF_MC(1, 1) FF_MC(2, 2) FF_MC(4, 4) FF_MC(5, 5) FF_MC(5, 0) FF_MC(10, 0)
 #undef FF_MC
-  launch_mcmc<-1, -1>(noise, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count);
-  FF_LAUNCH_CHECK();
-  return FF_OK;
+  // every other shape: sixteen lanes per determinant (ff_ho3d.hip; bit-identical to the one-lane general kernel it replaced)
+  return ff_mcmc_rows_launch(stream, 2, noise, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count);
 }
 
 // ---------------------------------------------------------------------------------------------------
