@@ -107,6 +107,7 @@ FF_D double ff_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfm
 // 64 cycles per instruction = 16 FMA per cycle and SIMD: the fp64 peak of the vector pipe, in one issue slot.
 typedef double ff_d4 __attribute__((vector_size(32)));
 FF_D ff_d4 ff_mfma16(double a, double b, ff_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+typedef float ff_f4 __attribute__((vector_size(16)));      // accumulator of v_mfma_f32_16x16x4_f32: register v of lane l holds C/D[4 (l / 16) + v][l % 16]
 
 // --- exp for |x| <= 708.  Rounding and scaling use the integer pipe instead of the quarter-rate
 //     v_rndne_f64 / v_cvt_i32_f64 / v_ldexp_f64: adding 1.5*2^52 leaves round(x*log2e) in the low mantissa word, and

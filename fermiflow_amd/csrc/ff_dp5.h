@@ -135,3 +135,164 @@ FF_D int ff_dp5_consume(int s, ff_stepper& S, ff_dp5_ctl& C, double* y, double* 
   if (S.done) return 99;
   return acc ? 1 : 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-segment variant for the matrix-core local-energy kernel: segment A (NA components of type TA -- double, or float for
+// the single-precision sensitivity path -- all with the error weight wA; its error accumulator c3A is any indexable vector)
+// and segment B (NB double components with weights wgtB(v)).  Same stage machine, same decisions: the arithmetic of segment A
+// runs in TA, its error norms are accumulated in TA and added to segment B's in double.
+FF_D double ff_t_abs(double x) { return __builtin_fabs(x); }
+FF_D float ff_t_abs(float x) { return __builtin_fabsf(x); }
+FF_D double ff_t_max(double a, double b) { return __builtin_fmax(a, b); }
+FF_D float ff_t_max(float a, float b) { return __builtin_fmaxf(a, b); }
+FF_D double ff_t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+FF_D float ff_t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+FF_D double ff_t_rcp(double x) { return ff_rcp(x); }
+FF_D float ff_t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp: error norms only
+
+template <int NA, class TA, class C3A, int NB, class C3B, class WB, class G>
+FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, TA* yA, TA* c0A, TA* c1A, TA* c2A, C3A& c3A, const TA* outA, double wA_,
+                         double* yB, double* c0B, double* c1B, double* c2B, C3B& c3B, const double* outB, WB wgtB, G gsum) {
+  const double h = S.h, rtol = C.rtol, atol = C.atol;
+  const TA hA = (TA)h, rtA = (TA)rtol, atA = (TA)atol, wA = (TA)wA_;
+  if (s == -2) {
+    TA qa0 = 0, qa1 = 0;
+#pragma unroll
+    for (int v = 0; v < NA; v++) {
+      c0A[v] = outA[v];
+      const TA isc = wA * ff_t_rcp(ff_t_fma(ff_t_abs(yA[v]), rtA, atA));
+      qa0 = ff_t_fma(yA[v] * isc, yA[v] * isc, qa0);
+      qa1 = ff_t_fma(c0A[v] * isc, c0A[v] * isc, qa1);
+    }
+    double p0 = (double)qa0, p1 = (double)qa1;
+#pragma unroll
+    for (int v = 0; v < NB; v++) {
+      c0B[v] = outB[v];
+      const double isc = wgtB(v) * ff_rcp(fma(fabs(yB[v]), rtol, atol));
+      p0 = fma(yB[v] * isc, yB[v] * isc, p0);
+      p1 = fma(c0B[v] * isc, c0B[v] * isc, p1);
+    }
+    const double d0 = sqrt(gsum(p0) * C.nt_inv);
+    C.d1v = sqrt(gsum(p1) * C.nt_inv);
+    C.h0v = S.h0(d0, C.d1v);
+    if (C.hwarm > 0.0) {
+      S.habs = fmin(C.hwarm, S.interval);
+      S.plan();
+      return S.done ? 99 : 1;
+    }
+    return S.done ? 99 : -1;
+  }
+  if (s == -1) {
+    TA qa = 0;
+#pragma unroll
+    for (int v = 0; v < NA; v++) {
+      const TA t = (outA[v] - c0A[v]) * wA * ff_t_rcp(ff_t_fma(ff_t_abs(yA[v]), rtA, atA));
+      qa = ff_t_fma(t, t, qa);
+    }
+    double p2 = (double)qa;
+#pragma unroll
+    for (int v = 0; v < NB; v++) {
+      const double t = (outB[v] - c0B[v]) * wgtB(v) * ff_rcp(fma(fabs(yB[v]), rtol, atol));
+      p2 = fma(t, t, p2);
+    }
+    const double d2 = sqrt(gsum(p2) * C.nt_inv) / C.h0v;
+    S.init_habs(C.h0v, C.d1v, d2);
+    S.plan();
+    return 1;
+  }
+  if (s == 0) {      // (three separate copies: a pointer selected at run time would force the register arrays into scratch)
+#pragma unroll
+    for (int v = 0; v < NA; v++) c0A[v] = outA[v];
+#pragma unroll
+    for (int v = 0; v < NB; v++) c0B[v] = outB[v];
+    return 1;
+  }
+  if (s == 1) {
+#pragma unroll
+    for (int v = 0; v < NA; v++) c1A[v] = outA[v];
+#pragma unroll
+    for (int v = 0; v < NB; v++) c1B[v] = outB[v];
+    return 2;
+  }
+  if (s == 2) {
+#pragma unroll
+    for (int v = 0; v < NA; v++) c2A[v] = outA[v];
+#pragma unroll
+    for (int v = 0; v < NB; v++) c2B[v] = outB[v];
+    return 3;
+  }
+  if (s == 3) {
+#pragma unroll
+    for (int v = 0; v < NA; v++) {
+      const TA k0v = c0A[v], k1v = c1A[v], k2v = c2A[v], k3v = outA[v], yv = yA[v];
+      c0A[v] = ff_t_fma(hA, (TA)FF_A40 * k0v + (TA)FF_A41 * k1v + (TA)FF_A42 * k2v + (TA)FF_A43 * k3v, yv);
+      c1A[v] = ff_t_fma(hA, (TA)FF_A50 * k0v + (TA)FF_A51 * k1v + (TA)FF_A52 * k2v + (TA)FF_A53 * k3v, yv);
+      c2A[v] = ff_t_fma(hA, (TA)FF_B0 * k0v + (TA)FF_B2 * k2v + (TA)FF_B3 * k3v, yv);
+      c3A[v] = hA * ((TA)FF_E0 * k0v + (TA)FF_E2 * k2v + (TA)FF_E3 * k3v);
+    }
+#pragma unroll
+    for (int v = 0; v < NB; v++) {
+      const double k0v = c0B[v], k1v = c1B[v], k2v = c2B[v], k3v = outB[v], yv = yB[v];
+      c0B[v] = fma(h, FF_A40 * k0v + FF_A41 * k1v + FF_A42 * k2v + FF_A43 * k3v, yv);
+      c1B[v] = fma(h, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
+      c2B[v] = fma(h, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
+      c3B[v] = h * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+    }
+    return 4;
+  }
+  if (s == 4) {
+#pragma unroll
+    for (int v = 0; v < NA; v++) {
+      c1A[v] = ff_t_fma(hA * (TA)FF_A54, outA[v], c1A[v]);
+      c2A[v] = ff_t_fma(hA * (TA)FF_B4, outA[v], c2A[v]);
+      c3A[v] = ff_t_fma(hA * (TA)FF_E4, outA[v], (TA)c3A[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NB; v++) {
+      c1B[v] = fma(h * FF_A54, outB[v], c1B[v]);
+      c2B[v] = fma(h * FF_B4, outB[v], c2B[v]);
+      c3B[v] = fma(h * FF_E4, outB[v], c3B[v]);
+    }
+    return 5;
+  }
+  if (s == 5) {
+#pragma unroll
+    for (int v = 0; v < NA; v++) {
+      c2A[v] = ff_t_fma(hA * (TA)FF_B5, outA[v], c2A[v]);
+      c3A[v] = ff_t_fma(hA * (TA)FF_E5, outA[v], (TA)c3A[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NB; v++) {
+      c2B[v] = fma(h * FF_B5, outB[v], c2B[v]);
+      c3B[v] = fma(h * FF_E5, outB[v], c3B[v]);
+    }
+    return 6;
+  }
+  // s == 6
+  TA qa = 0;
+#pragma unroll
+  for (int v = 0; v < NA; v++) {
+    const TA e = ff_t_fma(hA * (TA)FF_E6, outA[v], (TA)c3A[v]);
+    const TA t = e * wA * ff_t_rcp(ff_t_fma(ff_t_max(ff_t_abs(yA[v]), ff_t_abs(c2A[v])), rtA, atA));
+    qa = ff_t_fma(t, t, qa);
+  }
+  double pe = (double)qa;
+#pragma unroll
+  for (int v = 0; v < NB; v++) {
+    const double e = fma(h * FF_E6, outB[v], c3B[v]);
+    const double t = e * wgtB(v) * ff_rcp(fma(fmax(fabs(yB[v]), fabs(c2B[v])), rtol, atol));
+    pe = fma(t, t, pe);
+  }
+  const double err = sqrt(gsum(pe) * C.nt_inv);
+  const bool acc = S.decide(err, C.max_steps);
+  if (acc) {
+    C.hmax_acc = fmax(C.hmax_acc, fabs(h));
+#pragma unroll
+    for (int v = 0; v < NA; v++) { yA[v] = c2A[v]; c0A[v] = outA[v]; }
+#pragma unroll
+    for (int v = 0; v < NB; v++) { yB[v] = c2B[v]; c0B[v] = outB[v]; }
+  }
+  S.plan();
+  if (S.done) return 99;
+  return acc ? 1 : 0;
+}

@@ -241,21 +241,40 @@ ff_wide_flow_kernel(ff_fwd_args A, int n) {
 // Lane state (NV = 4 T + 4 doubles): [0, 4T) J, [4T] z_p, [4T+1] kbar_p, [4T+2] / [4T+3] the Delta / lap Delta shares.
 // The error accumulator of the Dormand-Prince step lives in lane-private LDS columns for T >= 3 (registers: the four other
 // vectors, the stage J and two sets of MFMA accumulators already fill the file).
-template <int NV, int NTHR, bool IN_LDS>
+template <class TE, int NV, int NTHR, bool IN_LDS>
 struct ff_wide_vec;
-template <int NV, int NTHR>
-struct ff_wide_vec<NV, NTHR, false> {
-  double r[NV];
-  FF_D ff_wide_vec(double*, int) {}
-  FF_D double& operator[](int v) { return r[v]; }
-  FF_D const double& operator[](int v) const { return r[v]; }
+template <class TE, int NV, int NTHR>
+struct ff_wide_vec<TE, NV, NTHR, false> {
+  TE r[NV];
+  FF_D ff_wide_vec(TE*, int) {}
+  FF_D TE& operator[](int v) { return r[v]; }
+  FF_D const TE& operator[](int v) const { return r[v]; }
 };
-template <int NV, int NTHR>
-struct ff_wide_vec<NV, NTHR, true> {
-  double* col;
-  FF_D ff_wide_vec(double* base, int tid) : col(base + tid) {}
-  FF_D double& operator[](int v) { return col[v * NTHR]; }
-  FF_D const double& operator[](int v) const { return col[v * NTHR]; }
+template <class TE, int NV, int NTHR>
+struct ff_wide_vec<TE, NV, NTHR, true> {
+  TE* col;
+  FF_D ff_wide_vec(TE* base, int tid) : col(base + tid) {}
+  FF_D TE& operator[](int v) { return col[v * NTHR]; }
+  FF_D const TE& operator[](int v) const { return col[v * NTHR]; }
+};
+
+// The matrix instruction per element type of J.  fp64: v_mfma_f64_16x16x4_f64, register v of lane (g, c) holds row 4 v + g of a
+// tile; fp32 (the single-precision sensitivity path of BASELINE configs[4]): v_mfma_f32_16x16x4_f32 -- twice the rate -- whose
+// register v holds row 4 g + v (measured: tools/probes/wide_probe.hip, profiles/r03_wide_probe_mfma_layouts.txt).
+template <class TJ> struct ff_wide_mma;
+template <> struct ff_wide_mma<double> {
+  typedef ff_d4 acc_t;
+  static FF_D int row(int K, int v, int g) { return 16 * K + 4 * v + g; }
+  static FF_D int row_lane(int g) { return g; }                       // row = row_lane(g) + row_step(K, v)
+  static FF_D constexpr int row_step(int K, int v) { return 16 * K + 4 * v; }
+  static FF_D acc_t mma(double a, double b, acc_t c) { return ff_mfma16(a, b, c); }
+};
+template <> struct ff_wide_mma<float> {
+  typedef ff_f4 acc_t;
+  static FF_D int row(int K, int v, int g) { return 16 * K + 4 * g + v; }
+  static FF_D int row_lane(int g) { return 4 * g; }
+  static FF_D constexpr int row_step(int K, int v) { return 16 * K + v; }
+  static FF_D acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 
 // sum over the four lanes of a quad (lanes 4q .. 4q+3), result on all four
@@ -265,17 +284,19 @@ FF_D double ff_quad_sum(double v) {
   return v;
 }
 
-template <int D, int T, bool TAB>
+template <int D, int T, bool TAB, class TJ>
 __global__ void __launch_bounds__(FF_WAVE * T)
 ff_wide_eloc_kernel(ff_fwd_args A, int n) {
-  constexpr int MP = 16 * T, NTHR = FF_WAVE * T, JS = MP + 2;
-  constexpr int NVJ = 4 * T, NV = NVJ + 4, IZ = NVJ, IK = NVJ + 1, IDL = NVJ + 2, ILP = NVJ + 3;
+  typedef ff_wide_mma<TJ> MMA;
+  constexpr bool F32 = sizeof(TJ) == 4;
+  constexpr int MP = 16 * T, NTHR = FF_WAVE * T, JS = F32 ? MP + 1 : MP + 2;     // (row stride of the LDS operand images)
+  constexpr int NVJ = 4 * T, NVS = 4, IZ = 0, IK = 1, IDL = 2, ILP = 3;           // J elements; the four fp64 scalars of a lane
   constexpr int NH = 4;
   constexpr int NCAP = (MP - 4) / D > FF_WIDE_NMAX ? FF_WIDE_NMAX : (MP - 4) / D;   // particles this instantiation can hold
   constexpr int RCAP = NCAP * (NCAP + 1) / 2;
   constexpr int NQ = (RCAP + NTHR - 1) / NTHR;
   constexpr int NPK = (NCAP + 3) / 4;                  // partners per row lane
-  constexpr bool C3_LDS = T >= 3 && TAB;       // (the direct-evaluation variant needs the LDS for its weight tables)
+  constexpr bool C3_LDS = T >= 3 && TAB && !F32;       // (the direct-evaluation variant needs the LDS for its weight tables)
   // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
   //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
   // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
@@ -284,11 +305,12 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 
   __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
   __shared__ double s_e2[TAB ? 1 : 64];
-  __shared__ __attribute__((aligned(16))) double s_J[MP * JS];   // stage J, [p][i]; then S = J J^T
-  __shared__ __attribute__((aligned(16))) double s_A[MP * JS];   // A = dv/dz with row M = -grad div
+  __shared__ __attribute__((aligned(16))) TJ s_J[MP * JS];   // stage J, [p][i]; then S = J J^T
+  __shared__ __attribute__((aligned(16))) TJ s_A[MP * JS];   // A = dv/dz with row M = -grad div
   __shared__ __attribute__((aligned(16))) double s_rec[(RCAP + 1) * RW];   // + one record that stays zero
   __shared__ double s_z[MP], s_kb[MP], s_red[NTHR], s_red2[16];
-  __shared__ double s_c3[C3_LDS ? NV * NTHR : 1];
+  __shared__ TJ s_c3[C3_LDS ? NVJ * NTHR : 1];
+  __shared__ double s_c3s[C3_LDS ? NVS * NTHR : 1];
   __shared__ int s_st[4];
   __shared__ long long s_next;
 
@@ -306,7 +328,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   }
   bool off_table = false;
   if (tid < 4) s_st[tid] = 0;
-  for (int e = tid; e < MP * JS; e += NTHR) { s_J[e] = 0.0; s_A[e] = 0.0; }
+  for (int e = tid; e < MP * JS; e += NTHR) { s_J[e] = (TJ)0; s_A[e] = (TJ)0; }
   for (int e = tid; e < (RCAP + 1) * RW; e += NTHR) s_rec[e] = 0.0;
   if (tid < MP) { s_z[tid] = 0.0; s_kb[tid] = 0.0; }
   __syncthreads();
@@ -346,17 +368,20 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     }
     if (bq >= A.B) break;
     const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);
-    double y[NV], c0[NV], c1[NV], c2[NV];
-    ff_wide_vec<NV, NTHR, C3_LDS> c3(s_c3, tid);
+    TJ yJ[NVJ], c0J[NVJ], c1J[NVJ], c2J[NVJ];
+    ff_wide_vec<TJ, NVJ, NTHR, C3_LDS> c3J(s_c3, tid);
+    double y[NVS], c0[NVS], c1[NVS], c2[NVS];
+    ff_wide_vec<double, NVS, NTHR, C3_LDS> c3(s_c3s, tid);
 #pragma unroll
-    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
+    for (int v = 0; v < NVS; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
     y[IZ] = ff_opt_load(A.y_in, own, b * M + rp, A.y_in, 0.0);
 #pragma unroll
     for (int K = 0; K < T; K++)
 #pragma unroll
       for (int v = 0; v < 4; v++) {
-        const int p = 16 * K + 4 * v + lg, i = 16 * w + lc;
-        y[4 * K + v] = (p == i && p < M) ? 1.0 : 0.0;
+        const int p = MMA::row(K, v, lg), i = 16 * w + lc;
+        yJ[4 * K + v] = (p == i && p < M) ? (TJ)1 : (TJ)0;
+        c0J[4 * K + v] = (TJ)0; c1J[4 * K + v] = (TJ)0; c2J[4 * K + v] = (TJ)0; c3J[4 * K + v] = (TJ)0;
       }
     ff_stepper S;
     S.begin(A.ta, A.tb, true);
@@ -369,7 +394,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     const double hwarm0 = C.hwarm;
     const double sens_w = loose ? A.sens_w : 1.0;
     int s = -2, nev = 0;
-    auto wgt = [&](int v) -> double { return v == IZ ? 1.0 : sens_w; };
+    auto wgt = [&](int v) -> double { return v == IZ ? 1.0 : sens_w; };      // (the J elements all weigh sens_w)
     auto gsum = [&](double part) -> double { return ff_wide_sum<NTHR>(s_red, s_red2, tid, part); };
 
 #pragma unroll 1
@@ -377,18 +402,20 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       double gy, g0, g1, g2;
       ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
+      const TJ gyJ = (TJ)gy, g0J = (TJ)g0, g1J = (TJ)g1, g2J = (TJ)g2;
       FF_STAMP(7);
       // ---------------------------------------------------------------- publish z, kbar, J (the stage J stays in registers:
       // it is the B operand of J' = A J)
-      double Jin[NVJ];
+      auto formJ = [&](int v) -> TJ { return ff_t_fma(g2J, c2J[v], ff_t_fma(g1J, c1J[v], ff_t_fma(g0J, c0J[v], gyJ * yJ[v]))); };
+      TJ Jin[NVJ];
 #pragma unroll
-      for (int v = 0; v < NVJ; v++) Jin[v] = form(v);
+      for (int v = 0; v < NVJ; v++) Jin[v] = formJ(v);
       const double kb_in = form(IK);
       if (own) { s_z[rp] = form(IZ); s_kb[rp] = kb_in; }
 #pragma unroll
       for (int K = 0; K < T; K++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = Jin[4 * K + v];
+        for (int v = 0; v < 4; v++) s_J[MMA::row(K, v, lg) * JS + 16 * w + lc] = Jin[4 * K + v];
       __syncthreads();
       FF_STAMP(0);
       // ---------------------------------------------------------------- R1, first half: radii, table rows requested
@@ -417,27 +444,27 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       }
       // ---------------------------------------------------------------- S = J J^T on the matrix cores (under the table fetch):
       // tiles (I, w) = sum_k J[16 I + i][k] J[16 w + j][k]; column blocks beyond M are zero and skipped
-      ff_d4 accS[T], accJ[T];
+      typename MMA::acc_t accS[T], accJ[T];
 #pragma unroll
       for (int I = 0; I < T; I++) {
-        const ff_d4 zero = {0.0, 0.0, 0.0, 0.0};
+        const typename MMA::acc_t zero = {0, 0, 0, 0};
         accS[I] = zero; accJ[I] = zero;
       }
       {
-        const double* Jb = &s_J[(16 * w + lc) * JS + lg];
-        const double* Ja = &s_J[lc * JS + lg];
+        const TJ* Jb = &s_J[(16 * w + lc) * JS + lg];
+        const TJ* Ja = &s_J[lc * JS + lg];
 #pragma unroll
         for (int K = 0; K < T; K++) {
           if (16 * K < M) {      // workgroup-uniform
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               const int ks = 4 * K + v;
-              const double bS = Jb[4 * ks];
-              double aS[T];
+              const TJ bS = Jb[4 * ks];
+              TJ aS[T];
 #pragma unroll
               for (int I = 0; I < T; I++) aS[I] = Ja[16 * I * JS + 4 * ks];
 #pragma unroll
-              for (int I = 0; I < T; I++) accS[I] = ff_mfma16(aS[I], bS, accS[I]);
+              for (int I = 0; I < T; I++) accS[I] = MMA::mma(aS[I], bS, accS[I]);
             }
           }
         }
@@ -484,7 +511,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
       for (int I = 0; I < T; I++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) s_J[(16 * I + 4 * v + lg) * JS + 16 * w + lc] = accS[I][v];   // ... whose place S takes
+        for (int v = 0; v < 4; v++) s_J[MMA::row(I, v, lg) * JS + 16 * w + lc] = accS[I][v];   // ... whose place S takes
       // ---------------------------------------------------------------- row lanes: own-row sums and row p of A
       double vi = 0.0, wk = 0.0, gdi = 0.0, Ad[D];
 #pragma unroll
@@ -497,12 +524,12 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         vi = fma(sg * f0, rcv, vi);
         wk = fma(sg, rec[QPW + rc], wk);
         gdi = fma(sg * rec[QGQ], rcv, gdi);
-        double* arow = &s_A[pdst[k]];
+        TJ* arow = &s_A[pdst[k]];
 #pragma unroll
         for (int c = 0; c < D; c++) {
           const double Bcc = fma(fc, rec[c], rc == c ? f0 : 0.0);
           Ad[c] += Bcc;
-          arow[c] = -Bcc;
+          arow[c] = (TJ)(-Bcc);
         }
       }
       vi = ff_quad_sum(vi); wk = ff_quad_sum(wk); gdi = ff_quad_sum(gdi);
@@ -512,26 +539,30 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         double adv = Ad[0];
 #pragma unroll
         for (int c = 1; c < D; c++) adv = (rs == c) ? Ad[c] : adv;
-        if (rs < D) s_A[rp * JS + ra * D + rs] = adv;                           // the diagonal block of particle ra, row rc
-        if (rs == 3) s_A[M * JS + rp] = -gdi;                                    // row M: (grad Delta)' = -g^T J
+        if (rs < D) s_A[rp * JS + ra * D + rs] = (TJ)adv;                       // the diagonal block of particle ra, row rc
+        if (rs == 3) s_A[M * JS + rp] = (TJ)(-gdi);                              // row M: (grad Delta)' = -g^T J
       }
       __syncthreads();
       FF_STAMP(3);
       // ---------------------------------------------------------------- J' = A J on the matrix cores: tiles (I, w) =
-      // sum_k A[16 I + i][k] J[k][16 w + j]; the B operand of k-step ks = 4 K + v is the lane's own Jin[ks]
+      // sum_k A[16 I + i][k] J[k][16 w + j]; the B operand of k-step (K, v) is the lane's own Jin[4 K + v], i.e. row MMA::row(K, v, g)
+      if constexpr (!F32 && T >= 4) {      // fp64 at four tiles: 32 registers are worth more than 64 FMAs -- the stage J is formed again
+#pragma unroll
+        for (int v = 0; v < NVJ; v++) { Jin[v] = formJ(v); }
+      }
       {
-        const double* Aa = &s_A[lc * JS + lg];
+        const TJ* Aa = &s_A[lc * JS + MMA::row_lane(lg)];
 #pragma unroll
         for (int K = 0; K < T; K++) {
           if (16 * K < M) {      // workgroup-uniform
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               const int ks = 4 * K + v;
-              double aJ[T];
+              TJ aJ[T];
 #pragma unroll
-              for (int I = 0; I < T; I++) aJ[I] = Aa[16 * I * JS + 4 * ks];
+              for (int I = 0; I < T; I++) aJ[I] = Aa[16 * I * JS + MMA::row_step(K, v)];
 #pragma unroll
-              for (int I = 0; I < T; I++) accJ[I] = ff_mfma16(aJ[I], Jin[ks], accJ[I]);
+              for (int I = 0; I < T; I++) accJ[I] = MMA::mma(aJ[I], Jin[ks], accJ[I]);
             }
           }
         }
@@ -557,8 +588,8 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
           double t = 0.0;
 #pragma unroll
           for (int c2i = 0; c2i < D; c2i++) {
-            double ww = s_J[(a * D + c) * JS + a * D + c2i];
-            if (pair) ww += s_J[(bb * D + c) * JS + bb * D + c2i] - s_J[(a * D + c) * JS + bb * D + c2i] - s_J[(a * D + c2i) * JS + bb * D + c];
+            double ww = (double)s_J[(a * D + c) * JS + a * D + c2i];
+            if (pair) ww += ((double)s_J[(bb * D + c) * JS + bb * D + c2i] - (double)s_J[(a * D + c) * JS + bb * D + c2i]) - (double)s_J[(a * D + c2i) * JS + bb * D + c];
             t = fma(ww, rho[c2i], t);
             if (c2i == c) tr += ww;
           }
@@ -575,7 +606,8 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       __syncthreads();
       FF_STAMP(5);
       // ---------------------------------------------------------------- second-order sums, right-hand side
-      double out[NV];
+      TJ outJ[NVJ];
+      double out[NVS];
       double qs = 0.0;
 #pragma unroll
       for (int k = 0; k < NPK; k++) qs = fma((prec[k] & 1) ? -1.0 : 1.0, s_rec[(prec[k] >> 1) + QPW + rc], qs);
@@ -583,13 +615,13 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
       for (int I = 0; I < T; I++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) out[4 * I + v] = accJ[I][v];
+        for (int v = 0; v < 4; v++) outJ[4 * I + v] = accJ[I][v];
       out[IZ] = own ? vi : 0.0;
       out[IK] = own ? wk + qs : 0.0;
       out[IDL] = -dsum;
       out[ILP] = -(qsum + (own ? gdi * kb_in : 0.0));
       FF_STAMP(6);
-      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
+      s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
       if (s == 99) break;
     }
     // -------------------------------------------------------------------- results
@@ -601,16 +633,16 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
     for (int K = 0; K < T; K++)
 #pragma unroll
-      for (int v = 0; v < 4; v++) s_J[(16 * K + 4 * v + lg) * JS + 16 * w + lc] = y[4 * K + v];
+      for (int v = 0; v < 4; v++) s_J[MMA::row(K, v, lg) * JS + 16 * w + lc] = yJ[4 * K + v];
     __syncthreads();
     // Jt[b][i][p] = dz_p/dx_i: wave w writes the rows i = w, w + T, ... as contiguous spans
     for (int i = w; i < M; i += T) {
-      if (l < M) A.Jt[(b * M + i) * M + l] = s_J[l * JS + i];
+      if (l < M) A.Jt[(b * M + i) * M + l] = (double)s_J[l * JS + i];
     }
     if (own) {
       A.y_out[b * M + rp] = y[IZ] + bad;
       A.kbar[b * M + rp] = y[IK];
-      A.dD[b * M + rp] = s_J[M * JS + rp];
+      A.dD[b * M + rp] = (double)s_J[M * JS + rp];
       A.Lpart[b * M + rp] = rp == 0 ? lapd : 0.0;
     }
     if (tid == 0) {
@@ -649,6 +681,13 @@ bool ff_wide_forced() {
   }
   return f == 1;
 }
+static std::atomic<int> g_sens_bits{64};
+static bool ff_wide_sens_fp32() { return g_sens_bits.load() == 32; }
+extern "C" int ff_set_sens_precision(int bits) {
+  const int prev = g_sens_bits.load();
+  g_sens_bits.store(bits == 32 ? 32 : 64);
+  return prev;
+}
 extern "C" int ff_set_kernel_family(int family) {
   const int prev = ff_wide_forced() ? 1 : 0;
   g_family.store(family == 1 ? 1 : 0);
@@ -683,8 +722,10 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
   const int64_t per_cu = T >= 3 ? 1 : (T == 2 ? 2 : 4);
   const int64_t cap = a.queue ? per_cu * wide_cus() : ((int64_t)1 << 20);
   const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
-  if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true>), grid, FF_WAVE * T, stream, a, n);
-  FF_LAUNCH((ff_wide_eloc_kernel<D, T, false>), grid, FF_WAVE * T, stream, a, n);
+  // single-precision sensitivities (ff_set_sens_precision(32)): the table kernel with J, A, S in fp32; its fallback stays fp64
+  if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float>), grid, FF_WAVE * T, stream, a, n);
+  else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double>), grid, FF_WAVE * T, stream, a, n);
+  FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double>), grid, FF_WAVE * T, stream, a, n);
 }
 
 int ff_wide_dispatch_fwd(int mode, void* stream, int n, int d, const ff_fwd_args& a) {

@@ -32,6 +32,12 @@ def set_kernel_family(family):
     return int(L.lib().ff_set_kernel_family(int(family)))
 
 
+def set_sens_precision(bits):
+    """ff_set_sens_precision: 64 (default) or 32 = single-precision sensitivity matrices in the matrix-core local-energy kernel
+    (11 particles and more).  Returns the previous setting."""
+    return int(L.lib().ff_set_sens_precision(int(bits)))
+
+
 def _state(ws):
     return None if ws is None else L.dev(ws, torch.int32, "walker_state")
 

@@ -84,6 +84,13 @@ const char* ff_last_error(void);
  * workgroup beyond (up to 24 particles, n d <= 60); 1 = one walker per workgroup for EVERY particle number (A/B and parity
  * testing; FF_WIDE=1 in the environment selects it at load time).  Returns the previous value. */
 int ff_set_kernel_family(int family);
+/* Precision of the SENSITIVITY matrices of the local-energy pass in the one-walker-per-workgroup kernels (J = dz/dx with the
+ * x-gradient of Delta, A = dv/dz, S = J J^T -- the operands of the two dense products per right-hand side): 64 (default) = fp64 on
+ * v_mfma_f64_16x16x4_f64; 32 = fp32 on v_mfma_f32_16x16x4_f32 at twice the rate and half the registers ("fp32 MFMA path" of
+ * BASELINE.json configs[4]).  Walker coordinates, radii, the radial functions, Delta, its Laplacian, the x-Laplacian of z and the
+ * whole finish stay fp64; E_loc then carries a relative error of ~1e-6 instead of ~1e-9 (printed by the tests).  No effect on the
+ * kernels of up to 10 particles.  Returns the previous value. */
+int ff_set_sens_precision(int bits);
 
 /* ---- many-body state enumeration (host code, no GPU) ------------------------------------------ */
 /* Orbitals.fermion_states (src/orbitals.py:33-54; the subset search of :14-31): all Slater-determinant states of nup

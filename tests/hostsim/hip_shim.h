@@ -147,6 +147,24 @@ inline ff_sim_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, ff_sim
   return c;
 }
 
+// v_mfma_f32_16x16x4_f32: register v of lane l holds C/D[4 (l / 16) + v][l % 16] (NOT the fp64 form's 4 v + l / 16)
+typedef float ff_sim_f4 __attribute__((vector_size(16)));
+static float ff_sim_mfma16f_a[1024], ff_sim_mfma16f_b[1024];
+inline ff_sim_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, ff_sim_f4 c, int, int, int) {
+  const int t = threadIdx.x, w0 = t & ~63, l = t & 63;
+  ff_sim_mfma16f_a[t] = a; ff_sim_mfma16f_b[t] = b;
+  __syncthreads();
+  for (int v = 0; v < 4; v++) {
+    const int i = 4 * (l / 16) + v, j = l % 16;
+    float acc = c[v];
+    for (int k = 0; k < 4; k++) acc = __builtin_fmaf(ff_sim_mfma16f_a[w0 + 16 * k + i], ff_sim_mfma16f_b[w0 + 16 * k + j], acc);
+    c[v] = acc;
+  }
+  __syncthreads();
+  return c;
+}
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+
 template <class K, class... A>
 inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   pthread_barrier_t bar;

@@ -203,3 +203,35 @@ def test_wide_direct_evaluation_equals_the_table_path(dev):
     np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-9)
     assert (np.abs(out[1][1] - out[0][1]) / np.abs(out[0][1])).max() < 1e-8
     np.testing.assert_allclose(out[1][2], out[0][2], atol=1e-8 * np.abs(out[0][2]).max())
+
+
+def test_config5_fp32_sensitivity_path_error_report(dev):
+    """ff_set_sens_precision(32): J, A = dv/dz and S = J J^T in fp32 on v_mfma_f32_16x16x4 (BASELINE.json configs[4]: "fp32 MFMA
+    path"), everything else fp64.  There is no reference for it (and none in fp64 for d = 3 beyond the oracle): the test REPORTS the
+    error of E_loc against the fp64 kernels on the same walkers and bounds it loosely -- two decades above what was measured."""
+    from fermiflow_amd import native
+    model = _model3d(dev, 10, 10, 2.0, False)
+    v = model.cnf.v_wrapper.v
+    torch.manual_seed(8)
+    B = 8192
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    net = v.net(refresh=True)
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8)
+    tu, td = model._tables(dev)
+    out = {}
+    for bits in (64, 32):
+        prev = native.set_sens_precision(bits)
+        try:
+            r = native.eloc(tu, td, 10, 10, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True)
+            assert int(r["stats"][3]) == 0
+            out[bits] = (r["eloc"].clone(), r["grad"].clone(), int(r["stats"][0]))
+        finally:
+            native.set_sens_precision(prev)
+    rel = ((out[32][0] - out[64][0]) / out[64][0]).abs()
+    gerr = (out[32][1] - out[64][1]).abs().max().item() / out[64][1].abs().max().item()
+    q = torch.quantile(rel, torch.tensor([0.5, 0.999], dtype=torch.float64, device=dev))
+    print(f"[fp32 sensitivities, config 5] E_loc rel. error vs fp64: median {q[0].item():.2e}, p99.9 {q[1].item():.2e}, max {rel.max().item():.2e}; "
+          f"grad logp {gerr:.2e} of its largest entry; RHS evaluations {out[32][2] / B:.2f} (fp64: {out[64][2] / B:.2f}) per walker; "
+          f"mean E_loc {out[32][0].mean().item():.6f} vs {out[64][0].mean().item():.6f}")
+    assert q[0].item() < 1e-4 and rel.max().item() < 1e-2 and gerr < 1e-4
+    assert abs(out[32][0].mean().item() / out[64][0].mean().item() - 1) < 1e-5

@@ -15,6 +15,9 @@ gs = Gm._model(dev, 2, 2, 2.0)
 orb = ff.HO3D() if d == 3 else ff.HO2D()
 model = ff.GSVMC(nup, ndn, orb, ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
 model.prefetch_walkers = False
+if os.environ.get("FF_SENS_BITS"):
+    from fermiflow_amd import native
+    native.set_sens_precision(int(os.environ["FF_SENS_BITS"]))
 torch.manual_seed(0)
 for it in range(iters):
     model.profile = {}
