@@ -48,6 +48,7 @@ FLOP_ADJ_RADIUS = 85            # tabulated adjoint: 45 heads + 40 record and ow
 FLOP_ADJ_LANE = 18              # own-row gather per coordinate
 FLOP_MCMC_STEP_PER_PARTICLE = 50    # proposal, Hermite recurrences, one row of the determinant update, accept (per particle of a walker-step)
 PEAK_FP64_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (vendor)
+PEAK_FP32_TFLOPS = 157.3        # MI355X fp32 matrix = fp32 vector peak (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at 64 FLOP/clk/SIMD)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -100,7 +101,8 @@ def eloc_flop_per_eval(kind, n, H, radial, d=2):
 
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_INSTS_VALU"),
-              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES"))
+              ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES"),
+              ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES"))
 
 
 def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
@@ -151,6 +153,9 @@ def main():
     ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12), 131072 (c5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --walkers-per-gpu walkers on EVERY GPU; strong: that many walkers in total, split over the GPUs")
+    ap.add_argument("--sens-bits", type=int, default=0, choices=[0, 32, 64],
+                    help="precision of the sensitivity matrices J, A, S in the matrix-core local-energy kernel (11 particles and more): "
+                         "64, or 32 = the fp32 MFMA path BASELINE.json configs[4] names; default: 32 for --workload c5, 64 otherwise")
     ap.add_argument("--trained-iters", type=int, default=300,
                     help="untimed training iterations at lr 1e-4 in front of the second timed leg (0 = no second leg)")
     ap.add_argument("--nup", type=int, default=0)
@@ -217,6 +222,8 @@ def main():
         model.to(dev)
     else:
         model = gs
+    sens_bits = args.sens_bits or (32 if wl == "c5" else 64)
+    native.set_sens_precision(sens_bits)
     from fermiflow_amd.utils import make_adam
     opt = make_adam(model.parameters(), lr=args.lr)
     if args.scaling == "strong":      # fixed global batch: every rank takes 1 / n_gpus of it
@@ -305,14 +312,21 @@ def main():
     kind, kname = eloc_kernel_name(n, dim)
     flop_per_eval = eloc_flop_per_eval(kind, n, H, radial, dim)
     achieved = evals * flop_per_eval / (k_ms * 1e-3) / 1e12
+    f32_path = kind == "wide" and sens_bits == 32 and (n * dim + 4 + 15) // 16 >= 2
+    if f32_path:
+        kname = kname.replace("true>", "true, float>")
+    elif kind == "wide":
+        kname = kname.replace("true>", "true, double>")
+    peak = PEAK_FP32_TFLOPS if f32_path else PEAK_FP64_TFLOPS
     roofline = {"kernel": kname + " (local-energy sensitivities)",
                 "bound": "mfma" if kind in ("mfma", "wide") else "fp64-valu",
-                "note": ("one walker per workgroup; J' = A J and S = J J^T on v_mfma_f64_16x16x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
+                "note": ("one walker per workgroup; J' = A J and S = J J^T on " + ("v_mfma_f32_16x16x4 (fp32 sensitivity matrices: priced against the fp32 "
+                         "matrix peak)" if f32_path else "v_mfma_f64_16x16x4") + " (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
                          if kind == "wide" else "runs on v_mfma_f64_4x4x4 + fp64 VALU" if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
-                        "; peak = MI355X fp64 vector = fp64 matrix peak",
-                "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
+                        ("; peak = MI355X fp32 matrix peak" if f32_path else "; peak = MI355X fp64 vector = fp64 matrix peak"),
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / wpg,
                 "flop_per_walker_eval": flop_per_eval, "radial_functions": radial,
                 "algorithmic_bytes": wpg * 8 * (M + M * M + 4 * M + 1)}
@@ -320,7 +334,7 @@ def main():
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",
            "value": B_glob * 100 * args.steps / dt, "unit": "walker-steps/s", "n_gpus": n_gpus, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f64" if not f32_path else "f64 (sensitivity matrices J, A, S of the local-energy pass: f32)", "data": "synthetic",
            "config": {"workload": ("BetaVMC beta=10 boltzmann deltaE=2 " if wl == "beta" else "GSVMC ") +
                                   f"nup={nup} ndown={ndown} {dim}D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8 "
                                   f"(sensitivity components of walkers with flow cost class <= {model.sens_tol_class}: x{model.sens_tol:g}; "
@@ -415,7 +429,7 @@ def main():
         if not args.no_pmc and os.environ.get("FF_BENCH_CHILD") != "1":
             os.environ["FF_BENCH_CHILD"] = "1"
             argv = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--lr", str(args.lr), "--nup", str(nup),
-                    "--ndown", str(ndown)]
+                    "--ndown", str(ndown), "--sens-bits", str(sens_bits)]
             ctr, why = pmc_counters(kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0], argv)
             if ctr is None:
                 roofline["traffic_source"] = f"unavailable: {why}"
@@ -432,6 +446,10 @@ def main():
                     roofline["lds_bank_conflict"] = ctr.get("SQ_LDS_BANK_CONFLICT", 0.0) / ctr["SQ_LDS_IDX_ACTIVE"]
                 if "SQ_INSTS_VALU_MFMA_MOPS_F64" in ctr:
                     roofline["mfma_mops_f64"] = ctr["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+                if "SQ_INSTS_VALU_MFMA_MOPS_F32" in ctr:
+                    roofline["mfma_mops_f32"] = ctr["SQ_INSTS_VALU_MFMA_MOPS_F32"]
+                if ctr.get("SQ_VALU_MFMA_BUSY_CYCLES"):      # share of the launch's SIMD-cycles (1024 SIMDs at 2.4 GHz) the matrix pipes work
+                    roofline["mfma_busy"] = ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / (k_ms * 1e-3 * 2.4e9 * 1024)
         # ---- CPU baseline: the oracle's full sweep on the host cores, bounded sample
         if args.cpu_walkers > 0 and wl not in ("beta", "c5"):
             from oracle import oracle as O
