@@ -168,7 +168,9 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
                     double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
   constexpr int NS = FF_MAX_NS;
   __shared__ double s_row[4][NS];
-  __shared__ int s_orb[4][NS];
+  __shared__ int s_deg[4][NS][D];               // Hermite degrees of the group's orbitals
+  __shared__ double s_h[FF_WAVE][D][8];         // per lane: h_0..h_7 of each coordinate of its particle
+  __shared__ int s_md;
   const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
   const int64_t gid = (int64_t)blockIdx.x * 4 + grp;
   int64_t b = gid >> 1;
@@ -179,44 +181,71 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
   const int ns = sp ? ndn : nup, off = sp ? nup : 0;
   const int st = wstate ? wstate[b] : 0;
   const bool mine = r < ns;
-  if (mine) s_orb[grp][r] = ((sp ? tab_dn : tab_up) + st * ns)[r];
+  if (lane == 0) s_md = 0;
   __syncthreads();
+  if (mine) {
+    const int k = ((sp ? tab_dn : tab_up) + st * ns)[r];
+    int dg[3] = {0, 0, 0};
+    if constexpr (D == 2) ff_orb_decode(k, dg[0], dg[1]); else ff_ho3d_decode(k, dg[0], dg[1], dg[2]);
+    int mx = 0;
+#pragma unroll
+    for (int c = 0; c < D; c++) { s_deg[grp][r][c] = dg[c]; mx = dg[c] > mx ? dg[c] : mx; }
+    atomicMax(&s_md, mx);
+  }
+  __syncthreads();
+  const int md = FF_UNIFORM(s_md);               // largest Hermite degree in the workgroup (scalar loop bound)
   const uint64_t wid = (uint64_t)(woff + b);
   const int i0 = D * (off + (mine ? r : 0));      // this lane's first coordinate
   const int nsmax = nup > ndn ? nup : ndn;
 
-  // log|det| of the species' matrix at the positions xx (this lane's particle); identical on all lanes of the group
+  // log|det| of the species' matrix at the positions xx (this lane's particle); identical on all lanes of the group.
+  // Orbitals: the normalised Hermite functions of every coordinate once per call (three-term recurrence, as the register-resident
+  // samplers of ff_walkers.hip), phi_j = gauss * prod_c h_{deg_j,c}(x_c).  LU with partial pivoting without moving rows; the
+  // pivot of a column is found by ONE 32-bit maximum over the group's 16 lanes (DPP): key = |entry| rounded to float with the lane
+  // index in the low four bits (equal keys: the lower lane) -- a pivot that is within 2^-19 of the largest entry instead of the
+  // largest changes the rounding of log|det|, not its value.  |det| is the product of the pivots (one log per determinant).
   auto logabsdet = [&](const double* xx) -> double {
     double A[NS];
     double gs;
     if constexpr (D == 2) gs = ff_gauss2d(xx[0], xx[1]); else gs = ff_gauss3d(xx);
 #pragma unroll
+    for (int c = 0; c < D; c++) {
+      double hm = 1.0, h = FF_REC_A[0] * xx[c];
+      s_h[lane][c][0] = 1.0;
+      s_h[lane][c][1] = h;
+      for (int m = 1; m < md; m++) {
+        const double hn = fma(FF_REC_A[m] * xx[c], h, -FF_REC_B[m] * hm);
+        hm = h;
+        h = hn;
+        s_h[lane][c][m + 1] = h;
+      }
+    }
+#pragma unroll
     for (int j = 0; j < NS; j++) {
       double v = 0.0;
       if (j < ns) {
-        if constexpr (D == 2) ff_orbital<false>(s_orb[grp][j], xx[0], xx[1], gs, v, nullptr, nullptr);
-        else { double lp; ff_orbital3d<false>(s_orb[grp][j], xx, gs, v, nullptr, lp); }
+        v = gs;
+#pragma unroll
+        for (int c = 0; c < D; c++) v *= s_h[lane][c][s_deg[grp][j][c]];
       }
       A[j] = v;
     }
-    double acc = 0.0;
+    double prod = 1.0;
     bool used = !mine;
 #pragma unroll
     for (int c = 0; c < NS; c++) {
       if (c >= nsmax) break;        // (kernel-uniform)
       const bool act = c < ns;      // (uniform within the group)
-      double best = (!used && act) ? fabs(A[c]) : -1.0;
-      int who = r;
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        const double ob = ff_lane_read(best, lane ^ m);
-        const int ow = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, who);
-        const bool take = ob > best || (ob == best && ow < who);
-        best = take ? ob : best;
-        who = take ? ow : who;
+      unsigned key = (!used && act) ? ((__float_as_uint((float)fabs(A[c])) & ~15u) | (unsigned)(15 - r)) : 0u;
+      {
+        unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xF, 0xF, true); key = o > key ? o : key;      // lane ^ 1
+        o = (unsigned)__builtin_amdgcn_mov_dpp((int)key, 0x4E, 0xF, 0xF, true); key = o > key ? o : key;               // lane ^ 2
+        o = (unsigned)__builtin_amdgcn_mov_dpp((int)key, 0x124, 0xF, 0xF, true); key = o > key ? o : key;              // row_ror:4
+        o = (unsigned)__builtin_amdgcn_mov_dpp((int)key, 0x128, 0xF, 0xF, true); key = o > key ? o : key;              // row_ror:8
       }
+      const int who = 15 - (int)(key & 15u);
       const double piv = ff_lane_read(A[c], (lane & ~15) | who);
-      if (act) acc += log(fabs(piv));
+      if (act) prod *= piv;
       const bool ispiv = act && who == r && !used;
       if (ispiv) {
 #pragma unroll
@@ -225,19 +254,13 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
       }
       __syncthreads();
       if (act && !used) {
-        if constexpr (D == 2) {
-          const double ip = 1.0 / piv, f = A[c] * ip;
+        const double f = A[c] * ff_rcp(piv);
 #pragma unroll
-          for (int j = 0; j < NS; j++) { if (j > c) A[j] = fma(-f, s_row[grp][j], A[j]); }
-        } else {
-          const double f = A[c] / piv;
-#pragma unroll
-          for (int j = 0; j < NS; j++) { if (j > c) A[j] = A[j] - f * s_row[grp][j]; }
-        }
+        for (int j = 0; j < NS; j++) { if (j > c) A[j] = fma(-f, s_row[grp][j], A[j]); }
       }
       __syncthreads();
     }
-    return acc;
+    return log(fabs(prod));
   };
   // log p of the walker = 2 (log|det up| + log|det down|): the two groups of a walker exchange their sums
   auto logprob = [&](const double* xx) -> double {

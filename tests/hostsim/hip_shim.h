@@ -84,6 +84,7 @@ inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline unsigned long long wall_clock64() {      // 100 MHz, as the GPU's constant clock
   return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }
@@ -94,7 +95,8 @@ inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) {
   const unsigned t = threadIdx.x;
   ff_sim_xlane_buf[t] = v;
   __syncthreads();
-  const int o = ff_sim_xlane_buf[(t & ~3u) | ((ctrl >> (2 * (t & 3))) & 3)];
+  const int o = (ctrl >= 0x121 && ctrl <= 0x12F) ? ff_sim_xlane_buf[(t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15)]      // row_ror:n within 16 lanes
+                                                 : ff_sim_xlane_buf[(t & ~3u) | ((ctrl >> (2 * (t & 3))) & 3)];
   __syncthreads();
   return o;
 }
