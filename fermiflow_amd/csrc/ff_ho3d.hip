@@ -637,6 +637,89 @@ ff_eloc_contract3d_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, co
   }
 }
 
+// The same contraction for walkers that fill a wave alone (M = 3 n > 32; BASELINE configs[4]: M = 60): ONE WALKER PER WORKGROUP
+// of four waves, FOUR lanes per direction i -- they split the particles a of the Hessian sum and the components k of g0 . u_i
+// (quad reductions by DPP).  The one-wave version above walks 2 x 10 x 10 (a, c) pairs per lane back to back, each a handful of
+// dependent LDS reads, with three waves resident per CU (42 KB of LDS each): 10.5 ms per 131 072 walkers at 20 particles.
+__global__ void __launch_bounds__(4 * FF_WAVE)
+ff_wide_contract3d_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, const double* __restrict__ x,
+                          const double* __restrict__ Q, const double* __restrict__ Jt, const double* __restrict__ kbar,
+                          const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
+                          double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
+                          double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
+  FF_DYN_LDS(ff_fin4_lds);
+  const int n = nup + ndn, M = 3 * n;
+  const int nq = M + 6 * n + 3 * (nup * nup + ndn * ndn) + 2;
+  const int tid = threadIdx.x, i = tid >> 2, s = tid & 3;
+  const bool valid = i < M;
+  double* const s_u = ff_fin4_lds;                           // [i][k] = dz_k/dx_i
+  double* const s_q = s_u + M * M;
+  double* const s_x = s_q + nq;
+  double (*const s_red)[FF_WAVE] = (double (*)[FF_WAVE])(s_x + FF_WAVE);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int e = tid; e < M * M; e += 4 * FF_WAVE) s_u[e] = Jt[b * M * M + e];
+    for (int e = tid; e < nq; e += 4 * FF_WAVE) s_q[e] = Q[b * nq + e];
+    if (tid < M) s_x[tid] = x[b * M + tid];
+    __syncthreads();
+    const double* u = s_u + (valid ? i : 0) * M;
+    const double* g0 = s_q;
+    double gi = 0.0, hq = 0.0;
+    for (int k = s; k < M; k += 4) gi = fma(g0[k], u[k], gi);
+    for (int sp = 0; sp < 2; sp++) {
+      const int ns = sp ? ndn : nup, off = sp ? nup : 0;
+      const double* T = s_q + M + 6 * n + (sp ? 3 * nup * nup : 0);
+      double q = 0.0;
+      for (int a = s; a < ns; a += 4) {
+        const double* ua = u + 3 * (off + a);
+        const double* Sa = s_q + M + 6 * (off + a);
+        q += ua[0] * ua[0] * Sa[0] + 2.0 * ua[0] * ua[1] * Sa[1] + 2.0 * ua[0] * ua[2] * Sa[2] + ua[1] * ua[1] * Sa[3]
+           + 2.0 * ua[1] * ua[2] * Sa[4] + ua[2] * ua[2] * Sa[5];
+        for (int c = 0; c < ns; c++) {
+          const double* uc = u + 3 * (off + c);
+          double Wac = 0.0, Wca = 0.0;
+#pragma unroll
+          for (int cm = 0; cm < 3; cm++) {
+            Wac = fma(ua[cm], T[cm * ns * ns + a * ns + c], Wac);
+            Wca = fma(uc[cm], T[cm * ns * ns + c * ns + a], Wca);
+          }
+          q -= Wac * Wca;
+        }
+      }
+      hq += 2.0 * q;
+    }
+    gi += ff_swap1(gi); gi += ff_swap2(gi);
+    hq += ff_swap1(hq); hq += ff_swap2(hq);
+    double lap_i = 0.0, v_i = 0.0, g2 = 0.0;
+    if (valid && s == 0) {
+      gi -= dD[b * M + i];
+      lap_i = hq - Lpart[b * M + i] + g0[i] * kbar[b * M + i];
+      if (i % 3 == 0) {     // the lane of particle a's x-coordinate takes a's trap term and its pairs with the later particles
+        const int a = i / 3;
+        double pair = 0.0;
+        for (int c = a + 1; c < n; c++) {
+          const double dx = s_x[3 * a] - s_x[3 * c], dy = s_x[3 * a + 1] - s_x[3 * c + 1], dz = s_x[3 * a + 2] - s_x[3 * c + 2];
+          pair += Zc / sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        v_i = pair + (use_ho ? 0.5 * (s_x[3 * a] * s_x[3 * a] + s_x[3 * a + 1] * s_x[3 * a + 1] + s_x[3 * a + 2] * s_x[3 * a + 2]) : 0.0);
+      }
+      g2 = gi * gi;
+      if (grad) grad[b * M + i] = gi;
+      if (glogp0) glogp0[b * M + i] = g0[i];
+      s_red[0][i] = g2; s_red[1][i] = lap_i; s_red[2][i] = v_i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double g2s = 0.0, lapv = 0.0, Vv = 0.0;
+      for (int k = 0; k < M; k++) { g2s += s_red[0][k]; lapv += s_red[1][k]; Vv += s_red[2][k]; }
+      if (logp) logp[b] = (s_q[nq - 2] + s_q[nq - 1]) - delta[b];
+      if (lap) lap[b] = lapv;
+      if (V) V[b] = Vv;
+      if (eloc) eloc[b] = -0.25 * lapv - 0.125 * g2s + Vv;
+    }
+  }
+}
+
 // =================================================================================================
 extern void ff_set_error(const char* msg);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
@@ -703,7 +786,12 @@ int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* t
   const size_t M = (size_t)n * 3;
   ff_eloc_ws w = ff_eloc_carve((void*)workspace, B, (size_t)n, 3);
   if (ff_slater_rows_launch(stream, 3, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q) != FF_OK) return FF_ELAUNCH;
-  {
+  if (3 * n > 32) {      // a walker per workgroup, four lanes per direction
+    const size_t lds = sizeof(double) * ((size_t)9 * n * n + (size_t)(3 * n + 6 * n + 3 * (nup * nup + ndn * ndn) + 2) + 4 * FF_WAVE);
+    FF_LAUNCH_LDS(ff_wide_contract3d_kernel, (unsigned)(B < 65536 ? B : 65536), 4 * FF_WAVE, lds, stream, B, nup, ndn, Z, use_ho, x,
+                  (const double*)w.Q, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
+                  (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+  } else {
     const int Gf = FF_WAVE / (3 * n);
     const int64_t ng = (B + Gf - 1) / Gf;
     FF_LAUNCH_LDS(ff_eloc_contract3d_kernel, (unsigned)(ng < 32768 ? ng : 32768), FF_WAVE, ff_contract3d_lds_bytes(nup, ndn), stream, B, nup, ndn, Z,
