@@ -5,14 +5,16 @@
 
 Same flags, same objects, same loop; under torch.distributed (one process per GPU, RCCL) `--batch` is the global
 walker count and every rank works on its shard (fermiflow_amd/dist.py).  `--save/--resume` add the
-state_dict checkpoint the reference lacks.
+state_dict checkpoint the reference lacks; `--dim 3` the three-dimensional trap (HO3D orbitals: BASELINE.json configs[4] is
+`--dim 3 --nup 10 --ndown 10 --sens_bits 32`), `--sens_bits 32` the single-precision sensitivity matrices of the matrix-core
+local-energy kernel (11 particles and more; include/fermiflow.h, ff_set_sens_precision).
 """
 import os
 import time
 
 import torch
 
-from . import HO2D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, GSVMC, checkpoint
+from . import HO2D, HO3D, FreeFermion, MLP, Backflow, CNF, HO, CoulombPairPotential, GSVMC, checkpoint, native
 from .utils import make_adam
 
 
@@ -30,6 +32,9 @@ def main(argv=None):
     parser.add_argument("--t1", type=float, default=1.0, help="ending time")
     parser.add_argument("--iternum", type=int, default=1000, help="number of new iterations")
     parser.add_argument("--batch", type=int, default=8000, help="batch size (global, over all ranks)")
+    parser.add_argument("--dim", type=int, default=2, choices=[2, 3], help="space dimension of the trap (not in the reference: 2 only)")
+    parser.add_argument("--sens_bits", type=int, default=64, choices=[32, 64],
+                        help="precision of the sensitivity matrices of the local-energy pass from 11 particles on (not in the reference)")
     parser.add_argument("--save", type=str, default=None, help="checkpoint file written after every iteration")
     parser.add_argument("--resume", type=str, default=None, help="checkpoint file to resume from")
     args = parser.parse_args(argv)
@@ -43,7 +48,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend="nccl", device_id=device)
 
-    orbitals = HO2D()
+    orbitals = HO2D() if args.dim == 2 else HO3D()
+    native.set_sens_precision(args.sens_bits)
     basedist = FreeFermion(device=device)
     eta = MLP(1, args.Deta)
     eta.init_zeros()

@@ -235,3 +235,19 @@ def test_config5_fp32_sensitivity_path_error_report(dev):
           f"mean E_loc {out[32][0].mean().item():.6f} vs {out[64][0].mean().item():.6f}")
     assert q[0].item() < 1e-4 and rel.max().item() < 1e-2 and gerr < 1e-4
     assert abs(out[32][0].mean().item() / out[64][0].mean().item() - 1) < 1e-5
+
+
+def test_driver_runs_the_three_dimensional_trap(dev, capsys):
+    """the drop-in driver with --dim 3 (HO3D orbitals) and --sens_bits 32: BASELINE.json configs[4]'s command line at a small batch;
+    zero-initialised flow (the driver's default, src/FermionHO2D.py:40-43) -> the first iteration's E is the free-fermion value plus
+    the Coulomb energy, finite, and training moves it."""
+    from fermiflow_amd import FermionHO2D, native
+    try:
+        torch.manual_seed(2)
+        FermionHO2D.main(["--dim", "3", "--nup", "10", "--ndown", "10", "--Z", "0.5", "--batch", "1024", "--iternum", "2", "--sens_bits", "32"])
+    finally:
+        native.set_sens_precision(64)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("iter:")]
+    assert len(lines) == 2
+    E = [float(ln.split("E:")[1].split()[0]) for ln in lines]
+    assert all(np.isfinite(E)) and 60.0 < E[0] < 120.0 and E[0] != E[1]
