@@ -67,10 +67,12 @@ FF_D void ff_wadj_seeds(const ff_adj_args& A, int64_t b, int M, int lane, bool o
 //               of the owning workgroup) -- a rejected one just clears it.
 // Deposits are partitioned by NODE: wave w adds the records whose node j has j % W == w, every wave scanning all radii
 // -- no two waves touch the same row, lanes of a wave add in lane order: a fixed summation order, bit-reproducible.
-// A radius beyond the LDS table (r >= 8) raises off_table: the direct kernel redoes the call (tail of |psi|^2: ~never).
+// A deposit beyond the LDS table (r >= 8: a few per sweep at 131 072 walkers of 20 particles) is parked in a short LDS list and
+// goes to the launch's global overflow table (atomics, as in the narrow kernel) when its step is accepted; r >= 32 raises off_table.
 // ~100 registers and 66 KB of LDS: two workgroups per CU (the register-resident version: 416 registers, one workgroup, 52 ms
 // per 131 072 walkers of 20 particles).
 struct __attribute__((aligned(16))) ff_wdep { double dr, ca, cb; int j, t; };
+#define FF_WOVL 48      // deposits of one step on nodes beyond the LDS table that the overflow list holds (more: the direct kernel redoes the call)
 
 template <int D, int W, int NQ>
 __global__ void __launch_bounds__(FF_WAVE * W, 2)
@@ -84,6 +86,8 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   __shared__ double s_T[RCAP][3 * D];
   __shared__ ff_wdep s_dep[2][RCAP];
   __shared__ double s_Tt[2][FF_DEP_NLDS][FF_DEP_LROW];
+  __shared__ ff_wdep s_ovl[FF_WOVL];       // the step's deposits on nodes beyond the LDS table (r >= 8), weights folded in
+  __shared__ int s_novl;
   __shared__ int s_st[4];
 
   const int lane = threadIdx.x, wv = lane / FF_WAVE;
@@ -92,6 +96,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   for (int e = lane; e < RCAP * 3 * D; e += NTHR) (&s_T[0][0])[e] = 0.0;
   for (int e = lane; e < 2 * RCAP; e += NTHR) { ff_wdep z = {0.0, 0.0, 0.0, 0, -1}; (&s_dep[0][0])[e] = z; }
   if (lane < 4) s_st[lane] = 0;
+  if (lane == 0) s_novl = 0;
   __syncthreads();
   const bool has_mu = A.net.Hm > 0;
   const int nrad = has_mu ? P + n : P;
@@ -99,6 +104,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   int rq_id[NQ];
 #pragma unroll
   for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * NTHR, nrad);
+  double* const ovf = A.trows + (size_t)gridDim.x * NE;      // nodes beyond the LDS tables: one global table [2][NTOT][ROW], atomics
   // coordinate p = lane / 4: its four lanes split the partners of p's particle (quad reduction); lane 4 p owns z_p, a_p
   const int rp = lane >> 2, rs = lane & 3;
   const bool rowlane = rp < M;
@@ -131,13 +137,18 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
         if (q < nrad) {
           const ff_wdep rc = s_dep[buf][q];
           if (rc.t >= 0 && (rc.j % W) == wv) {
-            double pk = 1.0, pm = 0.0;
-            double* row = &s_Tt[rc.t][rc.j][0];
+            if (rc.j >= FF_DEP_NLDS) {      // beyond the LDS table (rare): parked until the step is accepted
+              const int pos = atomicAdd(&s_novl, 1);
+              if (pos < FF_WOVL) { ff_wdep o = rc; o.ca *= w; o.cb *= w; s_ovl[pos] = o; }
+            } else {
+              double pk = 1.0, pm = 0.0;
+              double* row = &s_Tt[rc.t][rc.j][0];
 #pragma unroll
-            for (int k = 0; k < FF_DEP_ROW; k++) {
-              atomicAdd(row + k, w * fma(rc.ca, pk, rc.cb * pm));
-              pm = pk;
-              pk = pk * rc.dr * (1.0 / (k + 1));
+              for (int k = 0; k < FF_DEP_ROW; k++) {
+                atomicAdd(row + k, w * fma(rc.ca, pk, rc.cb * pm));
+                pm = pk;
+                pk = pk * rc.dr * (1.0 / (k + 1));
+              }
             }
           }
         }
@@ -175,7 +186,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
         const bool ok = ff_heads_table<3>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, r, hd);
         hd[0] = ok ? hd[0] : 0.0; hd[1] = ok ? hd[1] : 0.0; hd[2] = ok ? hd[2] : 0.0;
         double jf = rint(r * FF_DEP_INVH);
-        const bool on = jf <= (double)(FF_DEP_NLDS - 1);           // (false for NaN too)
+        const bool on = jf <= (double)(FF_DEP_NTOT - 1);           // (false for NaN too)
         if (act && (!ok || !on)) off_any = true;                    // beyond either table: the direct kernel redoes the call
         ff_wdep rc;
         rc.j = on ? (int)jf : 0;
@@ -225,6 +236,22 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
           if (acc) Wg[e] += *tt;
           *tt = 0.0;
         }
+        __syncthreads();
+        const int novl = s_novl;
+        if (novl > FF_WOVL) off_any = true;                          // more far deposits than the list holds: redo by the direct kernel
+        if (acc && lane < novl && lane < FF_WOVL) {
+          const ff_wdep rc = s_ovl[lane];
+          double pk = 1.0, pm = 0.0;
+          double* row = ovf + ((size_t)rc.t * FF_DEP_NTOT + rc.j) * FF_DEP_ROW;
+#pragma unroll
+          for (int k = 0; k < FF_DEP_ROW; k++) {
+            atomicAdd(row + k, fma(rc.ca, pk, rc.cb * pm));
+            pm = pk;
+            pk = pk * rc.dr * (1.0 / (k + 1));
+          }
+        }
+        __syncthreads();
+        if (lane == 0) s_novl = 0;
         if (acc) cur ^= 1;                                           // FSAL: the stage-6 records open the next step
       }
       if (s == 99) break;

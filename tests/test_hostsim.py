@@ -618,3 +618,27 @@ def test_one_walker_per_workgroup_kernels(nup, ndn, d, B, force):
             np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
     finally:
         S.lib().ff_set_kernel_family(prev)
+
+
+def test_wide_adjoint_far_radii_take_the_overflow_list():
+    """A pair 9-10 apart lies beyond the LDS part of the wide adjoint's deposit table (r >= 8): its deposits wait in the step's
+    overflow list and reach the launch's global table when the step is accepted -- same gradient as the oracle's, and the tabulated
+    kernel (not the direct fallback) must have served the call (same RHS-evaluation count as with the pair close)."""
+    rng = np.random.default_rng(3)
+    He = Hm = 8
+    eta = [rng.normal(size=He) * 0.5, rng.normal(size=He) * 0.3, rng.normal(size=He) * 0.05]
+    mu = [rng.normal(size=Hm) * 0.5, rng.normal(size=Hm) * 0.3, rng.normal(size=Hm) * 0.05]
+    z = rng.normal(size=(2, 3, 2)) * 0.7
+    z[1, 0, 0] += 9.5
+    onet = O.Net(eta, mu)
+    dl = np.zeros(2)
+    az, ad = rng.normal(size=z.shape), rng.normal(size=2)
+    gxo, gpo, _ = O.cnf_adjoint(z, dl, az, ad, onet, rtol=1e-11, atol=1e-13)
+    prev = S.lib().ff_set_kernel_family(1)
+    try:
+        gx, gp, st = S.cnf_adjoint(z, az, ad, S.Net(eta, mu, table=True), rtol=1e-8, atol=1e-10)
+    finally:
+        S.lib().ff_set_kernel_family(prev)
+    assert st[3] == 0
+    np.testing.assert_allclose(gx, gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
+    np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
