@@ -73,371 +73,45 @@ ff_ode_adj_kernel(ff_adj_args A) {
   __shared__ int s_pa[R], s_pb[R], s_any;
   __shared__ double s_e2[64];
 
-  const int lane = threadIdx.x;
-  const int g = lane / M, i = lane % M;
-  const bool ingrp = g < G;
-  const int gg = ingrp ? g : 0;
-  const int ai = i / D, ci = i % D;
-
-  ff_load_weights(s_w, A.net, lane);
-  ff_fill_exp2_table(s_e2, lane);
-  if (lane == 0) {
-    int p = 0;
-    for (int a = 0; a < N; a++)
-      for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
-    for (int a = 0; a < N; a++) { if (P + a < R) { s_pa[P + a] = a; s_pb[P + a] = -1; } }
-  }
-  __syncthreads();
-  const int He = A.net.He, Hm = A.net.Hm;
-  const bool has_mu = Hm > 0;
-  const int nrad = has_mu ? (P + N) : P;
-  const double rtol = A.rtol, atol = A.atol;
-  constexpr double NT = 2 * M;
-  const int64_t ngroups = (A.B + G - 1) / G;
   __shared__ int s_st[4];   // ODE statistics of this workgroup's walkers (LDS: nothing loop-carried in registers)
-  if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
+#include "ff_adj_direct_body.inc"
+}
 
-  // This lane's slice of the parameter-gradient row of (workgroup, group-slot): entries of its own units only,
-  // so accepted steps are added with plain (non-atomic) read-modify-writes; the API zeroes the rows first.
-  double* const myrow = A.rows + ((int64_t)blockIdx.x * G + (ingrp ? g : 0)) * (3 * He + 3 * Hm);
-  constexpr int UC = M * MAXU;                 // hidden units per gradient chunk
-  const int unit0 = A.unit0;
-  const int nchunks = ((He > Hm ? He : Hm) + UC - 1) / UC;
-  auto row_add = [&](int t, int j, int c, double v) {
-    const int k = unit0 + i + j * M, H = t ? Hm : He;
-    if (ingrp && k < H) myrow[(t ? 3 * He : 0) + c * H + k] += v;
-  };
+// LDS of the direct-evaluation kernel as one struct, for the instantiation below that places it in dynamic LDS
+template <int N, int D>
+struct ff_adj_smem {
+  static constexpr int M = ff_geom<N, D>::M, G = ff_geom<N, D>::G, R = ff_geom<N, D>::RA, CH = 8;
+  ff_wtab s_w[2][FF_HPAD];
+  double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G];
+  double s_rad[G][R], s_rinv[G][R], s_ca[G][R], s_cb[G][R];
+  double s_ph[G][M][CH][3], s_hd[G][R][3];
+  double s_e2[64];
+  int s_pa[R], s_pb[R], s_any, s_st[4];
+};
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t bq = grp * G + g;
-    const bool valid = ingrp && bq < A.B;
-    const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
-    double y[NV], k0[NV], k1[NV], k2[NV], k3[NV], k4[NV], k5[NV];
-    y[0] = ff_opt_load(A.z_in, valid, b * M + i, A.z_in, 0.25 * (i + 1) + 0.125 * ((i * 7) % 5));
-    {
-      // seeds: given, or formed from the local energies (ff_cnf_adjoint_energy); all loads branch-free (ff_opt_load)
-      const bool ws = A.w_e != nullptr;
-      const int wi = ff_opt_load(A.w_index, valid && ws, b, A.z_in, (int32_t)0);
-      const double wb = (ff_opt_load(A.w_e, valid, b, A.z_in, 0.0) - ff_opt_load(A.w_mean, valid && ws, wi, A.z_in, 0.0)) * A.w_scale;
-      const double az0 = ff_opt_load(A.az_in, valid, b * M + i, A.z_in, 0.0), ad0 = ff_opt_load(A.ad_in, valid, b, A.z_in, 0.0);
-      y[1] = ws ? wb * az0 : az0;
-      if (ingrp && i == 0) s_ad[g] = ws ? -wb : ad0;
-    }
-    // tent = B0*k0_theta + sum_{s=2..5} B_s*k_s_theta of the step under way (dropped if the step is rejected)
-    double tent[2][MAXU][3];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int j = 0; j < MAXU; j++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) tent[t][j][c] = 0.0;
-    ff_stepper S;
-    S.begin(A.ta, A.tb, valid);
-    // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
-    const bool warm = hwarm > 0.0;
-    double hmax_acc = 0.0;
-    int s = -2, nev = 0;
-    double h0v = 0.0, d1v = 0.0;
-
-    auto group_sum = [&](double part) -> double {
-      if (ingrp) s_err[g][i] = part;
-      __syncthreads();
-      double t = 0.0;
-#pragma unroll
-      for (int j = 0; j < M; j++) t += s_err[gg][j];
-      __syncthreads();
-      return t;
-    };
-
-#pragma unroll 1
-    for (;;) {
-      double in[NV];
-      const double h = S.h;
-      switch (s) {
-        case -2: case 0:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = y[v];
-          break;
-        case -1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h0v * S.dir, k0[v], y[v]);
-          break;
-        case 1:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h * FF_A10, k0[v], y[v]);
-          break;
-        case 2:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A20 * k0[v] + FF_A21 * k1[v], y[v]);
-          break;
-        case 3:
-#pragma unroll
-          for (int v = 0; v < NV; v++) in[v] = fma(h, FF_A30 * k0[v] + FF_A31 * k1[v] + FF_A32 * k2[v], y[v]);
-          break;
-        case 4:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A40 * k0[v] + FF_A41 * k1[v] + FF_A42 * k2[v] + FF_A43 * k3[v], y[v]);
-          break;
-        case 5:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_A50 * k0[v] + FF_A51 * k1[v] + FF_A52 * k2[v] + FF_A53 * k3[v] + FF_A54 * k4[v], y[v]);
-          break;
-        default:
-#pragma unroll
-          for (int v = 0; v < NV; v++)
-            in[v] = fma(h, FF_B0 * k0[v] + FF_B2 * k2[v] + FF_B3 * k3[v] + FF_B4 * k4[v] + FF_B5 * k5[v], y[v]);
-          break;
-      }
-      // ------------------------------------------------------------------ publish z_i, a_i
-      __syncthreads();
-      if (ingrp) { s_z[g][i] = in[0]; s_kb[g][i] = in[1]; }
-      __syncthreads();
-      // ------------------------------------------------------------------ radius set-up (lane <-> radius)
-      for (int q = lane; q < G * nrad; q += FF_WAVE) {
-        const int qg = q / nrad, p = q - qg * nrad;
-        const int a = s_pa[p], bb = s_pb[p];
-        double r2 = 0.0, al = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; c++) {
-          const double rho = s_z[qg][a * D + c] - (bb >= 0 ? s_z[qg][bb * D + c] : 0.0);
-          const double dl = s_kb[qg][a * D + c] - (bb >= 0 ? s_kb[qg][bb * D + c] : 0.0);
-          r2 = fma(rho, rho, r2);
-          al = fma(dl, rho, al);
-        }
-        const double r = sqrt(r2), ad = s_ad[qg];
-        s_rad[qg][p] = r;
-        s_rinv[qg][p] = ff_rcp(r);
-        // integrand of the parameter adjoint is  ca * df(r)/dtheta + cb * df'(r)/dtheta
-        s_ca[qg][p] = bb >= 0 ? -(al - 2.0 * D * ad) : -(al - D * ad);
-        s_cb[qg][p] = bb >= 0 ? 2.0 * ad * r : ad * r;
-      }
-      __syncthreads();
-      nev++;
-      // ------------------------------------------------------------------ unit phase
-      double cur[2][MAXU][3];
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int j = 0; j < MAXU; j++) cur[t][j][0] = cur[t][j][1] = cur[t][j][2] = 0.0;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int H = t ? Hm : He;
-        const int p_lo = t ? P : 0, p_hi = t ? nrad : P;
-        for (int pc = p_lo; pc < p_hi; pc += CH) {
-          const int pe = pc + CH < p_hi ? pc + CH : p_hi;
-          for (int p = pc; p < pe; p++) {
-          const double r = s_rad[gg][p], ca = s_ca[gg][p], cb = s_cb[gg][p];
-          double h0 = 0.0, h1 = 0.0, h2 = 0.0;
-          // this lane's units, MAXU side by side (units beyond H are masked: their weights read as zero); every chunk of
-          // the net contributes to the heads, the chunk starting at unit0 also to this launch's parameter integrands
-          for (int uc = 0; uc < nchunks; uc++) {
-            const bool mine = uc * UC == unit0;
-            ff_wtab w[MAXU];
-            double a[MAXU], sgv[MAXU], mk[MAXU];
-#pragma unroll
-            for (int j = 0; j < MAXU; j++) {
-              const int k = uc * UC + i + j * M;
-              w[j] = s_w[t][k < FF_HMAX ? k : FF_HMAX - 1];
-              mk[j] = k < H ? 1.0 : 0.0;
-              a[j] = fma(w[j].w1, r, w[j].b1);
-            }
-            ff_sigmoid_n<MAXU, false>(a, sgv, s_e2);
-#pragma unroll
-            for (int j = 0; j < MAXU; j++) {
-              const double sg = sgv[j];
-              const double s1 = sg * (1.0 - sg), s2 = s1 * fma(-2.0, sg, 1.0);
-              const double w2 = mk[j] * w[j].w2, w2w1 = w2 * w[j].w1;
-              h0 = fma(w2, sg, h0);
-              h1 = fma(w2w1, s1, h1);
-              h2 = fma(w2w1 * w[j].w1, s2, h2);
-              if (mine) {
-                const double w1rs2 = w[j].w1 * r * s2;
-                cur[t][j][0] += w2 * fma(ca * r, s1, cb * (s1 + w1rs2));
-                cur[t][j][1] += fma(ca * w2, s1, cb * w2w1 * s2);
-                cur[t][j][2] += mk[j] * fma(ca, sg, cb * w[j].w1 * s1);
-              }
-            }
-          }
-          if (ingrp) { s_ph[g][i][p - pc][0] = h0; s_ph[g][i][p - pc][1] = h1; s_ph[g][i][p - pc][2] = h2; }
-          }
-          __syncthreads();
-          // reduce this chunk's partial heads over the group's lanes
-          for (int e = i; e < (pe - pc) * 3; e += M) {
-            const int q = e / 3, m = e - 3 * q;
-            double tsum = 0.0;
-#pragma unroll
-            for (int l = 0; l < M; l++) tsum += s_ph[gg][l][q][m];
-            if (ingrp) s_hd[g][pc + q][m] = tsum;
-          }
-          __syncthreads();
-        }
-      }
-      // ------------------------------------------------------------------ component phase
-      double out[NV];
-      {
-        const double* sz = s_z[gg];
-        const double* sl = s_kb[gg];
-        double vi = 0.0, dvk = 0.0, gdi = 0.0;
-        for (int bq = 0; bq < N; bq++) {
-          if (bq == ai) continue;
-          const int lo = bq < ai ? bq : ai, hi = bq < ai ? ai : bq;
-          const int p = ff_pair_index(N, lo, hi);
-          const double rc = sz[ai * D + ci] - sz[bq * D + ci];
-          const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2];
-          double rdk = 0.0;
-#pragma unroll
-          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c] - sz[bq * D + c], sl[ai * D + c] - sl[bq * D + c], rdk);
-          const double ri = s_rinv[gg][p], r1 = rdk * ri;
-          vi = fma(f0, rc, vi);
-          dvk += fma(f1 * r1, rc, f0 * (sl[ai * D + ci] - sl[bq * D + ci]));
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(2.0 * sp * ri, rc, gdi);
-        }
-        if (has_mu) {
-          const int p = P + ai;
-          const double rc = sz[ai * D + ci];
-          const double f0 = s_hd[gg][p][0], f1 = s_hd[gg][p][1], f2 = s_hd[gg][p][2];
-          double rdk = 0.0;
-#pragma unroll
-          for (int c = 0; c < D; c++) rdk = fma(sz[ai * D + c], sl[ai * D + c], rdk);
-          const double ri = s_rinv[gg][p], r1 = rdk * ri;
-          vi = fma(f0, rc, vi);
-          dvk += fma(f1 * r1, rc, f0 * sl[ai * D + ci]);
-          const double sp = fma(f2, s_rad[gg][p], (1.0 + D) * f1);
-          gdi = fma(sp * ri, rc, gdi);
-        }
-        out[0] = vi;
-        out[1] = fma(s_ad[gg], gdi, -dvk);
-      }
-      // ------------------------------------------------------------------ consume
-      if (s == -2) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) k0[v] = out[v];
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int j = 0; j < MAXU; j++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) tent[t][j][c] = FF_B0 * cur[t][j][c];
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          const double isc = ff_rcp(fma(fabs(y[v]), rtol, atol));
-          p0 = fma(y[v] * isc, y[v] * isc, p0);
-          p1 = fma(k0[v] * isc, k0[v] * isc, p1);
-        }
-        const double d0 = sqrt(group_sum(p0) * (1.0 / NT));
-        d1v = sqrt(group_sum(p1) * (1.0 / NT));
-        h0v = S.h0(d0, d1v);
-        s = -1;
-        // every walker of the wave brings its own first step: no probe evaluation
-        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
-          S.habs = fmin(hwarm, S.interval);
-          S.plan();
-          s = 1;
-        }
-      } else if (s == -1) {
-        double p2 = 0.0;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - k0[v]) * ff_rcp(fma(fabs(y[v]), rtol, atol));
-          p2 = fma(t, t, p2);
-        }
-        const double d2 = sqrt(group_sum(p2) * (1.0 / NT)) / h0v;
-        S.init_habs(h0v, d1v, d2);
-        if (warm) S.habs = fmin(hwarm, S.interval);
-        S.plan();
-        s = 1;
-      } else if (s == 0) {   // re-evaluated f(y) after a rejection (k0 and its parameter integrand)
-#pragma unroll
-        for (int v = 0; v < NV; v++) k0[v] = out[v];
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int j = 0; j < MAXU; j++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) tent[t][j][c] = FF_B0 * cur[t][j][c];
-        s = 1;
-      } else if (s >= 1 && s <= 5) {
-        const double bw = s == 1 ? 0.0 : (s == 2 ? FF_B2 : (s == 3 ? FF_B3 : (s == 4 ? FF_B4 : FF_B5)));
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int j = 0; j < MAXU; j++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) tent[t][j][c] = fma(bw, cur[t][j][c], tent[t][j][c]);
-        if (s == 1) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) k1[v] = out[v];
-        } else if (s == 2) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) k2[v] = out[v];
-        } else if (s == 3) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) k3[v] = out[v];
-        } else if (s == 4) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) k4[v] = out[v];
-        } else {
-#pragma unroll
-          for (int v = 0; v < NV; v++) k5[v] = out[v];
-        }
-        s++;
-      } else {
-        double pe = 0.0;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
-          const double t = e * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
-          pe = fma(t, t, pe);
-        }
-        const double err = sqrt(group_sum(pe) * (1.0 / NT));
-        const bool was_active = !S.done;
-        const bool acc = S.decide(err, A.max_steps);
-        if (acc) hmax_acc = fmax(hmax_acc, fabs(h));
-        if (acc) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) { y[v] = in[v]; k0[v] = out[v]; }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-          for (int j = 0; j < MAXU; j++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              if (acc) row_add(t, j, c, h * tent[t][j][c]);
-              tent[t][j][c] = acc ? FF_B0 * cur[t][j][c] : 0.0;   // FSAL: k6_theta opens the next step
-            }
-        S.plan();
-        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
-        if (!any) break;
-        s = (any & 2) ? 0 : 1;   // somebody rejected: the whole wave passes through stage 0
-      }
-    }
-    if (valid) {
-      // failed integration (NaN error norm, max_steps): NaN into this walker's x-gradient and into the parameter gradient
-      const double bad = S.fail ? __builtin_nan("") : 0.0;
-      if (A.gx_out) A.gx_out[b * M + i] = y[1] + bad;
-      if (i == 0) {
-        if (S.fail && unit0 == 0) row_add(0, 0, 0, bad);
-        if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
-        if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
-        if (A.stats && unit0 == 0) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
-      }
-    }
-    __syncthreads();
+// The instantiation that is enqueued BEHIND the tabulated kernel as its (normally idle) fallback: compiled for four waves per
+// SIMD (<= 128 registers, spilling; its LDS is dynamic so that the compiler does not see an occupancy limit that lets it ignore
+// the bound).  An idle fallback has to be SCHEDULED before it can return -- and at 444 registers it could not enter a SIMD while
+// the next sweep's Metropolis waves (2 x 164 registers, side stream) were resident: it sat in the queue until they retired, 80-105
+// us of every iteration (profiles/r02_f, r03_c; 5 us on an empty GPU).  Calls without a radial table launch the full-speed kernel.
+template <int N, int D, int MAXU>
+__global__ void __launch_bounds__(FF_WAVE, 4)
+ff_ode_adj_lean_kernel(ff_adj_args A) {
+  using Gm = ff_geom<N, D>;
+  constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
+  constexpr int NV = 2;
+  {
+    const double* rt = A.net.radial_table;
+    if (rt && rt[3] == 0.0 && rt[4] == 0.0 && *A.off_table == 0.0) return;
   }
-  // (rows are summed deterministically by ff_rows_reduce_kernel)
-  __syncthreads();
-  if (A.stats && threadIdx.x == 0 && (s_st[0] || s_st[3])) {
-    atomicAdd(&A.stats[0], s_st[0]);
-    atomicMax(&A.stats[1], s_st[1]);
-    atomicAdd(&A.stats[2], s_st[2]);
-    if (s_st[3]) atomicMax(&A.stats[3], 1);
-  }
+  FF_DYN_LDS(ff_adj_lean_lds);
+  ff_adj_smem<N, D>& sm = *reinterpret_cast<ff_adj_smem<N, D>*>(ff_adj_lean_lds);
+  auto& s_w = sm.s_w; auto& s_z = sm.s_z; auto& s_kb = sm.s_kb; auto& s_err = sm.s_err; auto& s_ad = sm.s_ad;
+  auto& s_rad = sm.s_rad; auto& s_rinv = sm.s_rinv; auto& s_ca = sm.s_ca; auto& s_cb = sm.s_cb;
+  constexpr int CH = ff_adj_smem<N, D>::CH;
+  auto& s_ph = sm.s_ph; auto& s_hd = sm.s_hd; auto& s_pa = sm.s_pa; auto& s_pb = sm.s_pb; auto& s_any = sm.s_any;
+  auto& s_e2 = sm.s_e2; auto& s_st = sm.s_st;
+#include "ff_adj_direct_body.inc"
 }
 
 // out[k] = sum over rows of rows[r][k]: one workgroup per parameter, fixed tree (deterministic)
@@ -1005,13 +679,17 @@ static void launch_adj(void* stream, const ff_adj_args& a_in) {
   constexpr int MU_64 = (64 + M - 1) / M > 16 ? 16 : (64 + M - 1) / M, MU_50 = (50 + M - 1) / M > 16 ? 16 : (50 + M - 1) / M;
   const int hmax = a_in.net.He > a_in.net.Hm ? a_in.net.He : a_in.net.Hm;
   ff_adj_args a = a_in;
+  const bool lean = a_in.net.radial_table != nullptr;      // behind the tabulated kernel: the small-footprint fallback
+  const size_t lds = sizeof(ff_adj_smem<N, D>);
   if (MU_50 < MU_64 && hmax <= MU_50 * M) {
     a.unit0 = 0;
-    FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_50>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+    if (lean) FF_LAUNCH_LDS((ff_ode_adj_lean_kernel<N, D, MU_50>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, lds, stream, a);
+    else FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_50>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
   } else {
     for (int u0 = 0; u0 < hmax; u0 += MU_64 * M) {
       a.unit0 = u0;
-      FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_64>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
+      if (lean) FF_LAUNCH_LDS((ff_ode_adj_lean_kernel<N, D, MU_64>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, lds, stream, a);
+      else FF_LAUNCH((ff_ode_adj_kernel<N, D, MU_64>), adj_grid(a.B, ff_geom<N, D>::G), FF_WAVE, stream, a);
     }
   }
 }
