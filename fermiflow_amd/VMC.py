@@ -291,7 +291,11 @@ class GSVMC(_Sweep, torch.nn.Module):
             self._side = torch.cuda.Stream()
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
-            native.stream_delay(40.0)
+            # One (empty) kernel in front of the sampler: its launch latency alone lets the adjoint's waves be placed first -- with
+            # nothing here the Metropolis waves fill every SIMD first and the two kernels run one after the other (2.34 ms per
+            # iteration at config 2), with the empty launch 2.04-2.05 ms, with round 2's 40 us spin 2.07-2.10
+            # (FERMIFLOW_PREFETCH_DELAY_US: microseconds the kernel spins, for experiments)
+            native.stream_delay(float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "0")))
             from .base_dist import _draw_seed
             seed = _draw_seed()
             z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
