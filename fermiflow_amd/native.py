@@ -299,16 +299,7 @@ def beta_finish(buf, shift_dev, logits, beta, n_global):
     return est, gphi, mean_e, lpa
 
 
-def state_sums(e, walker_state, nstates):
-    """ff_state_sums: tensor [2, nstates] = (per-state sums of e, per-state walker counts); walker_state sorted int32."""
-    e = L.dev(e, name="e"); ws = L.dev(walker_state, torch.int32, "walker_state")
-    out = torch.empty(2, nstates, dtype=torch.float64, device=e.device)
-    L.check(L.lib().ff_state_sums(L.stream(), L.i64(e.numel()), int(nstates), L.ptr(ws), L.ptr(e), L.ptr(out[0]), L.ptr(out[1])),
-            "ff_state_sums")
-    return out
-
-
-# ---- d = 3 groundwork (csrc/ff_ho3d.hip) ---------------------------------------------------------------------------
+# ---- d = 3 (csrc/ff_ho3d.hip) ---------------------------------------------------------------------------
 def logprob3d(tab_up, tab_dn, nup, ndn, x, walker_state=None, derivs=False):
     x = L.dev(x, name="x")
     B = x.shape[0]
