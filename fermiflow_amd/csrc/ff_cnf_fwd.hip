@@ -1272,7 +1272,7 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
 }
 
 #ifndef FF_MFMA_WPS
-#define FF_MFMA_WPS 1   // waves per SIMD the matrix-core kernel is compiled for (A/B knob)
+#define FF_MFMA_WPS 2   // waves per SIMD the matrix-core kernel is compiled for (A/B knob)
 #endif
 // Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12
 template <int N, int D>
@@ -1281,7 +1281,7 @@ static void launch_mfma(void* stream, const ff_fwd_args& a) {
   const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   if (a.evt) FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), grid, FF_WAVE, stream, a);
-  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, FF_MFMA_WPS>), grid, FF_WAVE, stream, a);
+  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), grid, FF_WAVE, stream, a);
 }
 
 static std::atomic<uint64_t> g_evt_counter{1};
@@ -1310,7 +1310,8 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   static const int wide_from = [] { const char* e = getenv("FF_WIDE_ELOC_FROM"); return e ? atoi(e) : 11; }();
   if (MODE == 2 && d == 2 && (eloc_kind == 4 || (eloc_kind == 0 && n >= wide_from)) && ff_wide_supported(n, d))
     return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
-  if (MODE == 2 && eloc_kind == 1) {
+  static const int mfma_from = [] { const char* e = getenv("FF_MFMA_ELOC_FROM"); return e ? atoi(e) : 4; }();
+  if (MODE == 2 && (eloc_kind == 1 || (eloc_kind == 0 && d == 2 && n >= mfma_from && n <= 6))) {
 #define FF_MF(N_, D_) if (n == N_ && d == D_) { launch_mfma<N_, D_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)
 #undef FF_MF

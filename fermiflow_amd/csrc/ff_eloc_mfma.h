@@ -16,14 +16,40 @@
 //                       is A[4K+r][4I+c]: element (r, c) of block (K, I), read straight from the assembled matrix in LDS;
 //   S  block (I, Kc)  = sum_K  mfma(Jt[I][K], Jt[Kc][K]),  Jt = the blocks transposed in place (lane (r,c) <-> (c,r): two
 //                       ds_bpermute per double); only I <= Kc is computed, both halves are written to LDS.
-// Everything else is per-radius or per-coordinate work:
-//   R1  radius lanes (the wave's 4 R radii dealt over the lanes): heads from the radial table, then deposits -- the D x D
-//       block B = eta I + (eta'/r) rho rho^T into A (off-diagonal particle blocks stored, diagonal ones accumulated with
-//       LDS atomics), and each particle's velocity, A kbar and grad div sums (LDS atomics on a single wave: fixed order);
-//   R2  radius lanes: W from S, the second-order sources, deposited the same way;
-//   coordinate p = 4r + c (< M) is integrated by lane (r, c): z_p, kbar_p, its part of Delta and lap Delta; the component
-//   4c + r of grad Delta sits on lane (r, c) (it comes out of the transposed blocks by a quad reduction).
+// Everything else is per-radius or per-coordinate work, without atomics:
+//   R1  radius lanes -- the R radii of a walker are dealt over ITS sixteen lanes (radius i16, i16 + 16, ...): heads from the
+//       radial table, one record per radius (rho, eta, eta'/r, c phi'/r, 1/r^2, the first-order part of D_v[kbar], eta'', c phi'')
+//       in LDS; the radius' shares of div v and of the Laplacian source stay on the lane (Delta and lap Delta are integrated as
+//       per-lane partial sums);
+//   rows  lane (r, c) owns coordinate p = 4r + c (< M) of particle a = p / D: it walks the N records of its particle (pairs
+//       with either sign, the one-body radius), sums v_p, (A kbar)_p, (grad div)_p and the diagonal block of A, and stores row p
+//       of A -- every element of A is written by exactly one lane;
+//   R2  radius lanes: W from S, the second-order sources written back into the record; the row lanes gather them.
+//   S takes the place of A in LDS once the last operand of J' = A J has been read (one wave per workgroup: program order).
+//   The component 4c + r of grad Delta sits on lane (r, c) (it comes out of the transposed blocks by a quad reduction).
+// 20 KB of LDS and <= 256 registers: two waves per SIMD (the vector pipe issues at half rate for a single wave).
 #pragma once
+
+// Dormand-Prince vector of a lane whose components 1 .. NB (the J blocks) live in lane-private LDS columns and whose other
+// NS components (slot 0 and NB + 1 ...) live in registers
+// Weight of Delta and lap Delta in the error norm relative to the other sensitivity components.  The column and row kernels carry
+// both as per-lane partial sums, each controlled against its own magnitude -- a norm that is stricter by the square root of the
+// number of partials (more where they cancel); here each is ONE component and the weight stands in for that.  It decides how many
+// steps the walkers with a particle passing the origin take (the kink of mu(|x|) x), i.e. the length of the longest chain of the
+// launch, against their E_loc error (65 536 walkers, config 2, sweep policy; tools/probes/sens_tol.py):
+//   weight 1: max 2.9e-6, p99.9 1.6e-7, launch 0.79 ms | 4: 2.1e-6, 5.5e-8, 0.89 ms | 16: 2.1e-6, 1.3e-8, 1.05 ms
+//   (column kernel: 2.1e-7, 1.7e-8, 1.03 ms; the bar is 1e-5)
+#ifndef FF_MFMA_SUMW
+#define FF_MFMA_SUMW 4.0
+#endif
+template <int NB, int NS>
+struct ff_jsplit_vec {
+  double* col;
+  double r[NS];
+  FF_D ff_jsplit_vec(double* base, int lane) : col(base + lane) {}
+  FF_D double get(int v) const { return (v >= 1 && v <= NB) ? col[(v - 1) * FF_WAVE] : r[v == 0 ? 0 : v - NB]; }
+  FF_D void set(int v, double x) { if (v >= 1 && v <= NB) col[(v - 1) * FF_WAVE] = x; else r[v == 0 ? 0 : v - NB] = x; }
+};
 
 template <int N, int D, bool TAB, int WPS = 1>
 __global__ void __launch_bounds__(FF_WAVE, WPS)
@@ -31,21 +57,34 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   constexpr int M = N * D, MB = (M + 3) / 4, MP = 4 * MB, G = 4;
   static_assert(MB >= 1 && MB <= 3, "at most 12 coordinates per walker");
   constexpr int P = N * (N - 1) / 2, R = P + N;
-  constexpr int NH = 4, NB = MB * MB, NV = NB + 5;
-  constexpr int IK = NB + 1, IDD = NB + 2, IDL = NB + 3, ILP = NB + 4;
+  // components of a lane: 0: z_p on the coordinate lanes p < M, Delta on lane p = 12, lap Delta on lane p = 13 (M <= 12: never
+  // coordinate lanes); 1 .. NB: the J blocks; kbar_p; (grad Delta)_p
+  constexpr int NH = 4, NB = MB * MB, NV = NB + 3;
+  constexpr int IK = NB + 1, IDD = NB + 2, PDL = 12, PLP = 13;
 
   __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
   __shared__ double s_e2[TAB ? 1 : 64];
-  constexpr int AS = MP + 2;     // row stride of the per-walker matrices (even: 16-byte aligned rows)
-  __shared__ __attribute__((aligned(16))) double s_A[G][MP * AS], s_S[G][MP * AS];
-  // per coordinate: z, kbar (published), v, A kbar + second-order source, grad div (accumulated); per walker: div v, lap source
-  __shared__ double s_z[G][MP], s_kb[G][MP], s_v[G][MP], s_ws[G][MP], s_gd[G][MP], s_ds[G], s_ls[G];
-  // records R1 -> R2: rho (D), eta'/r, c phi'/r, 1/r^2, eta'', c phi''
-  constexpr int RW = (D + 5 + 1) & ~1;
-  __shared__ __attribute__((aligned(16))) double s_rec[G * R * RW];
-  __shared__ double s_err[FF_WAVE];
-  __shared__ double s_cv[NV][FF_WAVE];   // error accumulator of the Dormand-Prince step, lane-private columns
-  __shared__ int s_pa[R], s_pb[R], s_any;
+  constexpr int AS = MP + 1;     // row stride of the per-walker matrix (odd: the column reads of the operands spread over the banks)
+  __shared__ double s_A[G][MP * AS];       // A = dv/dz, then S = J J^T
+  __shared__ double s_z[G][MP], s_kb[G][MP];   // per coordinate: z, kbar (published); grad div (row lanes) takes the place of z
+  // step-size controller of a walker: kept in LDS, loaded by the walker's lanes where a decision is taken (every lane of the
+  // walker computes the same update and stores the same values) -- forty registers less in the right-hand side
+  struct ctl_t {
+    ff_stepper S; double hmax_acc, h0v, d1v, hwarm, sens_w;
+    FF_D void get(const ctl_t& o) {      // member by member (a struct copy is a memcpy through scratch)
+      S.t = o.S.t; S.tb = o.S.tb; S.dir = o.S.dir; S.interval = o.S.interval; S.habs = o.S.habs; S.h = o.S.h; S.tnew = o.S.tnew;
+      S.hprev = o.S.hprev; S.eprev = o.S.eprev; S.nacc = o.S.nacc; S.nrej = o.S.nrej; S.natt = o.S.natt; S.rejected = o.S.rejected;
+      S.fail = o.S.fail; S.done = o.S.done;
+      hmax_acc = o.hmax_acc; h0v = o.h0v; d1v = o.d1v; hwarm = o.hwarm; sens_w = o.sens_w;
+    }
+  };
+  __shared__ ctl_t s_ctl[G];
+  // record of a radius: [0,D) rho  [D] eta  [D+1] eta'/r  [D+2] c phi'/r  [D+3, 2D+3) this radius' term of A kbar + the second-order source
+  constexpr int RW = (2 * D + 3) | 1;     // odd: the row lanes of a wave read up to 4 N records at a time, one bank group each
+  constexpr int QF0 = D, QF1 = D + 1, QGQ = D + 2, QPW = D + 3;
+  __shared__ double s_rec[(G * R + 1) * RW];   // + one record that stays zero
+  __shared__ double s_cv[2 * NB][FF_WAVE];   // the J blocks of y and of the error accumulator of the Dormand-Prince step, lane-private columns
+  __shared__ int s_any;
   __shared__ int s_st[4];
   __shared__ long long s_next;
 
@@ -67,42 +106,54 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   }
   bool off_table = false;
   if (lane < 4) s_st[lane] = 0;
-  if (lane == 0) {
-    int q = 0;
-    for (int a = 0; a < N; a++)
-      for (int b = a + 1; b < N; b++) { s_pa[q] = a; s_pb[q] = b; q++; }
-    for (int a = 0; a < N; a++) { s_pa[P + a] = a; s_pb[P + a] = -1; }
-  }
-  for (int e = lane; e < G * MP * AS; e += FF_WAVE) { (&s_A[0][0])[e] = 0.0; (&s_S[0][0])[e] = 0.0; }   // padding stays zero
-  for (int e = lane; e < G * MP; e += FF_WAVE) { (&s_z[0][0])[e] = 0.0; (&s_kb[0][0])[e] = 0.0; (&s_gd[0][0])[e] = 0.0; }
+  for (int e = lane; e < G * MP * AS; e += FF_WAVE) (&s_A[0][0])[e] = 0.0;   // padding stays zero
+  for (int e = lane; e < G * MP; e += FF_WAVE) { (&s_z[0][0])[e] = 0.0; (&s_kb[0][0])[e] = 0.0; }
+  for (int e = lane; e < (G * R + 1) * RW; e += FF_WAVE) s_rec[e] = 0.0;
   __syncthreads();
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? R : P;
   const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
   const double rtol = A.rtol, atol = A.atol;
+  double (*s_gd)[MP] = s_z;
   constexpr double NT = (double)M * M + 4.0 * M + 2.0;   // z, J, kbar, grad Delta, Delta, lap Delta
   const int64_t ngroups = (A.B + G - 1) / G;
-  // radii this lane evaluates (slot qk: radius lane + 64 qk of the wave's G*nrad): walker | a << 4 | b (15: none) << 8 | index << 12
-  constexpr int NQ = (G * R + FF_WAVE - 1) / FF_WAVE;
+  // radii this lane evaluates for its own walker (slot qk: radius i16 + 16 qk): a | b (15: none) << 4 | record offset << 8
+  constexpr int NQ = (R + 15) / 16;
+  const int i16 = 4 * r + c;
   int rq_id[NQ];
 #pragma unroll
   for (int qk = 0; qk < NQ; qk++) {
-    const int q = lane + qk * FF_WAVE;
-    const bool act = q < G * nrad;
-    const int qg = act ? q / nrad : 0, pr = act ? q - qg * nrad : 0;
-    rq_id[qk] = act ? (qg | (s_pa[pr] << 4) | ((s_pb[pr] < 0 ? 15 : s_pb[pr]) << 8) | (pr << 12)) : -1;
+    const int pr = i16 + 16 * qk;
+    int a = 0, bb = 15;
+    if (pr < P) {
+      int q = pr;
+      while (q >= N - 1 - a) { q -= N - 1 - a; a++; }
+      bb = a + 1 + q;
+    } else {
+      a = pr - P;
+    }
+    rq_id[qk] = pr < nrad ? (a | (bb << 4) | (((w * R + pr) * RW) << 8)) : -1;
+  }
+  // row lanes: partner slot k = particle k (k == own particle: the one-body radius).  Packed: record offset << 1 | (k < own).
+  // An absent term reads the all-zero record behind the last one and "writes" -0.0 where the diagonal block is stored afterwards.
+  const int ra = owner ? p / D : 0, rc = owner ? p % D : 0;
+  int prec[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool ok = owner && (k != ra || has_mu);
+    const int lo = k < ra ? k : ra, hi = k < ra ? ra : k;
+    const int pr = k == ra ? P + ra : lo * (2 * N - lo - 1) / 2 + (hi - lo - 1);
+    prec[k] = ((ok ? (w * R + pr) : G * R) * RW) << 1 | ((ok && k < ra) ? 1 : 0);
   }
 
-  // sum over the 16 lanes of a walker (identical on all of them): quad by DPP, the four quads through LDS
+  // sum over the 16 lanes of a walker (identical on all of them): quad by DPP, the four quads through the LDS crossbar
   auto walker_sum = [&](double part) -> double {
     part += ff_swap1(part);
     part += ff_swap2(part);
-    s_err[lane] = part;
-    __syncthreads();
-    const double t = (s_err[4 * w] + s_err[16 + 4 * w]) + (s_err[32 + 4 * w] + s_err[48 + 4 * w]);
-    __syncthreads();
-    return t;
+    part += ff_lane_read(part, lane ^ 16);
+    part += ff_lane_read(part, lane ^ 32);
+    return part;
   };
 
 #ifdef FF_STAMPS
@@ -120,35 +171,45 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     const bool valid = bq < A.B;
     const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);
     // Dormand-Prince storage as in ff_ode_fwd_kernel: y, c0..c2 (k0..k2, then the inputs of stages 4, 5 and y_new), c3 (error)
-    double y[NV], c0[NV], c1[NV], c2[NV];
-    ff_lane_vec<NV, true> c3(&s_cv[0][0], lane);
+    double c0[NV], c1[NV], c2[NV];
+    ff_jsplit_vec<NB, 3> y(&s_cv[0][0], lane), c3(&s_cv[NB][0], lane);
 #pragma unroll
-    for (int v = 0; v < NV; v++) { y[v] = 0.0; c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3[v] = 0.0; }
+    for (int v = 0; v < NV; v++) { y.set(v, 0.0); c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3.set(v, 0.0); }
     {
       const double y0 = ff_opt_load(A.y_in, valid && owner, b * M + p, A.y_in, 0.25 * (p + 1) + 0.125 * ((p * 7) % 5));   // idle walkers: finite, distinct
-      y[0] = owner ? y0 : y[0];
+      if (owner) y.set(0, y0);
     }
 #pragma unroll
-    for (int I = 0; I < MB; I++) y[1 + I * MB + I] = (r == c && 4 * I + r < M) ? 1.0 : 0.0;   // J = identity
-    ff_stepper S;
-    S.begin(A.ta, A.tb, valid);
-    // walkers of a low cost class: looser tolerance for the sensitivity components, larger first step (ff_ode.walker_class)
-    const bool loose = ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
-    const bool warm = hwarm > 0.0;
-    // tolerance of the sensitivity components relative to the coordinates' (ff_ode.sens_tol): weight in the error norm
-    const double sens_w = loose ? A.sens_w : 1.0;
-    double hmax_acc = 0.0;
+    for (int I = 0; I < MB; I++) y.set(1 + I * MB + I, (r == c && 4 * I + r < M) ? 1.0 : 0.0);   // J = identity
+    {
+      ctl_t C;
+      C.S.begin(A.ta, A.tb, valid);
+      // walkers of a low cost class: looser tolerance for the sensitivity components, larger first step (ff_ode.walker_class)
+      const bool loose = ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
+      C.hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
+      if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
+      // tolerance of the sensitivity components relative to the coordinates' (ff_ode.sens_tol): weight in the error norm
+      C.sens_w = loose ? A.sens_w : 1.0;
+      C.hmax_acc = 0.0; C.h0v = 0.0; C.d1v = 0.0;
+      __syncthreads();
+      s_ctl[w].get(C);
+      __syncthreads();
+    }
     int s = -2, nev = 0;
-    double h0v = 0.0, d1v = 0.0;
 
 #pragma unroll 1
     for (;;) {
+      // the lane indices are laundered once per evaluation: otherwise every LDS address below becomes a loop-invariant register
+      int ln = lane;
+      FF_OPAQUE(ln);
+      const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c, tl = 16 * c + 4 * w + r;
+      const bool owner = p < M;
+      const int ra = owner ? p / D : 0, rc = owner ? p % D : 0;
       // ------------------------------------------------------------------ stage input (one expression for all stages)
-      const double hs = S.h;
+      const double hs = s_ctl[w].S.h;
       double gy = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
       switch (s) {
-        case -1: g0 = h0v * S.dir; break;
+        case -1: g0 = s_ctl[w].h0v * s_ctl[w].S.dir; break;
         case 1: g0 = hs * FF_A10; break;
         case 2: g0 = hs * FF_A20; g1 = hs * FF_A21; break;
         case 3: g0 = hs * FF_A30; g1 = hs * FF_A31; g2 = hs * FF_A32; break;
@@ -157,120 +218,166 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         case 6: gy = 0.0; g2 = 1.0; break;
         default: break;   // -2, 0: the state itself
       }
-      auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
+      auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y.get(v)))); };
       double out[NV];
       const double zin = form(0), kin = form(IK);
       FF_STAMP(0);
-      // ------------------------------------------------------------------ publish z, kbar; clear the accumulators
+      FF_SCHED_FENCE();
+      // ------------------------------------------------------------------ publish z, kbar
       __syncthreads();
-      if (owner) {
-        s_z[w][p] = zin; s_kb[w][p] = kin;
-        s_v[w][p] = 0.0; s_ws[w][p] = 0.0; s_gd[w][p] = 0.0;
-      }
-      if (r == 0 && c == 0) { s_ds[w] = 0.0; s_ls[w] = 0.0; }
-      // the particle-diagonal D x D blocks of A are accumulated: clear this lane's elements of them
+      if (owner) { s_z[w][p] = zin; s_kb[w][p] = kin; }
+      __syncthreads();
+      // ------------------------------------------------------------------ radius lanes (radii of the lane's own walker), first
+      // half: the radii, their table rows requested -- the fetch runs under the S product
+      double rq_rho[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
+      bool rq_ok[NQ];
 #pragma unroll
-      for (int K = 0; K < MB; K++)
+      for (int qk = 0; qk < NQ; qk++) {
+        int id = rq_id[qk];
+        FF_OPAQUE(id);
+        const bool act = id >= 0;
+        const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
+        const bool pair = bb0 != 15;
+        const int bb = pair ? bb0 : a;
+        double r2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < D; cc++) {
+          rq_rho[qk][cc] = s_z[w][a * D + cc] - (pair ? s_z[w][bb * D + cc] : 0.0);
+          r2 = fma(rq_rho[qk][cc], rq_rho[qk][cc], r2);
+        }
+        if (!act) r2 = 1.0;
+        ff_sqrt_rcp(r2, rq_r[qk], rq_ri[qk]);
+        rq_dr[qk] = 0.0;
+        rq_ok[qk] = true;
+        if constexpr (TAB) {
+          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[qk], rq_T[qk], rq_dr[qk]);
+          if (act && !rq_ok[qk]) off_table = true;
+        }
+      }
+      // ------------------------------------------------------------------ S = J J^T on the matrix cores
+      {
+        double Jt[NB];      // the blocks transposed in place: lane (r, c) <-> (c, r)
+#pragma unroll
+        for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form(1 + e), tl);
+        double* Sw = s_A[w];
 #pragma unroll
         for (int I = 0; I < MB; I++) {
-          if (4 % D == 0 && K != I) continue;     // D = 2: a particle's rows never straddle two 4-blocks
-          const int p1 = 4 * K + r, p2 = 4 * I + c;
-          if (p1 / D == p2 / D && p1 < M && p2 < M) s_A[w][p1 * AS + p2] = 0.0;
-        }
-      __syncthreads();
-      FF_STAMP(1);
-      // ------------------------------------------------------------------ R1: radius lanes
-      {
-        double rq_rho[NQ][D], rq_dk[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
-        bool rq_ok[NQ];
 #pragma unroll
-        for (int qk = 0; qk < NQ; qk++) {
-          int id = rq_id[qk];
-          FF_OPAQUE(id);
-          const bool act = id >= 0;
-          const int qg = act ? (id & 15) : 0, a = act ? ((id >> 4) & 15) : 0, bb0 = act ? ((id >> 8) & 15) : 15;
-          const bool pair = bb0 != 15;
-          const int bb = pair ? bb0 : a;
-          double r2 = 0.0;
+          for (int Kc = I; Kc < MB; Kc++) {
+            double acc = 0.0;
 #pragma unroll
-          for (int cc = 0; cc < D; cc++) {
-            rq_rho[qk][cc] = s_z[qg][a * D + cc] - (pair ? s_z[qg][bb * D + cc] : 0.0);
-            rq_dk[qk][cc] = s_kb[qg][a * D + cc] - (pair ? s_kb[qg][bb * D + cc] : 0.0);
-            r2 = fma(rq_rho[qk][cc], rq_rho[qk][cc], r2);
-          }
-          ff_sqrt_rcp(r2, rq_r[qk], rq_ri[qk]);
-          rq_dr[qk] = 0.0;
-          rq_ok[qk] = true;
-          if constexpr (TAB) {
-            rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[qk], rq_T[qk], rq_dr[qk]);
-            if (act && !rq_ok[qk]) off_table = true;
-          }
-        }
-#pragma unroll
-        for (int qk = 0; qk < NQ; qk++) {
-          int id = rq_id[qk];
-          FF_OPAQUE(id);
-          if (id >= 0) {
-            const int qg = id & 15, a = (id >> 4) & 15, bb0 = (id >> 8) & 15, pr = id >> 12;
-            const bool pair = bb0 != 15;
-            const int bb = pair ? bb0 : a;
-            const double* rho = rq_rho[qk];
-            const double* dk = rq_dk[qk];
-            const double rr = rq_r[qk], ri = rq_ri[qk];
-            double hd[NH];
-            if constexpr (TAB) {
-              if (rq_ok[qk]) ff_table_eval<NH>(rq_T[qk], rq_dr[qk], hd);
-              else {
-#pragma unroll
-                for (int m = 0; m < NH; m++) hd[m] = 0.0;
-              }
-            } else {
-              ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, rr, hd);
-            }
-            const double cf = pair ? 2.0 : 1.0;
-            const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
-            const double Ac = cf * fma(f2, rr, (1.0 + D) * f1), Bc = cf * fma(f3, rr, (2.0 + D) * f2);
-            double rdk = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < D; cc++) rdk = fma(rho[cc], dk[cc], rdk);
-            const double f1ri = f1 * ri, F1k = f1ri * rdk, gq = Ac * ri;
-            double* rec = &s_rec[(qg * R + pr) * RW];
-#pragma unroll
-            for (int cc = 0; cc < D; cc++) rec[cc] = rho[cc];
-            rec[D] = f1ri; rec[D + 1] = gq; rec[D + 2] = ri * ri; rec[D + 3] = f2; rec[D + 4] = Bc;
-            atomicAdd(&s_ds[qg], cf * fma(f1, rr, D * f0));       // this radius' share of div v
-            double* Am = s_A[qg];
-#pragma unroll
-            for (int cc = 0; cc < D; cc++) {
-              const double pv = f0 * rho[cc], pw = fma(F1k, rho[cc], f0 * dk[cc]), pg = gq * rho[cc];
-              atomicAdd(&s_v[qg][a * D + cc], pv); atomicAdd(&s_ws[qg][a * D + cc], pw); atomicAdd(&s_gd[qg][a * D + cc], pg);
-              if (pair) { atomicAdd(&s_v[qg][bb * D + cc], -pv); atomicAdd(&s_ws[qg][bb * D + cc], -pw); atomicAdd(&s_gd[qg][bb * D + cc], -pg); }
-              const double fr = f1ri * rho[cc];
-#pragma unroll
-              for (int c2i = 0; c2i < D; c2i++) {
-                const double Bcc = fma(fr, rho[c2i], c2i == cc ? f0 : 0.0);   // B = f0 I + (f1/r) rho rho^T
-                atomicAdd(&Am[(a * D + cc) * AS + a * D + c2i], Bcc);         // dv_a/dz_a += B
-                if (pair) {
-                  atomicAdd(&Am[(bb * D + cc) * AS + bb * D + c2i], Bcc);     // dv_b/dz_b += B
-                  Am[(a * D + cc) * AS + bb * D + c2i] = -Bcc;                // dv_a/dz_b = dv_b/dz_a = -B
-                  Am[(bb * D + cc) * AS + a * D + c2i] = -Bcc;
-                }
-              }
-            }
+            for (int K = 0; K < MB; K++) acc = ff_mfma4(Jt[I * MB + K], Jt[Kc * MB + K], acc);
+            Sw[(4 * I + r) * AS + 4 * Kc + c] = acc;
+            if (Kc != I) Sw[(4 * Kc + c) * AS + 4 * I + r] = acc;
           }
         }
       }
       __syncthreads();
+      FF_STAMP(1);
+      FF_SCHED_FENCE();
+      // ------------------------------------------------------------------ radius lanes, second half: heads, contraction of the
+      // second-order terms with S, one record per radius
+      double dsum = 0.0, qsum = 0.0;
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        int id = rq_id[qk];
+        FF_OPAQUE(id);
+        const bool act = id >= 0;
+        const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
+        const bool pair = bb0 != 15;
+        const int bb = pair ? bb0 : a;
+        const double* rho = rq_rho[qk];
+        const double rr = rq_r[qk], ri = rq_ri[qk];
+        double hd[NH];
+        if constexpr (TAB) {
+          if (rq_ok[qk]) ff_table_eval<NH>(rq_T[qk], rq_dr[qk], hd);
+          else {
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, rr, hd);
+        }
+        if (act) {
+          const double cf = pair ? 2.0 : 1.0;
+          const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
+          const double Ac = cf * fma(f2, rr, (1.0 + D) * f1), Bc = cf * fma(f3, rr, (2.0 + D) * f2);
+          const double f1ri = f1 * ri, gq = Ac * ri;
+          // W = S_aa + S_bb - S_ab - S_ba (S_aa for a one-body radius);  w1 = W rho, q = rho^T W rho / r^2
+          const double* Sg = s_A[w];
+          double w1[D], dk[D], qq = 0.0, tr = 0.0, rdk = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+            double t = 0.0;
+#pragma unroll
+            for (int c2i = 0; c2i < D; c2i++) {
+              double ww = Sg[(a * D + cc) * AS + a * D + c2i];
+              if (pair) ww += (Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i]) - Sg[(a * D + c2i) * AS + bb * D + cc];
+              t = fma(ww, rho[c2i], t);
+              if (c2i == cc) tr += ww;
+            }
+            w1[cc] = t;
+            qq = fma(rho[cc], t, qq);
+            dk[cc] = s_kb[w][a * D + cc] - (pair ? s_kb[w][bb * D + cc] : 0.0);
+            rdk = fma(rho[cc], dk[cc], rdk);
+          }
+          qq *= ri * ri;
+          const double tq = tr - qq;                       // sum_i (|delta_i|^2 - r1_i^2)
+          const double F2 = fma(f2, qq, fma(f1ri, tq, f1ri * rdk)), F1x2 = 2.0 * f1ri;
+          double* rec = &s_rec[id >> 8];
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+            rec[cc] = rho[cc];
+            rec[QPW + cc] = fma(F2, rho[cc], fma(F1x2, w1[cc], f0 * dk[cc]));    // D_v[kbar] + the second-order source, this radius
+          }
+          rec[QF0] = f0; rec[QF1] = f1ri; rec[QGQ] = gq;
+          dsum = fma(cf, fma(f1, rr, D * f0), dsum);       // this radius' share of div v
+          qsum += fma(Bc, qq, gq * tq);                    // ... and of the Laplacian source
+        }
+      }
+      __syncthreads();      // records complete; S has been read: A takes its place
       nev++;
       FF_STAMP(2);
-      // ------------------------------------------------------------------ the two products on the matrix cores
+      FF_SCHED_FENCE();
+      // ------------------------------------------------------------------ row lanes: own-row sums and row p of A
+      double vi = 0.0, wk = 0.0, gdi = 0.0;
       {
-        double Jin[NB], Jt[NB];
+        double Ad[D];
 #pragma unroll
-        for (int e = 0; e < NB; e++) { Jin[e] = form(1 + e); Jt[e] = ff_lane_read(Jin[e], tl); }
-        double gdc[MB];   // grad div at the coordinates 4I + c (for the grad-Delta product with the transposed blocks)
+        for (int cc = 0; cc < D; cc++) Ad[cc] = 0.0;
+        double* arow = &s_A[w][(owner ? p : 0) * AS];
 #pragma unroll
-        for (int I = 0; I < MB; I++) gdc[I] = s_gd[w][4 * I + c];
+        for (int k = 0; k < N; k++) {
+          int pk = prec[k];
+          FF_OPAQUE(pk);
+          const double* rec = &s_rec[pk >> 1];
+          const double sg = (pk & 1) ? -1.0 : 1.0;
+          const double f0 = rec[QF0], rcv = rec[rc], fc = rec[QF1] * rcv;
+          vi = fma(sg * f0, rcv, vi);
+          wk = fma(sg, rec[QPW + rc], wk);
+          gdi = fma(sg * rec[QGQ], rcv, gdi);
+          double* ablk = arow + k * D;       // (k == own particle: overwritten by the diagonal block below)
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+            const double Bcc = fma(fc, rec[cc], rc == cc ? f0 : 0.0);    // B = eta I + (eta'/r) rho rho^T, row rc
+            Ad[cc] += Bcc;
+            if (owner) ablk[cc] = -Bcc;
+          }
+        }
+        if (owner) {
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) arow[ra * D + cc] = Ad[cc];
+          s_gd[w][p] = gdi;
+        }
+      }
+      __syncthreads();
+      FF_STAMP(3);
+      FF_SCHED_FENCE();
+      // ------------------------------------------------------------------ J' = A J on the matrix cores, (grad Delta)' = -J^T g
+      {
+        double Jin[NB];
+#pragma unroll
+        for (int e = 0; e < NB; e++) Jin[e] = form(1 + e);
         const double* Aw = s_A[w];
 #pragma unroll
         for (int I = 0; I < MB; I++) {
@@ -285,121 +392,71 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             out[1 + I * MB + Kc] = acc;
           }
         }
-        double* Sw = s_S[w];
-#pragma unroll
-        for (int I = 0; I < MB; I++) {
-#pragma unroll
-          for (int Kc = I; Kc < MB; Kc++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int K = 0; K < MB; K++) acc = ff_mfma4(Jt[I * MB + K], Jt[Kc * MB + K], acc);
-            Sw[(4 * I + r) * AS + 4 * Kc + c] = acc;
-            if (Kc != I) Sw[(4 * Kc + c) * AS + 4 * I + r] = acc;
-          }
-        }
-        // grad Delta' = -J^T g: component 4K + r (K = c) from the transposed blocks, summed over the quad
+        // component 4K + c of g^T J: sum over the rows 4I + r -- over I on the lane, over r across the walker's four quads; the
+        // lane keeps the component of its own coordinate p = 4r + c
         double dd = 0.0;
 #pragma unroll
         for (int K = 0; K < MB; K++) {
           double t = 0.0;
 #pragma unroll
-          for (int I = 0; I < MB; I++) t = fma(gdc[I], Jt[I * MB + K], t);
-          t += ff_swap1(t);
-          t += ff_swap2(t);
-          dd = (c == K) ? t : dd;
+          for (int I = 0; I < MB; I++) t = fma(s_gd[w][4 * I + r], Jin[I * MB + K], t);
+          t += ff_lane_read(t, ln ^ 16);
+          t += ff_lane_read(t, ln ^ 32);
+          dd = (r == K) ? t : dd;
         }
+        // Delta' = -div v and (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar): summed over the walker's lanes, integrated by two spare ones
+        const double dtot = walker_sum(dsum), qtot = walker_sum(fma(gdi, kin, qsum));
+        out[0] = owner ? vi : (p == PDL ? -dtot : (p == PLP ? -qtot : 0.0));
+        out[IK] = wk;                         // (row lanes beyond M read the zero record: all their sums vanish)
         out[IDD] = -dd;
       }
-      __syncthreads();
-      FF_STAMP(3);
-      // ------------------------------------------------------------------ R2: radius lanes contract their terms with S
-#pragma unroll
-      for (int qk = 0; qk < NQ; qk++) {
-        int id = rq_id[qk];
-        FF_OPAQUE(id);
-        if (id >= 0) {
-          const int qg = id & 15, a = (id >> 4) & 15, bb0 = (id >> 8) & 15, pr = id >> 12;
-          const bool pair = bb0 != 15;
-          const int bb = pair ? bb0 : a;
-          const double* rec = &s_rec[(qg * R + pr) * RW];
-          double rho[D];
-#pragma unroll
-          for (int cc = 0; cc < D; cc++) rho[cc] = rec[cc];
-          const double f1ri = rec[D], gq = rec[D + 1], ri2 = rec[D + 2], f2 = rec[D + 3], Bc = rec[D + 4];
-          const double* Sg = s_S[qg];
-          double W[D][D];
-#pragma unroll
-          for (int cc = 0; cc < D; cc++)
-#pragma unroll
-            for (int c2i = 0; c2i < D; c2i++) {
-              double ww = Sg[(a * D + cc) * AS + a * D + c2i];
-              if (pair) ww += Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i] - Sg[(a * D + c2i) * AS + bb * D + cc];
-              W[cc][c2i] = ww;
-            }
-          double w1[D], qq = 0.0, tr = 0.0;
-#pragma unroll
-          for (int cc = 0; cc < D; cc++) {
-            double t = 0.0;
-#pragma unroll
-            for (int c2i = 0; c2i < D; c2i++) t = fma(W[cc][c2i], rho[c2i], t);
-            w1[cc] = t;
-            qq = fma(rho[cc], t, qq);
-            tr += W[cc][cc];
-          }
-          qq *= ri2;
-          const double tq = tr - qq;                       // sum_i (|delta_i|^2 - r1_i^2)
-          const double F2 = fma(f2, qq, f1ri * tq), F1x2 = 2.0 * f1ri;
-#pragma unroll
-          for (int cc = 0; cc < D; cc++) {
-            const double quad = fma(F2, rho[cc], F1x2 * w1[cc]);
-            atomicAdd(&s_ws[qg][a * D + cc], quad);
-            if (pair) atomicAdd(&s_ws[qg][bb * D + cc], -quad);
-          }
-          atomicAdd(&s_ls[qg], fma(Bc, qq, gq * tq));
-        }
-      }
-      __syncthreads();
       FF_STAMP(4);
-      // ------------------------------------------------------------------ per-coordinate sums
-      {
-        const double gdp = owner ? s_gd[w][p] : 0.0;
-        out[0] = owner ? s_v[w][p] : 0.0;
-        out[IK] = owner ? s_ws[w][p] : 0.0;
-        out[IDL] = (p == 0) ? -s_ds[w] : 0.0;
-        out[ILP] = owner ? -(((p == 0) ? s_ls[w] : 0.0) + gdp * kin) : 0.0;
-      }
-      FF_STAMP(5);
+      FF_SCHED_FENCE();
       // ------------------------------------------------------------------ consume (Dormand-Prince bookkeeping)
       if (s == -2) {
+        ctl_t C; C.get(s_ctl[w]);
+        __syncthreads();
+        const double sens_w = C.sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         double p0 = 0.0, p1 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double isc = (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fabs(y[v]), rtol, atol));
-          p0 = fma(y[v] * isc, y[v] * isc, p0);
+          const double yv = y.get(v);
+          const double isc = wgt(v) * ff_rcp(fma(fabs(yv), rtol, atol));
+          p0 = fma(yv * isc, yv * isc, p0);
           p1 = fma(c0[v] * isc, c0[v] * isc, p1);
         }
         const double d0 = sqrt(walker_sum(p0) * (1.0 / NT));
-        d1v = sqrt(walker_sum(p1) * (1.0 / NT));
-        h0v = S.h0(d0, d1v);
+        C.d1v = sqrt(walker_sum(p1) * (1.0 / NT));
+        C.h0v = C.S.h0(d0, C.d1v);
         s = -1;
-        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {   // every walker of the wave brings its own first step
-          S.habs = fmin(hwarm, S.interval);
-          S.plan();
+        if (!ff_wave_or(&s_any, lane, (!C.S.done && !(C.hwarm > 0.0)) ? 1 : 0)) {   // every walker of the wave brings its own first step
+          C.S.habs = fmin(C.hwarm, C.S.interval);
+          C.S.plan();
           s = 1;
         }
+        s_ctl[w].get(C);
+        __syncthreads();
       } else if (s == -1) {
+        ctl_t C; C.get(s_ctl[w]);
+        __syncthreads();
+        const double sens_w = C.sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double t = (out[v] - c0[v]) * (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fabs(y[v]), rtol, atol));
+          const double yv = y.get(v);
+          const double t = (out[v] - c0[v]) * wgt(v) * ff_rcp(fma(fabs(yv), rtol, atol));
           p2 = fma(t, t, p2);
         }
-        const double d2 = sqrt(walker_sum(p2) * (1.0 / NT)) / h0v;
-        S.init_habs(h0v, d1v, d2);
-        if (warm) S.habs = fmin(hwarm, S.interval);
-        S.plan();
+        const double d2 = sqrt(walker_sum(p2) * (1.0 / NT)) / C.h0v;
+        C.S.init_habs(C.h0v, C.d1v, d2);
+        if (C.hwarm > 0.0) C.S.habs = fmin(C.hwarm, C.S.interval);
+        C.S.plan();
+        s_ctl[w].get(C);
+        __syncthreads();
         s = 1;
       } else if (s == 0) {
 #pragma unroll
@@ -416,11 +473,11 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       } else if (s == 3) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v], yv = y[v];
+          const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v], yv = y.get(v);
           c0[v] = fma(hs, FF_A40 * k0v + FF_A41 * k1v + FF_A42 * k2v + FF_A43 * k3v, yv);
           c1[v] = fma(hs, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
           c2[v] = fma(hs, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
-          c3[v] = hs * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+          c3.set(v, hs * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v));
         }
         s = 4;
       } else if (s == 4) {
@@ -428,58 +485,68 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         for (int v = 0; v < NV; v++) {
           c1[v] = fma(hs * FF_A54, out[v], c1[v]);
           c2[v] = fma(hs * FF_B4, out[v], c2[v]);
-          c3[v] = fma(hs * FF_E4, out[v], c3[v]);
+          c3.set(v, fma(hs * FF_E4, out[v], c3.get(v)));
         }
         s = 5;
       } else if (s == 5) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c2[v] = fma(hs * FF_B5, out[v], c2[v]);
-          c3[v] = fma(hs * FF_E5, out[v], c3[v]);
+          c3.set(v, fma(hs * FF_E5, out[v], c3.get(v)));
         }
         s = 6;
       } else {
+        const double sens_w = s_ctl[w].sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
         double pe = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double e = fma(hs * FF_E6, out[v], c3[v]);
-          const double t = e * (v >= 1 ? sens_w : 1.0) * ff_rcp(fma(fmax(fabs(y[v]), fabs(c2[v])), rtol, atol));   // c2 = the candidate y_new
+          const double e = fma(hs * FF_E6, out[v], c3.get(v)), yv = y.get(v);
+          const double t = e * wgt(v) * ff_rcp(fma(fmax(fabs(yv), fabs(c2[v])), rtol, atol));   // c2 = the candidate y_new
           pe = fma(t, t, pe);
         }
         const double err = sqrt(walker_sum(pe) * (1.0 / NT));
-        const bool was_active = !S.done;
-        const bool acc = S.decide(err, A.max_steps);
-        if (acc) hmax_acc = fmax(hmax_acc, fabs(hs));
+        ctl_t C; C.get(s_ctl[w]);
+        __syncthreads();
+        const bool was_active = !C.S.done;
+        const bool acc = C.S.decide(err, A.max_steps);
+        if (acc) C.hmax_acc = fmax(C.hmax_acc, fabs(hs));
         if (acc) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) { y[v] = c2[v]; c0[v] = out[v]; }
+          for (int v = 0; v < NV; v++) { y.set(v, c2[v]); c0[v] = out[v]; }
         }
-        S.plan();
-        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
+        C.S.plan();
+        s_ctl[w].get(C);
+        __syncthreads();
+        const int any = ff_wave_or(&s_any, lane, C.S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
       FF_STAMP(6);
+      FF_SCHED_FENCE();
     }
     // ---------------------------------------------------------------------- results
-    const double delta = walker_sum(y[IDL]);
     if (valid) {
+      ctl_t C; C.get(s_ctl[w]);
+      const ff_stepper& S = C.S;
+      const double hmax_acc = C.hmax_acc, hwarm = C.hwarm;
       const bool failed = S.fail != 0;
       const double bad = failed ? __builtin_nan("") : 0.0;   // failed integration -> NaN results (see ff_ode_fwd_kernel)
       if (owner) {
-        A.y_out[b * M + p] = y[0] + bad;
-        A.kbar[b * M + p] = y[IK];
-        A.Lpart[b * M + p] = y[ILP];
+        A.y_out[b * M + p] = y.get(0) + bad;
+        A.kbar[b * M + p] = y.get(IK);
+        A.dD[b * M + p] = y.get(IDD);
+        if (p > 0) A.Lpart[b * M + p] = 0.0;
       }
-      if (4 * c + r < M && c < MB) A.dD[b * M + 4 * c + r] = y[IDD];
+      if (p == PDL) A.dl_out[b] = y.get(0) + bad;
+      if (p == PLP) A.Lpart[b * M] = y.get(0);
 #pragma unroll
       for (int I = 0; I < MB; I++)
 #pragma unroll
         for (int K = 0; K < MB; K++) {
-          if (4 * I + r < M && 4 * K + c < M) A.Jt[(b * M + 4 * K + c) * M + 4 * I + r] = y[1 + I * MB + K];   // Jt[b][i][k] = dz_k/dx_i
+          if (4 * I + r < M && 4 * K + c < M) A.Jt[(b * M + 4 * K + c) * M + 4 * I + r] = y.get(1 + I * MB + K);   // Jt[b][i][k] = dz_k/dx_i
         }
       if (r == 0 && c == 0) {
-        A.dl_out[b] = delta + bad;
         if (A.h_out) A.h_out[b] = hmax_acc > 0.0 ? hmax_acc : hwarm;
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }

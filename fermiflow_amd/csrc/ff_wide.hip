@@ -284,8 +284,11 @@ FF_D double ff_quad_sum(double v) {
   return v;
 }
 
+#ifndef FF_WIDE_T1_WAVES
+#define FF_WIDE_T1_WAVES 1
+#endif
 template <int D, int T, bool TAB, class TJ>
-__global__ void __launch_bounds__(FF_WAVE * T)
+__global__ void __launch_bounds__(FF_WAVE * T, T == 1 ? FF_WIDE_T1_WAVES : 1)
 ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   typedef ff_wide_mma<TJ> MMA;
   constexpr bool F32 = sizeof(TJ) == 4;

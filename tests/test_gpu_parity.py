@@ -512,8 +512,11 @@ def test_walker_schedule_is_invisible_in_the_results(dev):
         assert torch.equal(r0[k], r1[k]), k
     assert torch.equal(steps0, steps1)
     # the predictor does its job: the walkers the flow pass marks expensive are the ones the sensitivity pass works on longest
-    top = order[: B // 100].long()
-    assert steps0[top].double().mean() > 1.5 * steps0.double().mean()
+    # (steps0: attempted steps of the sensitivity pass; most walkers take the same few, the tail takes up to ten times as many)
+    heavy = (steps0 >= steps0.median() + 2).nonzero().squeeze(1)
+    rank = torch.empty(B, dtype=torch.long, device=dev)
+    rank[order.long()] = torch.arange(B, device=dev)
+    assert heavy.numel() > 0 and (rank[heavy] < B // 20).double().mean() > 0.7
     w = (r0["eloc"] - r0["eloc"].mean()) / B
     gx0, gp0 = native.cnf_adjoint(net, r0["z"], w[:, None, None] * r0["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8)
     gx1, gp1 = native.cnf_adjoint(net, r0["z"], w[:, None, None] * r0["glogp0"], -w, 0.0, 1.0, 1e-6, 1e-8,

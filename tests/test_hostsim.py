@@ -380,6 +380,32 @@ def test_three_local_energy_kernels_agree(golden, kind, monkeypatch):
     np.testing.assert_allclose(lap, G["z2_nt_lap"][:7], rtol=1e-7, atol=1e-6)
 
 
+@pytest.mark.parametrize("nup,ndn,B", [(1, 1, 5), (2, 1, 2), (2, 2, 5), (3, 2, 3)])
+def test_matrix_core_kernel_every_block_count(nup, ndn, B):
+    """ff_eloc_mfma_kernel for 2 ... 5 particles (one to three 4 x 4 blocks per side, coordinates that do not fill the last block,
+    one or two radius slots per lane, walker groups with idle slots) against the oracle; 6 particles: the test above."""
+    import subprocess, sys, json, os
+    code = ("import numpy as np, json; from tests.hostsim import simlib as S; from oracle import oracle as O;"
+            f"nup,ndn,B={nup},{ndn},{B}; n=nup+ndn; rng=np.random.default_rng(7*n+B);"
+            "eta=[rng.normal(size=10)*0.5, rng.normal(size=10)*0.3, rng.normal(size=10)*0.06];"
+            "mu=[rng.normal(size=6)*0.5, rng.normal(size=6)*0.3, rng.normal(size=6)*0.06];"
+            "x=rng.normal(size=(B,n,2))*1.2;"
+            "ref=O.eloc(x,nup,ndn,O.Net(eta,mu),2.0,rtol=1e-11,atol=1e-13);"
+            "out=[]\n"
+            "for table in (True, False):\n"
+            "    r=S.eloc(x,nup,ndn,S.Net(eta,mu,table=table),2.0,rtol=1e-9,atol=1e-11);"
+            "    out.append([r['eloc'].tolist(), r['grad'].tolist(), r['lap'].tolist(), r['stats'].tolist()])\n"
+            "print(json.dumps([out, ref['eloc'].tolist(), ref['grad'].tolist(), ref['lap'].tolist()]))")
+    env = dict(os.environ, FF_ELOC_KERNEL="mfma")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res, el, gr, lap = json.loads(out.decode().strip().splitlines()[-1])
+    for r in res:
+        assert r[3][3] == 0
+        np.testing.assert_allclose(r[0], el, rtol=1e-7)
+        np.testing.assert_allclose(r[1], gr, atol=1e-7)
+        np.testing.assert_allclose(r[2], lap, rtol=1e-6, atol=1e-6)
+
+
 def test_state_sums_of_the_finite_temperature_estimator():
     """ff_state_sums: per-state sums over the sorted state list (src/VMC.py:164-169), including empty states and the
     everything-in-state-0 case of beta = 10."""

@@ -10,7 +10,7 @@ python3 - "$csrc" "$kind" "$@" <<'PY'
 import sys
 csrc, kind, args = sys.argv[1], sys.argv[2], sys.argv[3:]
 src = open(csrc + "/ff_cnf_fwd.hip").read()
-head = src[:src.index("template <int N, int D, int MODE, bool TAB>\n__global__ void __launch_bounds__(FF_WAVE, FF_FWD_WAVES_PER_SIMD)")]
+head = src[:src.index("template <int N, int D, int MODE, bool TAB>\n__global__ void __launch_bounds__(FF_WAVE,")]
 if kind == "rows":
     n, split = args[0], args[1]; wps = args[2] if len(args) > 2 and args[2].isdigit() else "1"
     inst = f'#include "ff_eloc_rows.h"\ntemplate __global__ void ff_eloc_rows_kernel<{n}, 2, {split}, true, {wps}>(ff_fwd_args);\n'

@@ -14,10 +14,19 @@ z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
 net = model.cnf.v_wrapper.v.net()
 cost = torch.empty(B, dtype=torch.int32, device=dev); hg = torch.empty(B, dtype=torch.float64, device=dev)
 x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
+if os.environ.get("FF_AB_LIGHT"):      # throughput only: the walkers of the lowest cost classes, repeated to fill the batch
+    keep = (cost <= int(os.environ["FF_AB_LIGHT"])).nonzero().squeeze(1)
+    idx = keep[torch.arange(B, device=dev) % keep.numel()]
+    x, z, cost, hg = x[idx].contiguous(), z[idx].contiguous(), cost[idx].contiguous(), hg[idx].contiguous()
+    print("light walkers:", keep.numel(), "of", B)
+if os.environ.get("FF_AB_HEAVY"):      # latency only: the walkers of the highest cost classes alone
+    idx = torch.argsort(cost, descending=True)[: int(os.environ["FF_AB_HEAVY"])]
+    x, z, cost, hg = x[idx].contiguous(), z[idx].contiguous(), cost[idx].contiguous(), hg[idx].contiguous()
+    B = x.shape[0]
 order = native.walker_order(cost)
 tu, td = model._tables(dev)
 scale = model._h_scale_eloc
-wc = torch.zeros(B, dtype=torch.int32, device=dev)
+wc = torch.zeros(x.shape[0], dtype=torch.int32, device=dev)
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, pass1_events=(e0, e1),
@@ -31,6 +40,8 @@ if os.environ.get("FERMIFLOW_LIB", "").endswith("stamps.so"):
     tot = st.sum()
     kind = os.environ.get("FF_ELOC_KERNEL", "mfma")
     names = ["form", "publish", "R1", "sweep/mfma", "R2", "sums", "consume", "epilogue", "-"]
+    if kind == "mfma":
+        names = ["form", "publish", "R1", "rows", "products", "R2", "sums+consume", "epilogue", "-"]
     nwe = r["stats"][0].item() / (4.0 if kind == "mfma" else 5.0)
     print("phase cycles per wave-eval:", {n: int(v / nwe) for n, v in zip(names, st)}, "total/eval", int(tot / nwe))
 torch.save(r["eloc"].cpu(), f"/tmp/eloc_{os.environ.get('FF_ELOC_KERNEL', 'rows')}.pt")
