@@ -369,18 +369,18 @@ def test_three_local_energy_kernels_agree(golden, kind, monkeypatch):
     import subprocess, sys, json, os
     code = ("import numpy as np, json; from tests.hostsim import simlib as S; from tests.common import net_arrays;"
             "G=np.load('tests/golden/g5_gsvmc.npz'); eta,mu=net_arrays(G,'z2_nt_');"
-            "r=S.eloc(G['z2_nt_x'][:7],3,3,S.Net(eta,mu,table=True),2.0,rtol=1e-9,atol=1e-11);"
+            "r=S.eloc(G['z2_nt_x'][:4],3,3,S.Net(eta,mu,table=True),2.0,rtol=1e-9,atol=1e-11);"
             "print(json.dumps([r['eloc'].tolist(), r['lap'].tolist(), r['stats'].tolist()]))")
     env = dict(os.environ, FF_ELOC_KERNEL=kind)
     out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     el, lap, st = json.loads(out.decode().strip().splitlines()[-1])
     G = golden["g5_gsvmc"]
     assert st[3] == 0
-    np.testing.assert_allclose(el, G["z2_nt_Eloc"][:7], rtol=1e-8)
-    np.testing.assert_allclose(lap, G["z2_nt_lap"][:7], rtol=1e-7, atol=1e-6)
+    np.testing.assert_allclose(el, G["z2_nt_Eloc"][:4], rtol=1e-8)
+    np.testing.assert_allclose(lap, G["z2_nt_lap"][:4], rtol=1e-7, atol=1e-6)
 
 
-@pytest.mark.parametrize("nup,ndn,B", [(1, 1, 5), (2, 1, 2), (2, 2, 5), (3, 2, 3)])
+@pytest.mark.parametrize("nup,ndn,B", [(1, 1, 5), (2, 1, 2), (2, 2, 3), (3, 2, 2)])
 def test_matrix_core_kernel_every_block_count(nup, ndn, B):
     """ff_eloc_mfma_kernel for 2 ... 5 particles (one to three 4 x 4 blocks per side, coordinates that do not fill the last block,
     one or two radius slots per lane, walker groups with idle slots) against the oracle; 6 particles: the test above."""
@@ -626,7 +626,7 @@ def test_one_walker_per_workgroup_kernels(nup, ndn, d, B, force):
     gxo, gpo, _ = O.cnf_adjoint(zo, dlo, az, ad, onet, rtol=1e-11, atol=1e-13)
     prev = S.lib().ff_set_kernel_family(1 if force else 0)
     try:
-        for table in ((True, False) if n < 10 else (True,)):
+        for table in ((True, False) if n < 10 and d == 2 else (True,)):      # (the direct-evaluation variants: once, on the smallest system)
             net = S.Net(eta, mu, table=table)
             xs, st = S.cnf_generate(x, net, **tol)
             assert st[3] == 0
