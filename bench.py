@@ -79,8 +79,8 @@ def eloc_kernel_name(n, d=2):
     if os.environ.get("FF_WIDE") == "1" or kind == "wide" or (d == 2 and n >= int(os.environ.get("FF_WIDE_ELOC_FROM", "11")) and kind == "auto") \
             or (d == 2 and n > 12) or (d == 3 and n > 4):
         return "wide", f"ff_wide_eloc_kernel<{d}, {(n * d + 4 + 15) // 16}, true>"
-    if kind == "mfma" and n <= 6:
-        return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 1>"
+    if d == 2 and 2 <= n <= 6 and (kind == "mfma" or (kind == "auto" and n >= int(os.environ.get("FF_MFMA_ELOC_FROM", "4")))):
+        return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 2>"
     split = {7: 2, 8: 2, 9: 3, 10: 3, 11: 2, 12: 2}.get(n, 1)
     if kind == "rows" or n in (1, 7, 9, 11) or (kind in ("auto", "mfma") and n >= 9):
         return "rows", f"ff_eloc_rows_kernel<{n}, 2, {split}, true, 1>"
@@ -322,7 +322,8 @@ def main():
                 "bound": "mfma" if kind in ("mfma", "wide") else "fp64-valu",
                 "note": ("one walker per workgroup; J' = A J and S = J J^T on " + ("v_mfma_f32_16x16x4 (fp32 sensitivity matrices: priced against the fp32 "
                          "matrix peak)" if f32_path else "v_mfma_f64_16x16x4") + " (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
-                         if kind == "wide" else "runs on v_mfma_f64_4x4x4 + fp64 VALU" if kind == "mfma" else
+                         if kind == "wide" else ("four walkers per wave, two waves per SIMD; J' = A J and S = J J^T on v_mfma_f64_4x4x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU; "
+                          "the flops are those of the S = J J^T formulation this kernel runs (the column sweep of rounds 1-2 priced 13575 per evaluation at 6 particles)") if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
                         ("; peak = MI355X fp32 matrix peak" if f32_path else "; peak = MI355X fp64 vector = fp64 matrix peak"),
