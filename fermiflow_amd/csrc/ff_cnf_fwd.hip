@@ -1274,14 +1274,61 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
 #ifndef FF_MFMA_WPS
 #define FF_MFMA_WPS 2   // waves per SIMD the matrix-core kernel is compiled for (A/B knob)
 #endif
-// Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12
+// Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12, two waves per SIMD.
+//
+// Routing by cost class.  The launch cannot end before its longest chain of steps has: a walker with a particle passing the origin
+// takes 20-30 steps of 7 dependent evaluations, 3.7 us each for a lone wave of this kernel -- as long as the other 99.6 % of the
+// walkers need the whole GPU.  The one-walker-per-wave kernel of ff_wide.hip runs one evaluation in 2.6 us.  With cost classes at
+// hand (ff_ode.walker_class: the sweeps pass the flow pass's) the walkers of class >= FF_HEAVY_CLASS (0.4 % at config 2) therefore go
+// to that kernel, launched first on the caller's stream (one wave per walker; its 292 registers keep the SIMD to itself), and
+// everyone else to this one on a side stream, both joined before anything else runs.  Which kernel integrates a walker depends on
+// the walker's own class only, never on the batch it is part of or on the order of work.
+#ifndef FF_HEAVY_CLASS
+#define FF_HEAVY_CLASS 12
+#endif
+#ifndef FF_HEAVY_TOL
+#define FF_HEAVY_TOL 0.3
+#endif
+struct ff_side_lane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static ff_side_lane* ff_side() {
+  static thread_local ff_side_lane lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  ff_side_lane& l = lanes[dev];
+  if (!l.stream) {
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) { l.stream = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &l;
+}
 template <int N, int D>
-static void launch_mfma(void* stream, const ff_fwd_args& a) {
-  int64_t ngroups = (a.B + 3) / 4;
-  const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
-  const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
-  if (a.evt) FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), grid, FF_WAVE, stream, a);
-  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), grid, FF_WAVE, stream, a);
+static void launch_mfma(void* stream, const ff_fwd_args& a_in) {
+  ff_fwd_args a = a_in;
+  const int64_t ngroups = (a.B + 3) / 4;
+  const char* eh = getenv("FF_HEAVY_CLASS");       // (read per call: tests and probes switch it inside one process; <= 0: no routing)
+  const int heavy_class = eh ? atoi(eh) : FF_HEAVY_CLASS;
+  ff_side_lane* side = (a.evt && a.wclass && heavy_class > 0 && ff_wide_supported(N, D)) ? ff_side() : nullptr;
+  if (side && hipEventRecord(side->fork, (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
+    ff_fwd_args h = a;
+    h.queue = nullptr; h.heavy_mode = 1; h.heavy_class = heavy_class;      // grid-stride over every walker, the light ones skipped
+    // These are the walkers whose E_loc error is largest (the embedded error estimate underrates the kink they pass), and their
+    // chain has slack now: they are integrated at FF_HEAVY_TOL x (rtol, atol)
+    const char* et = getenv("FF_HEAVY_TOL");
+    const double heavy_tol = et ? atof(et) : FF_HEAVY_TOL;
+    if (heavy_tol > 0.0) { h.rtol *= heavy_tol; h.atol *= heavy_tol; }
+    a.heavy_mode = 2; a.heavy_class = heavy_class;
+    (void)ff_wide_eloc_heavy(stream, N, D, h, 1024);                       // placed first: the persistent grid below takes every register file it finds
+    const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+    FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, side->stream, a);
+    (void)hipEventRecord(side->join, side->stream);
+    (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0);
+    a.heavy_mode = 0;                                                      // (the fallback, if it has to run, redoes every walker)
+  } else if (a.evt) {
+    const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+    FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, stream, a);
+  }
+  const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), (unsigned)(ngroups < cap1 ? ngroups : cap1), FF_WAVE, stream, a);
 }
 
 static std::atomic<uint64_t> g_evt_counter{1};

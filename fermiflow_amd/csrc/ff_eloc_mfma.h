@@ -168,8 +168,10 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     }
     if (grp >= ngroups) break;
     const int64_t bq = grp * G + w;
-    const bool valid = bq < A.B;
-    const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);
+    const bool inb = bq < A.B;
+    const int64_t b = ff_opt_load(A.order, inb, bq, A.y_in, (int32_t)bq);
+    // routing by cost class (launch_mfma): with heavy_mode = 2 the walkers of class >= heavy_class belong to another launch
+    const bool valid = inb && !(A.heavy_mode == 2 && ff_opt_load(A.wclass, inb, b, A.y_in, (int32_t)0) >= A.heavy_class);
     // Dormand-Prince storage as in ff_ode_fwd_kernel: y, c0..c2 (k0..k2, then the inputs of stages 4, 5 and y_new), c3 (error)
     double c0[NV], c1[NV], c2[NV];
     ff_jsplit_vec<NB, 3> y(&s_cv[0][0], lane), c3(&s_cv[NB][0], lane);

@@ -35,6 +35,9 @@ struct ff_fwd_args {
   // Work queue (optional): with `queue` set the launch is a persistent grid and every workgroup takes its next walker
   // group from this counter (slot 0: table kernel, slot 1: direct kernel), zeroed by the host before the launch.
   unsigned long long* queue;
+  // Routing of the local-energy pass by cost class (needs wclass): heavy_mode 1 = this launch integrates ONLY the walkers with
+  // class >= heavy_class, 2 = only the others, 0 = every walker (ff_cnf_fwd.hip, launch_mfma)
+  int heavy_mode, heavy_class;
 };
 
 // Kernels for walkers that do not fit one wave's column / row layouts (n > 12 in d = 2, n > 4 in d = 3): ff_wide.hip.
@@ -42,5 +45,7 @@ struct ff_fwd_args {
 int ff_wide_dispatch_fwd(int mode, void* stream, int n, int d, const ff_fwd_args& a);
 // nonzero if the wide family serves (n, d)
 int ff_wide_supported(int n, int d);
+// the local-energy kernel of the family for the walkers a launch with heavy_mode = 1 selects: at most `max_groups` single-walker workgroups
+int ff_wide_eloc_heavy(void* stream, int n, int d, const ff_fwd_args& a, int64_t max_groups);
 // FF_WIDE=1 in the environment routes EVERY particle number to the wide family (A/B and parity testing)
 bool ff_wide_forced();

@@ -371,6 +371,10 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     }
     if (bq >= A.B) break;
     const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);
+    if (A.heavy_mode) {      // routing by cost class (workgroup-uniform): this launch takes one side of the threshold only
+      const bool heavy = A.wclass[b] >= A.heavy_class;
+      if (heavy != (A.heavy_mode == 1)) continue;
+    }
     TJ yJ[NVJ], c0J[NVJ], c1J[NVJ], c2J[NVJ];
     ff_wide_vec<TJ, NVJ, NTHR, C3_LDS> c3J(s_c3, tid);
     double y[NVS], c0[NVS], c1[NVS], c2[NVS];
@@ -729,6 +733,15 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
   if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float>), grid, FF_WAVE * T, stream, a, n);
   else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double>), grid, FF_WAVE * T, stream, a, n);
   FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double>), grid, FF_WAVE * T, stream, a, n);
+}
+
+int ff_wide_eloc_heavy(void* stream, int n, int d, const ff_fwd_args& a, int64_t max_groups) {
+  if (!ff_wide_supported(n, d) || (n * d + 4 + 15) / 16 != 1 || !a.evt || a.queue) return FF_EUNSUPPORTED;   // (table kernel, T = 1, grid-stride)
+  const unsigned grid = (unsigned)(a.B < max_groups ? a.B : max_groups);
+  if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double>), grid, FF_WAVE, stream, a, n);
+  else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double>), grid, FF_WAVE, stream, a, n);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
 }
 
 int ff_wide_dispatch_fwd(int mode, void* stream, int n, int d, const ff_fwd_args& a) {

@@ -47,6 +47,14 @@ inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); re
 #define hipMemcpyDeviceToDevice 3
 inline int hipMemcpyAsync(void* dst, const void* src, size_t n, int, void*) { memcpy(dst, src, n); return 0; }
 #define hipDeviceAttributeMultiprocessorCount 0
+// (launches run to completion inside hipLaunchKernelGGL: streams and events have nothing to order)
+typedef void* hipEvent_t;
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline int hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int one; *s = &one; return 0; }
+inline int hipEventCreateWithFlags(hipEvent_t* e, unsigned) { static int one; *e = &one; return 0; }
+inline int hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline int hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline int hipGetDevice(int* d) { *d = 0; return 0; }
 inline int hipDeviceGetAttribute(int* v, int, int) { *v = 2; return 0; }   // the simulator pretends to have two CUs
 

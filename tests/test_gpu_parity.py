@@ -636,10 +636,10 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     assert int(a["stats"][3]) == 0 and int(b["stats"][3]) == 0
     assert int(b["stats"][0]) < 0.8 * int(a["stats"][0]), (a["stats"][:3], b["stats"][:3])
     ra, rb = (a["eloc"] / tight - 1).abs(), (b["eloc"] / tight - 1).abs()
-    # maximum over ALL walkers (set by the strict ones, i.e. by the walkers with a particle passing the origin): 2.5e-6 at 6
-    # particles with the matrix-core kernel (its weight of Delta / lap Delta in the error norm trades their error against the
-    # longest chain of steps of the launch: csrc/ff_eloc_mfma.h, FF_MFMA_SUMW; 2.1e-7 with the column kernel), 1.3e-6 at 12 -- bar 1e-5
-    assert rb[loose].max().item() < 1e-6 and rb.max().item() < 3e-6, (rb[loose].max(), rb.max())
+    # maximum over ALL walkers (set by the strict ones, i.e. by the walkers with a particle passing the origin): 4.9e-7 at 6
+    # particles (those walkers, class >= 12, are routed to the one-walker-per-wave kernel at 0.3 x the tolerances: csrc/ff_cnf_fwd.hip,
+    # launch_mfma; 2.1e-7 with the column kernel of rounds 1-2), 1.3e-6 at 12 -- bar 1e-5
+    assert rb[loose].max().item() < 1e-6 and rb.max().item() < (1e-6 if nup + ndn <= 6 else 3e-6), (rb[loose].max(), rb.max())
     assert torch.equal(a["eloc"][~loose], b["eloc"][~loose]) or (rb[~loose].max() <= 2 * ra[~loose].max() + 1e-9)
     assert abs(b["eloc"].mean().item() / a["eloc"].mean().item() - 1) < 1e-7
     Es = []

@@ -406,6 +406,44 @@ def test_matrix_core_kernel_every_block_count(nup, ndn, B):
         np.testing.assert_allclose(r[2], lap, rtol=1e-6, atol=1e-6)
 
 
+def test_local_energy_routing_by_cost_class():
+    """launch_mfma (csrc/ff_cnf_fwd.hip): with cost classes the walkers of class >= FF_HEAVY_CLASS are integrated by the
+    one-walker-per-wave kernel (csrc/ff_wide.hip), the others by the four-walkers-per-wave matrix-core kernel.  Every walker is
+    integrated exactly once and agrees with the oracle; a walker's result depends on its own class only -- not on the order of
+    work, not on the rest of the batch."""
+    import subprocess, sys, json, os
+    code = ("import numpy as np, json, os; from tests.hostsim import simlib as S; from oracle import oracle as O;"
+            "rng=np.random.default_rng(5); eta=[rng.normal(size=6)*0.5, rng.normal(size=6)*0.3, rng.normal(size=6)*0.06];"
+            "mu=[rng.normal(size=6)*0.5, rng.normal(size=6)*0.3, rng.normal(size=6)*0.06];"
+            "x=rng.normal(size=(6,2,2))*1.2; cls=np.array([3,14,5,12,2,20],dtype=np.int32);"
+            "ref=O.eloc(x,1,1,O.Net(eta,mu),2.0,rtol=1e-11,atol=1e-13); net=S.Net(eta,mu,table=True); out=[]\n"
+            "def run(xx, cc, order=None):\n"
+            "    S.warm(wclass=cc, sens_tol=1.0, sens_class=0)\n"
+            "    try:\n"
+            "        r=S.eloc(xx,1,1,net,2.0,rtol=1e-9,atol=1e-11,order=order)\n"
+            "    finally:\n"
+            "        S.warm()\n"
+            "    return [r['eloc'].tolist(), r['grad'].tolist(), r['stats'].tolist()]\n"
+            "out.append(run(x, cls))\n"
+            "out.append(run(x, cls, order=np.array([5,1,3,2,0,4],dtype=np.int32)))\n"
+            "out.append(run(x[[1,4]], cls[[1,4]]))\n"
+            "os.environ['FF_HEAVY_CLASS']='0'\n"
+            "out.append(run(x, cls))\n"
+            "print(json.dumps([out, ref['eloc'].tolist(), ref['grad'].tolist()]))")
+    env = dict(os.environ, FF_ELOC_KERNEL="mfma")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    (plain, ordered, subset, unrouted), el, gr = json.loads(out.decode().strip().splitlines()[-1])
+    for r in (plain, ordered, unrouted):
+        assert r[2][3] == 0
+        np.testing.assert_allclose(r[0], el, rtol=1e-7)
+        np.testing.assert_allclose(r[1], gr, atol=1e-7)
+    assert plain[0] == ordered[0] and plain[1] == ordered[1]                       # the order of work is invisible
+    assert subset[0] == [plain[0][1], plain[0][4]]                                 # ... and so is the rest of the batch
+    light, heavy = [0, 2, 4], [1, 3, 5]
+    assert [plain[0][i] for i in light] == [unrouted[0][i] for i in light]         # light walkers: the same kernel either way
+    assert any(plain[0][i] != unrouted[0][i] for i in heavy)                       # heavy ones did go through the other kernel
+
+
 def test_state_sums_of_the_finite_temperature_estimator():
     """ff_state_sums: per-state sums over the sorted state list (src/VMC.py:164-169), including empty states and the
     everything-in-state-0 case of beta = 10."""
