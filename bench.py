@@ -323,7 +323,9 @@ def main():
                 "note": ("one walker per workgroup; J' = A J and S = J J^T on " + ("v_mfma_f32_16x16x4 (fp32 sensitivity matrices: priced against the fp32 "
                          "matrix peak)" if f32_path else "v_mfma_f64_16x16x4") + " (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
                          if kind == "wide" else ("four walkers per wave, two waves per SIMD; J' = A J and S = J J^T on v_mfma_f64_4x4x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU; "
-                          "the flops are those of the S = J J^T formulation this kernel runs (the column sweep of rounds 1-2 priced 13575 per evaluation at 6 particles)") if kind == "mfma" else
+                          "the flops are those of the S = J J^T formulation this kernel runs (the column sweep of rounds 1-2 priced 13575 per evaluation at 6 particles); "
+                          "avg_launch_ms spans the whole pass: the 0.4 % of the walkers of cost class >= 12 run beside it on the one-walker-per-wave kernel "
+                          "(ff_wide_eloc_kernel<2, 1, true, double>, DESIGN.md 3g), their evaluations are in the count") if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
                         ("; peak = MI355X fp32 matrix peak" if f32_path else "; peak = MI355X fp64 vector = fp64 matrix peak"),

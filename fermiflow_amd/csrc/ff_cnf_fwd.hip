@@ -169,8 +169,12 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     }
     if (grp >= ngroups) break;
     const int64_t bq = grp * G + g;
-    const bool valid = ingrp && bq < A.B;
-    const int64_t b = ff_opt_load(A.order, valid, bq, A.y_in, (int32_t)bq);   // the walker this lane group integrates
+    const bool inb = ingrp && bq < A.B;
+    const int64_t b = ff_opt_load(A.order, inb, bq, A.y_in, (int32_t)bq);   // the walker this lane group integrates
+    // (routing by cost class, launch_routed below: with heavy_mode = 2 the walkers of class >= heavy_class belong to another launch)
+    // (only where this kernel is the local-energy pass's default, up to 3 particles: the larger instantiations sit at the edge of the
+    // register allocator's bug of DESIGN.md 10 and are left exactly as they were)
+    const bool valid = inb && !(MODE == 2 && N <= 3 && A.heavy_mode == 2 && ff_opt_load(A.wclass, inb, b, A.y_in, (int32_t)0) >= A.heavy_class);
     // Stage storage, 5 vectors instead of the textbook 7 (y, k0..k5): c0..c2 hold k0..k2 up to stage 3; once k3 is
     // known the remaining stage inputs and the error accumulator are formed and overwrite them:
     //   c0 = input of stage 4, c1 = partial input of stage 5, c2 = partial y_new, c3 = partial error.
@@ -1237,13 +1241,63 @@ static int64_t fwd_queue_blocks() {
   return n;
 }
 
+// Routing of the local-energy pass by cost class.  A launch cannot end before its longest chain of steps has: a walker with a
+// particle passing the origin takes 20-30 steps of 7 dependent evaluations, 3.7-5.5 us each for a lone wave of the several-walkers-
+// per-wave kernels -- as long as the other 99.6 % of the walkers need the whole GPU.  The one-walker-per-wave kernel of ff_wide.hip
+// runs one evaluation in 2.6 us.  With cost classes at hand (ff_ode.walker_class: the sweeps pass the flow pass's) the walkers of
+// class >= FF_HEAVY_CLASS (0.4 % at config 2) therefore go to that kernel, launched first on the caller's stream (one wave per
+// walker; its 292 registers keep the SIMD to itself), and everyone else to the throughput kernel on a side stream, both joined
+// before anything else runs.  Which kernel integrates a walker depends on the walker's own class only, never on the batch it is
+// part of or on the order of work.  The heavy walkers are also the ones whose E_loc error is largest (the embedded error estimate
+// underrates the kink they pass) and their chain has slack now: they are integrated at FF_HEAVY_TOL x (rtol, atol).
+#ifndef FF_HEAVY_CLASS
+#define FF_HEAVY_CLASS 12
+#endif
+#ifndef FF_HEAVY_TOL
+#define FF_HEAVY_TOL 0.3
+#endif
+struct ff_side_lane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static ff_side_lane* ff_side() {
+  static thread_local ff_side_lane lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  ff_side_lane& l = lanes[dev];
+  if (!l.stream) {
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) { l.stream = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &l;
+}
+// launch_table(stream, args): the table kernel of the throughput family.  Returns true if the pass was routed (the caller's
+// fallback launch then redoes EVERY walker should it have to run: heavy_mode stays 0 in its arguments).
+template <class F>
+static bool launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F launch_table) {
+  const char* eh = getenv("FF_HEAVY_CLASS");       // (read per call: tests and probes switch it inside one process; <= 0: no routing)
+  const int heavy_class = eh ? atoi(eh) : FF_HEAVY_CLASS;
+  if (!(a.evt && a.wclass && heavy_class > 0 && n * d <= 12 && ff_wide_supported(n, d))) return false;
+  ff_side_lane* side = ff_side();
+  if (!side || hipEventRecord(side->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return false;
+  ff_fwd_args h = a, l = a;
+  h.queue = nullptr; h.heavy_mode = 1; h.heavy_class = heavy_class;      // grid-stride over every walker, the light ones skipped
+  const char* et = getenv("FF_HEAVY_TOL");
+  const double heavy_tol = et ? atof(et) : FF_HEAVY_TOL;
+  if (heavy_tol > 0.0) { h.rtol *= heavy_tol; h.atol *= heavy_tol; }
+  l.heavy_mode = 2; l.heavy_class = heavy_class;
+  (void)ff_wide_eloc_heavy(stream, n, d, h, 1024);                       // placed first: a persistent grid takes every register file it finds
+  launch_table(side->stream, l);
+  (void)hipEventRecord(side->join, side->stream);
+  (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0);
+  return true;
+}
+
 template <int N, int D, int MODE>
 static void launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
   const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);   // without a queue: one workgroup per walker group
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
-  if (a.evt) FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, stream, a);
+  auto table = [&](void* st, const ff_fwd_args& aa) { FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, st, aa); };
+  if (!(MODE == 2 && N <= 3 && launch_routed(stream, N, D, a, table)) && a.evt) table(stream, a);
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
 }
 
@@ -1274,59 +1328,15 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
 #ifndef FF_MFMA_WPS
 #define FF_MFMA_WPS 2   // waves per SIMD the matrix-core kernel is compiled for (A/B knob)
 #endif
-// Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12, two waves per SIMD.
-//
-// Routing by cost class.  The launch cannot end before its longest chain of steps has: a walker with a particle passing the origin
-// takes 20-30 steps of 7 dependent evaluations, 3.7 us each for a lone wave of this kernel -- as long as the other 99.6 % of the
-// walkers need the whole GPU.  The one-walker-per-wave kernel of ff_wide.hip runs one evaluation in 2.6 us.  With cost classes at
-// hand (ff_ode.walker_class: the sweeps pass the flow pass's) the walkers of class >= FF_HEAVY_CLASS (0.4 % at config 2) therefore go
-// to that kernel, launched first on the caller's stream (one wave per walker; its 292 registers keep the SIMD to itself), and
-// everyone else to this one on a side stream, both joined before anything else runs.  Which kernel integrates a walker depends on
-// the walker's own class only, never on the batch it is part of or on the order of work.
-#ifndef FF_HEAVY_CLASS
-#define FF_HEAVY_CLASS 12
-#endif
-#ifndef FF_HEAVY_TOL
-#define FF_HEAVY_TOL 0.3
-#endif
-struct ff_side_lane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static ff_side_lane* ff_side() {
-  static thread_local ff_side_lane lanes[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  ff_side_lane& l = lanes[dev];
-  if (!l.stream) {
-    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) { l.stream = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  return &l;
-}
+// Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12, two waves per SIMD
 template <int N, int D>
-static void launch_mfma(void* stream, const ff_fwd_args& a_in) {
-  ff_fwd_args a = a_in;
+static void launch_mfma(void* stream, const ff_fwd_args& a) {
   const int64_t ngroups = (a.B + 3) / 4;
-  const char* eh = getenv("FF_HEAVY_CLASS");       // (read per call: tests and probes switch it inside one process; <= 0: no routing)
-  const int heavy_class = eh ? atoi(eh) : FF_HEAVY_CLASS;
-  ff_side_lane* side = (a.evt && a.wclass && heavy_class > 0 && ff_wide_supported(N, D)) ? ff_side() : nullptr;
-  if (side && hipEventRecord(side->fork, (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
-    ff_fwd_args h = a;
-    h.queue = nullptr; h.heavy_mode = 1; h.heavy_class = heavy_class;      // grid-stride over every walker, the light ones skipped
-    // These are the walkers whose E_loc error is largest (the embedded error estimate underrates the kink they pass), and their
-    // chain has slack now: they are integrated at FF_HEAVY_TOL x (rtol, atol)
-    const char* et = getenv("FF_HEAVY_TOL");
-    const double heavy_tol = et ? atof(et) : FF_HEAVY_TOL;
-    if (heavy_tol > 0.0) { h.rtol *= heavy_tol; h.atol *= heavy_tol; }
-    a.heavy_mode = 2; a.heavy_class = heavy_class;
-    (void)ff_wide_eloc_heavy(stream, N, D, h, 1024);                       // placed first: the persistent grid below takes every register file it finds
-    const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
-    FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, side->stream, a);
-    (void)hipEventRecord(side->join, side->stream);
-    (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0);
-    a.heavy_mode = 0;                                                      // (the fallback, if it has to run, redoes every walker)
-  } else if (a.evt) {
-    const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
-    FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, stream, a);
-  }
+  const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  auto table = [&](void* st, const ff_fwd_args& aa) {
+    FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, st, aa);
+  };
+  if (!launch_routed(stream, N, D, a, table) && a.evt) table(stream, a);
   const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), (unsigned)(ngroups < cap1 ? ngroups : cap1), FF_WAVE, stream, a);
 }
