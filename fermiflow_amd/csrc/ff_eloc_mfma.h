@@ -120,11 +120,14 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   const int64_t ngroups = (A.B + G - 1) / G;
   // radii this lane evaluates for its own walker (slot qk: radius i16 + 16 qk): a | b (15: none) << 4 | record offset << 8
   constexpr int NQ = (R + 15) / 16;
+  constexpr bool SPLIT1B = P <= 16 && R > 16;
   const int i16 = 4 * r + c;
   int rq_id[NQ];
 #pragma unroll
   for (int qk = 0; qk < NQ; qk++) {
-    const int pr = i16 + 16 * qk;
+    // SPLIT1B (the pairs fill one slot and the one-body radii do not fit beside them: 6 particles): slot 0 holds pairs only, slot 1
+    // one-body radii only -- which a radius is becomes a compile-time property of the slot and each slot's code loses the other's half
+    const int pr = SPLIT1B ? (qk == 0 ? (i16 < P ? i16 : R) : (i16 < N ? P + i16 : R)) : i16 + 16 * qk;
     int a = 0, bb = 15;
     if (pr < P) {
       int q = pr;
@@ -239,7 +242,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         FF_OPAQUE(id);
         const bool act = id >= 0;
         const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
-        const bool pair = bb0 != 15;
+        const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
         const int bb = pair ? bb0 : a;
         double r2 = 0.0;
 #pragma unroll
@@ -286,7 +289,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         FF_OPAQUE(id);
         const bool act = id >= 0;
         const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
-        const bool pair = bb0 != 15;
+        const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
         const int bb = pair ? bb0 : a;
         const double* rho = rq_rho[qk];
         const double rr = rq_r[qk], ri = rq_ri[qk];
