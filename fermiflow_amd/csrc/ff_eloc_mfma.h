@@ -351,20 +351,25 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int cc = 0; cc < D; cc++) Ad[cc] = 0.0;
         double* arow = &s_A[w][(owner ? p : 0) * AS];
+        double dsel[D];      // row rc of the identity
+#pragma unroll
+        for (int cc = 0; cc < D; cc++) dsel[cc] = rc == cc ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < N; k++) {
           int pk = prec[k];
           FF_OPAQUE(pk);
           const double* rec = &s_rec[pk >> 1];
-          const double sg = (pk & 1) ? -1.0 : 1.0;
-          const double f0 = rec[QF0], rcv = rec[rc], fc = rec[QF1] * rcv;
-          vi = fma(sg * f0, rcv, vi);
-          wk = fma(sg, rec[QPW + rc], wk);
-          gdi = fma(sg * rec[QGQ], rcv, gdi);
+          const int smask = (int)((unsigned)pk << 31);                                        // the sign of this partner's odd terms, as a sign bit
+          const double f0 = rec[QF0], ru = rec[rc], fc = rec[QF1] * ru;
+          const double rcv = __hiloint2double(__double2hiint(ru) ^ smask, __double2loint(ru));
+          const double pw = rec[QPW + rc];
+          vi = fma(f0, rcv, vi);
+          wk += __hiloint2double(__double2hiint(pw) ^ smask, __double2loint(pw));
+          gdi = fma(rec[QGQ], rcv, gdi);
           double* ablk = arow + k * D;       // (k == own particle: overwritten by the diagonal block below)
 #pragma unroll
           for (int cc = 0; cc < D; cc++) {
-            const double Bcc = fma(fc, rec[cc], rc == cc ? f0 : 0.0);    // B = eta I + (eta'/r) rho rho^T, row rc
+            const double Bcc = fma(fc, rec[cc], f0 * dsel[cc]);               // B = eta I + (eta'/r) rho rho^T, row rc
             Ad[cc] += Bcc;
             if (owner) ablk[cc] = -Bcc;
           }
