@@ -608,6 +608,48 @@ def test_step_size_warm_start(dev):
     assert abs(Es[0][0] - Es[1][0]) < 1e-6 * abs(Es[1][0]) and abs(Es[0][1] - Es[1][1]) < 1e-5 * Es[1][1]
 
 
+@pytest.mark.parametrize("nup,ndn", [(3, 3), (2, 1)])
+def test_local_energy_routing_by_cost_class(dev, nup, ndn, monkeypatch):
+    """launch_routed (csrc/ff_cnf_fwd.hip): with cost classes the walkers of class >= 12 run on the one-walker-per-wave kernel (at
+    0.3 x the tolerances) beside the throughput kernel that takes everyone else.  Light walkers are untouched by the routing, the
+    heavy ones stay within 1e-6 of a tight solve (over seeds: 5e-7 against 2.5e-6 without it), and a walker's result depends on its own class only: not on the
+    order of work, not on the rest of the batch.  (6 particles: the matrix-core kernel; 3: the column kernel.)"""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, nup, ndn, 2.0)
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    B = 30000
+    torch.manual_seed(17)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    f = dict(dtype=torch.float64, device=dev)
+    hg, cost = torch.zeros(B, **f), torch.zeros(B, dtype=torch.int32, device=dev)
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
+    heavy = cost >= 12
+    assert 0 < int(heavy.sum()) < B // 20
+    kw = dict(walker_h_scale=model._h_scale_eloc, sens_tol=model.sens_tol, sens_tol_class=model.sens_tol_class,
+              walker_h_scale_loose=model._h_scale_loose)
+    run = lambda xx, hh, cc, **extra: native.eloc(tu, td, nup, ndn, net, xx, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True,
+                                                  walker_h_init=hh, walker_class=cc, **kw, **extra)
+    tight = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+    routed = run(x, hg, cost)
+    ordered = run(x, hg, cost, walker_order=native.walker_order(cost))
+    monkeypatch.setenv("FF_HEAVY_CLASS", "0")
+    plain = run(x, hg, cost)
+    monkeypatch.delenv("FF_HEAVY_CLASS")
+    assert int(routed["stats"][3]) == 0 and int(plain["stats"][3]) == 0
+    for k in ("eloc", "grad", "lap", "z", "dlogp"):
+        assert torch.equal(routed[k], ordered[k]), k                      # the order of work is invisible
+        assert torch.equal(routed[k][~heavy], plain[k][~heavy]), k        # light walkers: the same kernel, the same numbers
+    assert not torch.equal(routed["eloc"][heavy], plain["eloc"][heavy])  # the heavy ones did go through the other kernel
+    er, ep = (routed["eloc"] / tight - 1).abs(), (plain["eloc"] / tight - 1).abs()
+    assert er[heavy].max().item() < 1e-6 and er[heavy].max().item() <= 2 * ep[heavy].max().item() + 1e-7, (er[heavy].max(), ep[heavy].max())
+    # a sub-batch: the same walkers, the same numbers
+    idx = torch.cat([heavy.nonzero().squeeze(1)[:7], (~heavy).nonzero().squeeze(1)[:1000]])
+    sub = run(x[idx].contiguous(), hg[idx].contiguous(), cost[idx].contiguous())
+    assert torch.equal(sub["eloc"], routed["eloc"][idx]) and torch.equal(sub["grad"], routed["grad"][idx])
+
+
 @pytest.mark.parametrize("nup,ndn,B", [(3, 3, 65536), (6, 6, 8192)])
 def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     """ff_ode.walker_class / sens_tol as GSVMC/BetaVMC sweeps use it: walkers whose flow-pass cost class is <= 8
