@@ -291,11 +291,13 @@ class GSVMC(_Sweep, torch.nn.Module):
             self._side = torch.cuda.Stream()
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
-            # One (empty) kernel in front of the sampler: its launch latency alone lets the adjoint's waves be placed first -- with
-            # nothing here the Metropolis waves fill every SIMD first and the two kernels run one after the other (2.34 ms per
-            # iteration at config 2), with the empty launch 2.04-2.05 ms, with round 2's 40 us spin 2.07-2.10
-            # (FERMIFLOW_PREFETCH_DELAY_US: microseconds the kernel spins, for experiments)
-            native.stream_delay(float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "0")))
+            # One short kernel in front of the sampler lets the adjoint's waves be placed first -- with nothing here the Metropolis
+            # waves fill every SIMD first and the two kernels run one after the other (2.34 ms per iteration at config 2).  How long
+            # it spins is measured, not derived: with the column kernel of round 2 an empty launch was best (2.04-2.05 ms, 40 us:
+            # 2.07-2.10); since the local-energy pass ends on a stream join the empty launch leaves the pair's overlap
+            # to chance (1.82-1.89 ms, adjoint stage 0.64-0.72) and 10 us makes it stick (1.807-1.814, 0.625; 20 us: 1.817, 40 us: 1.825;
+            # tools/probes/bench_spread.sh).  FERMIFLOW_PREFETCH_DELAY_US overrides.
+            native.stream_delay(float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "10")))
             from .base_dist import _draw_seed
             seed = _draw_seed()
             z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
