@@ -10,7 +10,9 @@
  *  - every pointer is a DEVICE pointer to fp64 (or int32/uint8 where typed so), contiguous,
  *    row-major; walker coordinates are (B, n, d) exactly as the reference's tensors;
  *  - `stream` is a hipStream_t (0 = default stream); every call only enqueues work, no hidden sync;
- *  - the library allocates nothing: callers pass workspaces where a size query exists;
+ *  - the library allocates no memory: callers pass workspaces where a size query exists.  ff_eloc / ff_eloc_sensitivities
+ *    with ff_ode.walker_class set (up to 6 particles, d = 2) run two kernels side by side -- the second on a side stream the
+ *    library creates once per device and thread, forked from and joined to `stream` by events inside the call;
  *  - return value: 0 ok, 1 invalid argument, 2 no native instantiation for this configuration,
  *    3 HIP launch failure; ff_last_error() gives a message.  No C++ exception crosses the ABI.
  *  - orbitals are identified by their index k into HO2D().orbitals (src/orbitals.py:81,
