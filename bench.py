@@ -147,8 +147,10 @@ def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: the GPU reaches its steady clocks only after some ten iterations (tools/probes/warmup_sweep.sh: 1.93 ms per iteration
+    # at --steps 5 --warmup 2, 1.89 at 10/2, 1.84 at 20/2, 1.81 at 20/5 and 20/10: every stage shrinks by the same factor)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["gsvmc", "beta", "n12", "c5"], default="gsvmc")
     ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12), 131072 (c5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
