@@ -343,8 +343,8 @@ def main():
            "config": {"workload": ("BetaVMC beta=10 boltzmann deltaE=2 " if wl == "beta" else "GSVMC ") +
                                   f"nup={nup} ndown={ndown} {dim}D Z={args.Z} H=50 t_span=(0,1) rtol=1e-6 atol=1e-8 "
                                   f"(sensitivity components of walkers with flow cost class <= {model.sens_tol_class}: x{model.sens_tol:g}; "
-                                  + (f"walkers of class >= {os.environ.get('FF_HEAVY_CLASS', '12')}: x{os.environ.get('FF_HEAVY_TOL', '0.3')} on the one-walker-per-wave kernel; "
-                                     if (dim == 2 and n <= 6 and int(os.environ.get('FF_HEAVY_CLASS', '12')) > 0 and model.sens_tol > 1.0) else "") +
+                                  + (f"walkers of class >= {model.heavy_class or 12}: x{model.heavy_tol or 0.3:g} on the one-walker-per-wave kernel; "
+                                     if (dim == 2 and n <= 6 and model.heavy_class >= 0) else "") +
                                   f"step-size warm start {'on' if model.warm_start else 'off'}; "
                                   f"walker prefetch {'on' if getattr(model, 'prefetch_walkers', False) else 'off'}), "
                                   f"{wpg} walkers/GPU, 100 Metropolis steps/iter, seeded gaussian weights x(30,300), Adam lr={args.lr}",

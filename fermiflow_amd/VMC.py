@@ -50,6 +50,42 @@ def _flow_params(cnf):
     return v, list(v.parameters())
 
 
+def potential_plan(pair_potential, sp_potential):
+    """How `pair_potential.V(x) + sp_potential.V(x)` (src/VMC.py:51-53) is evaluated: (Z, use_ho, extra).
+
+    The stock potentials -- CoulombPairPotential(Z) and HO(), exact types -- are fused into the local-energy finish
+    (ff_eloc: Z, use_ho).  Anything else (a PairPotential subclass with its own v(), another trap) keeps the reference's
+    generic semantics: the native pass is given Z = 0 / no trap for that part and `extra` lists the objects whose V(x) is
+    called on the device walkers and added to E_loc.  An object without a callable V raises TypeError -- nothing is ever
+    silently treated as Z = 0 or as a harmonic trap."""
+    from .potentials import CoulombPairPotential, HO
+    Z, use_ho, extra = 0.0, False, []
+    if type(pair_potential) is CoulombPairPotential:
+        Z = float(pair_potential.Z)
+    elif pair_potential is not None:
+        if not callable(getattr(pair_potential, "V", None)):
+            raise TypeError(f"pair_potential {pair_potential!r} has no V(x) (src/potentials.py:23-47)")
+        extra.append(pair_potential)
+    else:
+        raise TypeError("pair_potential is required (the reference calls pair_potential.V(x) unconditionally, src/VMC.py:51)")
+    if type(sp_potential) is HO:
+        use_ho = True
+    elif sp_potential:                       # the reference's own test: `if self.sp_potential:`
+        if not callable(getattr(sp_potential, "V", None)):
+            raise TypeError(f"sp_potential {sp_potential!r} has no V(x) (src/potentials.py:5-14)")
+        extra.append(sp_potential)
+    return Z, use_ho, extra
+
+
+def _add_generic_potentials(r, x, extra):
+    """E_loc and V of a native pass plus the user-defined potentials' V(x) (torch code of the caller, on the device)."""
+    if extra:
+        v = sum(p.V(x) for p in extra).to(r["eloc"].dtype)
+        r["V"] = r["V"] + v
+        r["eloc"] = r["eloc"] + v
+    return r
+
+
 class _Sweep:
     """What GSVMC and BetaVMC share: flow + local energy of given base walkers with the walker schedule and the
     step-size warm start, the lazily converted device scalars, and the checkpointable sweep state."""
@@ -71,6 +107,12 @@ class _Sweep:
         self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "10"))
         self.sens_tol_class = 8
         self._h_scale_loose = 1.0
+        # routing of the local-energy pass (ff_ode.heavy_class / heavy_tol / sum_weight; 0 = the library's defaults 12, 0.3, 4;
+        # heavy_class < 0: no routing).  Reference semantics -- one tolerance, one kernel for every walker -- are
+        # sens_tol = 1, heavy_class = -1 (FERMIFLOW_SENS_TOL=1 FERMIFLOW_HEAVY_CLASS=-1).
+        self.heavy_class = int(os.environ.get("FERMIFLOW_HEAVY_CLASS", "0"))
+        self.heavy_tol = float(os.environ.get("FERMIFLOW_HEAVY_TOL", "0"))
+        self.sum_weight = float(os.environ.get("FERMIFLOW_SUM_WEIGHT", "0"))
 
     def _mark(self, ev, name):
         if self.profile is not None:
@@ -114,12 +156,15 @@ class _Sweep:
         order = native.walker_order(cost)
         self._mark(ev, "generate")
         p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
+        Z, use_ho, extra = potential_plan(self.pair_potential, self.sp_potential)
         r = native.eloc(tu, td, nup, ndown, net, x, t0, t1, self.cnf.rtol, self.cnf.atol,
-                        getattr(self.pair_potential, "Z", 0.0), self.sp_potential is not None, walker_state=walker_state,
+                        Z, use_ho, walker_state=walker_state,
                         want_stats=prof is not None, pass1_events=p1, walker_order=order,
                         walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he,
-                        walker_class=cost if self.sens_tol > 1.0 else None, sens_tol=self.sens_tol,
-                        sens_tol_class=self.sens_tol_class, walker_h_scale_loose=self._h_scale_loose)
+                        walker_class=cost if (self.sens_tol > 1.0 or self.heavy_class > 0) else None, sens_tol=self.sens_tol,
+                        sens_tol_class=self.sens_tol_class, walker_h_scale_loose=self._h_scale_loose,
+                        heavy_class=self.heavy_class, heavy_tol=self.heavy_tol, sum_weight=self.sum_weight)
+        _add_generic_potentials(r, x, extra)
         self._mark(ev, "eloc")
         if prof is not None:
             prof.setdefault("pass1", []).append(p1)
@@ -149,10 +194,14 @@ class _Sweep:
             st["z_next_shard"] = (int(rank), int(ws), int(getattr(self.basedist, "walker_offset", 0)))
             if len(self._z_next) > 4 and self._z_next[4] is not None:
                 st["z_next_seed"] = int(self._z_next[4])      # the Philox key they were drawn with
+            if self._z_next[3] is not None:
+                st["z_next_rng"] = self._z_next[3]            # torch's CPU generator right after that key was drawn (_prefetched_ok)
         return st
 
     def set_extra_state(self, st):
         st = st or {}      # (an absent _extra_state -- a plain parameter state_dict -- is a cold sweep state)
+        self._resume_seed = None          # (a later load without prefetched walkers must not inherit an earlier load's key)
+        self._resume_rng = None
         self._h_flow = st.get("h_flow")
         self._dev = dict(st.get("dev", {}))
         self._n_global = st.get("n_global", 0)
@@ -166,10 +215,15 @@ class _Sweep:
                 # (the Philox key comes from the restored CPU generator, the counters from the global walker index).
                 rank, ws = D.world()
                 shard = tuple(st.get("z_next_shard", (0, 1, 0)))
+                snap = st.get("z_next_rng")
+                snap = snap.cpu() if snap is not None else None
                 if shard[0] == rank and shard[1] == ws:
-                    self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), None, st.get("z_next_seed"))
+                    self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), snap, st.get("z_next_seed"))
                 else:
-                    self._resume_seed = st.get("z_next_seed")      # this rank re-draws ITS shard with the same key (forward())
+                    # this rank re-draws ITS shard with the same key (forward()), under the owner's guard (_prefetched_ok): only if
+                    # torch's CPU generator is where it was when the key was drawn -- checkpoint.load puts it there; a
+                    # torch.manual_seed() between the load and the sweep means fresh walkers on EVERY rank
+                    self._resume_seed, self._resume_rng = st.get("z_next_seed"), snap
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # a state_dict without "_extra_state" (weights trained with the reference, an earlier checkpoint, another model's
@@ -236,10 +290,10 @@ class GSVMC(_Sweep, torch.nn.Module):
         """logp, grad logp, laplacian logp, V and E_loc of every walker in one native pass (src/VMC.py:46-55)."""
         tu, td = self._tables(x.device)
         t0, t1 = self.cnf.t_span
-        Z = getattr(self.pair_potential, "Z", 0.0)
-        return native.eloc(tu, td, self.nup, self.ndown, self.cnf.v_wrapper.v.net(), x.detach(), t0, t1,
-                           self.cnf.rtol, self.cnf.atol, Z, self.sp_potential is not None,
-                           walker_state=walker_state, want_stats=want_stats)
+        Z, use_ho, extra = potential_plan(self.pair_potential, self.sp_potential)
+        r = native.eloc(tu, td, self.nup, self.ndown, self.cnf.v_wrapper.v.net(), x.detach(), t0, t1,
+                        self.cnf.rtol, self.cnf.atol, Z, use_ho, walker_state=walker_state, want_stats=want_stats)
+        return _add_generic_potentials(r, x.detach(), extra)
 
     def _native_grad_laplacian(self, x):
         r = self.local_energy(x)
@@ -257,7 +311,7 @@ class GSVMC(_Sweep, torch.nn.Module):
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
                                          equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
-            elif self._z_next is None and getattr(self, "_resume_seed", None) is not None and not self.persistent_walkers:
+            elif self._z_next is None and self._resume_ok():
                 # resumed on a rank other than the one whose prefetched walkers the checkpoint holds: the same Philox key and this
                 # rank's walker offset give exactly the walkers the uninterrupted run prefetched here (the CPU generator is not touched)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=self._resume_seed)
@@ -269,7 +323,7 @@ class GSVMC(_Sweep, torch.nn.Module):
             else:
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
             self._z_next = None
-            self._resume_seed = None
+            self._resume_seed = self._resume_rng = None
             self._z_prev = z if self.persistent_walkers else None
         self._mark(ev, "mcmc")
         return self._sweep(z, batch, ev, prefetch=nloc if (self.prefetch_walkers and not self.persistent_walkers and z.is_cuda) else 0)
@@ -281,6 +335,14 @@ class GSVMC(_Sweep, torch.nn.Module):
         if self._z_next is None or self.persistent_walkers or self._z_next[2] != nloc:
             return False
         snap = self._z_next[3]
+        return snap is None or torch.equal(snap, torch.get_rng_state())
+
+    def _resume_ok(self):
+        """A rank that resumes from another rank's checkpoint re-draws its shard with the checkpointed Philox key -- under the same
+        condition as _prefetched_ok: nobody touched torch's CPU generator since the key was drawn."""
+        if getattr(self, "_resume_seed", None) is None or self.persistent_walkers:
+            return False
+        snap = getattr(self, "_resume_rng", None)
         return snap is None or torch.equal(snap, torch.get_rng_state())
 
     def _prefetch(self, nloc, go):
@@ -443,9 +505,10 @@ class BetaVMC(_Sweep, torch.nn.Module):
     def local_energy(self, x, walker_state):
         tu, td = self._state_tables(x.device)
         t0, t1 = self.cnf.t_span
-        Z = getattr(self.pair_potential, "Z", 0.0)
-        return native.eloc(tu, td, self.nup, self.ndown, self.cnf.v_wrapper.v.net(), x.detach(), t0, t1,
-                           self.cnf.rtol, self.cnf.atol, Z, self.sp_potential is not None, walker_state=walker_state)
+        Z, use_ho, extra = potential_plan(self.pair_potential, self.sp_potential)
+        r = native.eloc(tu, td, self.nup, self.ndown, self.cnf.v_wrapper.v.net(), x.detach(), t0, t1,
+                        self.cnf.rtol, self.cnf.atol, Z, use_ho, walker_state=walker_state)
+        return _add_generic_potentials(r, x.detach(), extra)
 
     def _native_grad_laplacian(self, x):
         r = self.local_energy(x, self._walker_state(x.device))

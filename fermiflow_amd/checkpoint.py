@@ -2,7 +2,13 @@
 in the reference).  A checkpoint carries everything the NEXT iteration depends on: parameters, optimizer moments, the
 sweep state of the estimator (previous mean energies used as reduction shifts, step-size warm start, persistent walkers:
 `_extra_state` of the model's state_dict) and the torch RNG streams the sweep draws from (CPU generator -> Philox key of
-the Metropolis kernel; device generator -> BetaVMC's state sampling)."""
+the Metropolis kernel; device generator -> BetaVMC's state sampling).
+
+Multi-rank runs write ONE checkpoint (rank 0's).  Parameters, optimizer and the RNG streams are identical on every rank; of the
+sweep state, the prefetched walkers are rank-stamped (other ranks re-draw their own shard from the same Philox key: bit-identical
+to the uninterrupted run) and `h_flow`, the mean flow step size that opens the next sweep's first integration, is rank 0's local
+mean: on ranks above 0 the resumed run therefore repeats the uninterrupted one to solver tolerance (the error test of every step is
+unchanged), not bit for bit."""
 import os
 
 import torch

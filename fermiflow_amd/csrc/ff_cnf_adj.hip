@@ -710,12 +710,20 @@ static bool adj_is_wide(int n, int d) {
   return ff_wide_supported(n, d) && (!narrow || ff_wide_forced());
 }
 
+// doubles of the layout one kernel family uses (0: that family does not serve (n, d))
+static size_t adj_ws_doubles(bool wide, int64_t B, int n, int d, int He, int Hm) {
+  if (wide) return ff_wide_supported(n, d) ? adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1 : 0;
+  const bool narrow = (d == 2 && n >= 1 && n <= 12) || (d == 3 && n >= 2 && n <= 4);
+  const int G = adj_G(n, d);
+  return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d)) + 1 : 0;
+}
+
+// The larger of the two families' layouts: which family a call uses is decided when it runs (ff_set_kernel_family / FF_WIDE may
+// change between this query and the call, e.g. from another thread) -- a buffer of this size serves either.
 size_t ff_cnf_adjoint_workspace_bytes(int64_t B, int n, int d, int He, int Hm) {
   if (B <= 0) return 0;
-  if (adj_is_wide(n, d)) return sizeof(double) * (adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1);
-  int G = adj_G(n, d);
-  if (G == 0) return 0;
-  return sizeof(double) * (adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d)) + 1);
+  const size_t a = adj_ws_doubles(false, B, n, d, He, Hm), b = adj_ws_doubles(true, B, n, d, He, Hm);
+  return sizeof(double) * (a > b ? a : b);
 }
 
 static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* z_t0,
@@ -757,14 +765,14 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
   a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_index = w_index; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
-  const bool wide = adj_is_wide(n, d);
+  const bool wide = adj_is_wide(n, d);      // the family of THIS call, read once: layout, memset and launches below all follow it
   {
     const int Gq = wide ? 1 : adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
     a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d));
   }
-  if (hipMemsetAsync(workspace, 0, ff_cnf_adjoint_workspace_bytes(B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (hipMemsetAsync(workspace, 0, sizeof(double) * adj_ws_doubles(wide, B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
   if (wide) {
     // lanes per walker: two waves up to 128 radii (pairs + one-body), four beyond; one radius per lane up to 22 particles

@@ -1223,6 +1223,8 @@ extern int ff_slater_rows_launch(void* stream, int d, int64_t B, int nup, int nd
 
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 // persistent single-wave workgroups; FF_PERSIST_BLOCKS env overrides (tuning experiments)
 static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
@@ -1245,60 +1247,92 @@ static int64_t fwd_queue_blocks() {
 // particle passing the origin takes 20-30 steps of 7 dependent evaluations, 3.7-5.5 us each for a lone wave of the several-walkers-
 // per-wave kernels -- as long as the other 99.6 % of the walkers need the whole GPU.  The one-walker-per-wave kernel of ff_wide.hip
 // runs one evaluation in 2.6 us.  With cost classes at hand (ff_ode.walker_class: the sweeps pass the flow pass's) the walkers of
-// class >= FF_HEAVY_CLASS (0.4 % at config 2) therefore go to that kernel, launched first on the caller's stream (one wave per
+// class >= ff_ode.heavy_class (default 12: 0.4 % at config 2) therefore go to that kernel, launched first on the caller's stream (one wave per
 // walker; its 292 registers keep the SIMD to itself), and everyone else to the throughput kernel on a side stream, both joined
 // before anything else runs.  Which kernel integrates a walker depends on the walker's own class only, never on the batch it is
 // part of or on the order of work.  The heavy walkers are also the ones whose E_loc error is largest (the embedded error estimate
-// underrates the kink they pass) and their chain has slack now: they are integrated at FF_HEAVY_TOL x (rtol, atol).
-#ifndef FF_HEAVY_CLASS
-#define FF_HEAVY_CLASS 12
-#endif
-#ifndef FF_HEAVY_TOL
-#define FF_HEAVY_TOL 0.3
-#endif
+// underrates the kink they pass) and their chain has slack now: they are integrated at ff_ode.heavy_tol (default 0.3) x (rtol, atol).
+#define FF_HEAVY_CLASS_DEFAULT 12
+#define FF_HEAVY_TOL_DEFAULT 0.3
+#define FF_SUM_WEIGHT_DEFAULT 4.0
+// One side stream + two events per DEVICE, created on the first routed call on that device and shared by every host thread:
+// the whole fork / launch / join sequence of a routed pass runs under g_side_mutex (two threads driving the same device then
+// take turns on the side stream; their own streams stay independent).  ff_shutdown() releases everything.
 struct ff_side_lane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::mutex g_side_mutex;
+static std::vector<ff_side_lane> g_side_lanes;
+static void ff_side_destroy(ff_side_lane& l) {
+  if (l.fork) (void)hipEventDestroy(l.fork);
+  if (l.join) (void)hipEventDestroy(l.join);
+  if (l.stream) (void)hipStreamDestroy(l.stream);
+  l = ff_side_lane();
+}
+// caller holds g_side_mutex
 static ff_side_lane* ff_side() {
-  static thread_local ff_side_lane lanes[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  ff_side_lane& l = lanes[dev];
+  int dev = 0, ndev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  if ((size_t)dev >= g_side_lanes.size()) {
+    if (hipGetDeviceCount(&ndev) != hipSuccess || dev >= ndev) return nullptr;
+    g_side_lanes.resize((size_t)ndev);
+  }
+  ff_side_lane& l = g_side_lanes[(size_t)dev];
   if (!l.stream) {
-    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) { l.stream = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) { l = ff_side_lane(); return nullptr; }
+    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) { ff_side_destroy(l); return nullptr; }
   }
   return &l;
 }
-// launch_table(stream, args): the table kernel of the throughput family.  Returns true if the pass was routed (the caller's
-// fallback launch then redoes EVERY walker should it have to run: heavy_mode stays 0 in its arguments).
+enum { FF_ROUTE_NONE = 0, FF_ROUTE_DONE = 1, FF_ROUTE_FAILED = 2 };
+// launch_table(stream, args): the table kernel of the throughput family.
+// FF_ROUTE_DONE: both launches are enqueued and joined (the caller's fallback launch then redoes EVERY walker should it have to run:
+// heavy_mode stays 0 in its arguments).  FF_ROUTE_NONE: nothing was launched -- no classes, routing switched off, no side stream, or
+// the heavy launch was refused -- and the caller launches its table kernel for every walker.  FF_ROUTE_FAILED: the throughput
+// launch or the join failed after the heavy kernel was enqueued; both streams have been drained and the caller returns FF_ELAUNCH
+// (the outputs of this call are undefined).
 template <class F>
-static bool launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F launch_table) {
-  const char* eh = getenv("FF_HEAVY_CLASS");       // (read per call: tests and probes switch it inside one process; <= 0: no routing)
-  const int heavy_class = eh ? atoi(eh) : FF_HEAVY_CLASS;
-  if (!(a.evt && a.wclass && heavy_class > 0 && n * d <= 12 && ff_wide_supported(n, d))) return false;
+static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F launch_table) {
+  if (!(a.evt && a.wclass && a.heavy_class > 0 && n * d <= 12 && ff_wide_supported(n, d))) return FF_ROUTE_NONE;
+  std::lock_guard<std::mutex> lock(g_side_mutex);
   ff_side_lane* side = ff_side();
-  if (!side || hipEventRecord(side->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return false;
+  if (!side || hipEventRecord(side->fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return FF_ROUTE_NONE;
+  }
   ff_fwd_args h = a, l = a;
-  h.queue = nullptr; h.heavy_mode = 1; h.heavy_class = heavy_class;      // grid-stride over every walker, the light ones skipped
-  const char* et = getenv("FF_HEAVY_TOL");
-  const double heavy_tol = et ? atof(et) : FF_HEAVY_TOL;
-  if (heavy_tol > 0.0) { h.rtol *= heavy_tol; h.atol *= heavy_tol; }
-  l.heavy_mode = 2; l.heavy_class = heavy_class;
-  (void)ff_wide_eloc_heavy(stream, n, d, h, 1024);                       // placed first: a persistent grid takes every register file it finds
+  h.queue = nullptr; h.heavy_mode = 1;      // grid-stride over every walker, the light ones skipped
+  if (a.heavy_tol > 0.0) { h.rtol *= a.heavy_tol; h.atol *= a.heavy_tol; }
+  l.heavy_mode = 2;
+  // placed first: a persistent grid takes every register file it finds
+  if (ff_wide_eloc_heavy(stream, n, d, h, 1024) != FF_OK) { (void)hipGetLastError(); return FF_ROUTE_NONE; }
   launch_table(side->stream, l);
-  (void)hipEventRecord(side->join, side->stream);
-  (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0);
-  return true;
+  const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(side->join, side->stream) == hipSuccess &&
+                  hipStreamWaitEvent((hipStream_t)stream, side->join, 0) == hipSuccess;
+  if (!ok) {
+    // the heavy kernel is running (or queued) on `stream`, possibly the throughput kernel on the side stream: let both finish
+    // before the caller sees the error, so that nothing of this call still writes when it returns
+    (void)hipStreamSynchronize(side->stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipGetLastError();
+    ff_set_error("ff_eloc: the routed local-energy launch failed (throughput kernel or stream join)");
+    return FF_ROUTE_FAILED;
+  }
+  return FF_ROUTE_DONE;
 }
 
 template <int N, int D, int MODE>
-static void launch_fwd(void* stream, const ff_fwd_args& a) {
+static int launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
   const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);   // without a queue: one workgroup per walker group
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   auto table = [&](void* st, const ff_fwd_args& aa) { FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, st, aa); };
-  if (!(MODE == 2 && N <= 3 && launch_routed(stream, N, D, a, table)) && a.evt) table(stream, a);
+  int routed = FF_ROUTE_NONE;
+  if constexpr (MODE == 2 && N <= 3) routed = launch_routed(stream, N, D, a, table);
+  if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
+  if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
+  return FF_OK;
 }
 
 // n >= 8 uses the two-lanes-per-direction local-energy kernel (measured, 32768 walkers: n = 8 6.5 -> 4.5 ms,
@@ -1330,15 +1364,18 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
 #endif
 // Matrix-core local-energy kernel (ff_eloc_mfma.h): four walkers per wave, M = n d <= 12, two waves per SIMD
 template <int N, int D>
-static void launch_mfma(void* stream, const ff_fwd_args& a) {
+static int launch_mfma(void* stream, const ff_fwd_args& a) {
   const int64_t ngroups = (a.B + 3) / 4;
   const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   auto table = [&](void* st, const ff_fwd_args& aa) {
     FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, st, aa);
   };
-  if (!launch_routed(stream, N, D, a, table) && a.evt) table(stream, a);
+  const int routed = launch_routed(stream, N, D, a, table);
+  if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
+  if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
   const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), (unsigned)(ngroups < cap1 ? ngroups : cap1), FF_WAVE, stream, a);
+  return FF_OK;
 }
 
 static std::atomic<uint64_t> g_evt_counter{1};
@@ -1369,7 +1406,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
   static const int mfma_from = [] { const char* e = getenv("FF_MFMA_ELOC_FROM"); return e ? atoi(e) : 4; }();
   if (MODE == 2 && (eloc_kind == 1 || (eloc_kind == 0 && d == 2 && n >= mfma_from && n <= 6))) {
-#define FF_MF(N_, D_) if (n == N_ && d == D_) { launch_mfma<N_, D_>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+#define FF_MF(N_, D_) if (n == N_ && d == D_) { const int s_ = launch_mfma<N_, D_>(stream, a); if (s_) return s_; FF_LAUNCH_CHECK(); return FF_OK; }
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)
 #undef FF_MF
   }
@@ -1386,7 +1423,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     FF_SP(8) FF_SP(10) FF_SP(12)
 #undef FF_SP
   }
-#define FF_ND(N_, D_) if (n == N_ && d == D_) { launch_fwd<N_, D_, MODE>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
+#define FF_ND(N_, D_) if (n == N_ && d == D_) { const int s_ = launch_fwd<N_, D_, MODE>(stream, a); if (s_) return s_; FF_LAUNCH_CHECK(); return FF_OK; }
   FF_ND(6, 2) FF_ND(3, 2) FF_ND(12, 2) FF_ND(2, 2) FF_ND(4, 2) FF_ND(5, 2) FF_ND(8, 2) FF_ND(10, 2)
   if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) FF_ND(2, 3) FF_ND(3, 3) FF_ND(4, 3) }   // (their local-energy pass is the row-layout kernel above)
 #undef FF_ND
@@ -1404,6 +1441,20 @@ static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode
 }
 
 extern "C" {
+
+int ff_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  int dev0 = 0;
+  const bool have = hipGetDevice(&dev0) == hipSuccess;
+  for (size_t k = 0; k < g_side_lanes.size(); k++) {
+    if (!g_side_lanes[k].stream) continue;
+    if (hipSetDevice((int)k) == hipSuccess) (void)hipStreamSynchronize(g_side_lanes[k].stream);
+    ff_side_destroy(g_side_lanes[k]);
+  }
+  if (have) (void)hipSetDevice(dev0);
+  (void)hipGetLastError();
+  return FF_OK;
+}
 
 size_t ff_radial_table_bytes(void) { return sizeof(double) * (size_t)FF_TAB_DOUBLES; }
 
@@ -1470,6 +1521,9 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.wclass = ode->walker_class; a.sens_class = ode->sens_tol_class;
   a.sens_w = ode->sens_tol > 1.0 ? 1.0 / ode->sens_tol : 1.0;
   a.h_scale_loose = ode->walker_h_scale_loose > 0.0 ? ode->walker_h_scale_loose : fabs(ode->walker_h_scale);
+  a.heavy_class = ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT : ode->heavy_class;      // (< 0: no routing)
+  a.heavy_tol = ode->heavy_tol > 0.0 ? ode->heavy_tol : FF_HEAVY_TOL_DEFAULT;
+  a.sum_w = ode->sum_weight > 0.0 ? ode->sum_weight : FF_SUM_WEIGHT_DEFAULT;
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {
     if (hipMemsetAsync(w.queue, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;

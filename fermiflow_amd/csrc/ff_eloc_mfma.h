@@ -39,9 +39,7 @@
 // launch, against their E_loc error (65 536 walkers, config 2, sweep policy; tools/probes/sens_tol.py):
 //   weight 1: max 2.9e-6, p99.9 1.6e-7, launch 0.79 ms | 4: 2.1e-6, 5.5e-8, 0.89 ms | 16: 2.1e-6, 1.3e-8, 1.05 ms
 //   (column kernel: 2.1e-7, 1.7e-8, 1.03 ms; the bar is 1e-5)
-#ifndef FF_MFMA_SUMW
-#define FF_MFMA_SUMW 4.0
-#endif
+// The weight is ff_ode.sum_weight (A.sum_w; the entry point substitutes the default, 4, for 0).
 template <int NB, int NS>
 struct ff_jsplit_vec {
   double* col;
@@ -426,7 +424,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       if (s == -2) {
         ctl_t C; C.get(s_ctl[w]);
         __syncthreads();
-        const double sens_w = C.sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
         auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
@@ -452,7 +450,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       } else if (s == -1) {
         ctl_t C; C.get(s_ctl[w]);
         __syncthreads();
-        const double sens_w = C.sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
         auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
         double p2 = 0.0;
 #pragma unroll
@@ -506,7 +504,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         }
         s = 6;
       } else {
-        const double sens_w = s_ctl[w].sens_w, w0 = owner ? 1.0 : FF_MFMA_SUMW * sens_w;
+        const double sens_w = s_ctl[w].sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
         auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
         double pe = 0.0;
 #pragma unroll

@@ -38,6 +38,8 @@ struct ff_fwd_args {
   // Routing of the local-energy pass by cost class (needs wclass): heavy_mode 1 = this launch integrates ONLY the walkers with
   // class >= heavy_class, 2 = only the others, 0 = every walker (ff_cnf_fwd.hip, launch_mfma)
   int heavy_mode, heavy_class;
+  double heavy_tol;        // tolerances of the heavy launch: heavy_tol x (rtol, atol)  (ff_ode.heavy_tol)
+  double sum_w;            // ff_ode.sum_weight: error-norm weight of Delta and lap Delta in the matrix-core kernel
 };
 
 // Kernels for walkers that do not fit one wave's column / row layouts (n > 12 in d = 2, n > 4 in d = 3): ff_wide.hip.

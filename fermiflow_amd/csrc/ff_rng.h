@@ -24,36 +24,33 @@ FF_D ff_u4 ff_philox(uint64_t key, uint64_t c01, uint32_t c2, uint32_t c3) {
 
 FF_D uint64_t ff_bits53(uint32_t hi, uint32_t lo) { return (((uint64_t)hi << 32) | lo) >> 11; }
 
-// two independent N(0,1) from one Philox block
-FF_D void ff_normal_pair(uint64_t key, uint64_t walker, uint32_t step, uint32_t slot, double& z0, double& z1) {
-  ff_u4 r = ff_philox(key, walker, step, slot);
-  double u1 = (double)(ff_bits53(r.x, r.y) + 1) * 1.1102230246251565e-16;  // (0,1]
-  double u2 = (double)ff_bits53(r.z, r.w) * 1.1102230246251565e-16;        // [0,1)
-  double rad = sqrt(-2.0 * ff_log(u1));
-  double s, c;
-  ff_sincospi(2.0 * u2, &s, &c);
-  z0 = rad * c;
-  z1 = rad * s;
+// Two N(0,1) from two 32-bit words (Box-Muller) on the hardware fp32 transcendentals -- v_log_f32 (log2), v_sqrt_f32,
+// v_sin_f32 / v_cos_f32 (argument in revolutions) -- promoted to fp64.  A Metropolis chain only needs its proposal to be
+// SYMMETRIC to be exact, and this one is by construction: the radius uniform (a + 1/2) 2^-32 lies in (0, 1] (no infinite
+// proposal), the angle covers the first quadrant only (30 bits of b) and each normal takes its sign from a bit of b of its
+// own, so g and -g (indeed any sign pattern) are equally likely bit for bit whatever the rounding of the transcendentals.
+// 24-bit normals with the tail to 6.7 sigma; the fp64 chain (log, sqrt, sincospi: ~90 fp64 instructions per pair) was a
+// third of the Metropolis kernel.  ff_rng_fill materialises exactly these values.
+FF_D void ff_normal_pair32(uint32_t a, uint32_t b, double& z0, double& z1) {
+  const float u1 = fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);              // (a + 1/2) 2^-32
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1)
+  const float phi = (float)(b >> 2) * 2.3283064365386963e-10f;                                     // [0, 1/4] revolutions
+  const float c = rad * __builtin_amdgcn_cosf(phi), s = rad * __builtin_amdgcn_sinf(phi);
+  z0 = (double)__uint_as_float(__float_as_uint(c) ^ (b << 31));
+  z1 = (double)__uint_as_float(__float_as_uint(s) ^ ((b << 30) & 0x80000000u));
 }
 
-// four independent N(0,1) from one Philox block: Box-Muller on two pairs of 32-bit uniforms (u1 in (0,1] and u2 in
-// [0,1) on a 2^-32 grid: the normal's tail ends at 6.7 sigma and the angle grid maps onto itself under z -> -z, so the
-// Metropolis proposal stays exactly symmetric).  Slot `quad` of a (walker, step) serves particles 2*quad and 2*quad+1.
+// four independent N(0,1) from one Philox block.  Slot `quad` of a (walker, step) serves particles 2*quad and 2*quad+1
+// (d = 2; coordinates 4*quad .. 4*quad+3 of the walker in general).
 FF_D void ff_normal_quad(uint64_t key, uint64_t walker, uint32_t step, uint32_t quad, double* z) {
   ff_u4 r = ff_philox(key, walker, step, quad);
-  const double s32 = 2.3283064365386963e-10;   // 2^-32
-  const double ua = ((double)r.x + 1.0) * s32, ub = (double)r.y * s32;
-  const double uc = ((double)r.z + 1.0) * s32, ud = (double)r.w * s32;
-  const double ra = sqrt(-2.0 * ff_log(ua)), rc = sqrt(-2.0 * ff_log(uc));
-  double sn, cs;
-  ff_sincospi(2.0 * ub, &sn, &cs);
-  z[0] = ra * cs; z[1] = ra * sn;
-  ff_sincospi(2.0 * ud, &sn, &cs);
-  z[2] = rc * cs; z[3] = rc * sn;
+  ff_normal_pair32(r.x, r.y, z[0], z[1]);
+  ff_normal_pair32(r.z, r.w, z[2], z[3]);
 }
 
 // uniform in [0,1) (torch.rand_like semantics)
+FF_D double ff_uniform_words(uint32_t hi, uint32_t lo) { return (double)ff_bits53(hi, lo) * 1.1102230246251565e-16; }
 FF_D double ff_uniform(uint64_t key, uint64_t walker, uint32_t step, uint32_t slot) {
   ff_u4 r = ff_philox(key, walker, step, slot);
-  return (double)ff_bits53(r.x, r.y) * 1.1102230246251565e-16;
+  return ff_uniform_words(r.x, r.y);
 }

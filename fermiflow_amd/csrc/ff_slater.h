@@ -96,10 +96,9 @@ FF_D double ff_herm_rec(int n, double x, int md) {
 
 // nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop;
 // md: a wave-uniform upper bound of those degrees.
-// log|det D| of a register-resident NS x NS matrix (destroyed): LU with partial pivoting, |det| as the product of the pivots,
-// one log per determinant (NS <= 6: no over/underflow)
+// |det D| of a register-resident NS x NS matrix (destroyed): LU with partial pivoting, the product of the pivots
 template <int NS>
-FF_D double ff_lu_logabsdet_reg(double (&D)[NS][NS]) {
+FF_D double ff_lu_absdet_reg(double (&D)[NS][NS]) {
   double prod = 1.0;
 #pragma unroll
   for (int c = 0; c < NS; c++) {
@@ -130,7 +129,55 @@ FF_D double ff_lu_logabsdet_reg(double (&D)[NS][NS]) {
       for (int j = c + 1; j < NS; j++) D[r][j] = fma(-f, D[c][j], D[r][j]);
     }
   }
-  return ff_log(prod);
+  return prod;
+}
+// log|det D|: one log per determinant (NS <= 6: no over/underflow of the product)
+template <int NS>
+FF_D double ff_lu_logabsdet_reg(double (&D)[NS][NS]) { return ff_log(ff_lu_absdet_reg<NS>(D)); }
+
+// det D up to its sign, for the ratio test of the Philox-fed Metropolis kernels: closed form up to 3 x 3, pivoted LU beyond
+template <int NS>
+FF_D double ff_det_reg(double (&D)[NS][NS]) {
+  if constexpr (NS == 1) return D[0][0];
+  else if constexpr (NS == 2) return fma(D[0][0], D[1][1], -D[0][1] * D[1][0]);
+  else if constexpr (NS == 3) {
+    const double m0 = fma(D[1][1], D[2][2], -D[1][2] * D[2][1]);
+    const double m1 = fma(D[1][0], D[2][2], -D[1][2] * D[2][0]);
+    const double m2 = fma(D[1][0], D[2][1], -D[1][1] * D[2][0]);
+    return fma(D[0][0], m0, fma(-D[0][1], m1, D[0][2] * m2));
+  } else return ff_lu_absdet_reg<NS>(D);
+}
+
+// the polynomial part of one row of the Slater matrix: h_nx_j(x) h_ny_j(y) -- phi_j(x, y) without pi^-1/2 exp(-r^2/2), which is
+// the same for every orbital of the row: det[phi_j(r_i)] = prod_i (pi^-1/2 exp(-r_i^2/2)) det[h_nx_j(x_i) h_ny_j(y_i)]
+// (one pass of the recurrence per coordinate serves the NS orbitals: NS selects per degree instead of NS recurrences)
+template <int NS>
+FF_D void ff_herm_rec_n(const int* n, double x, int md, double* res) {
+  double hm = 1.0, h = FF_REC_A[0] * x;
+#pragma unroll
+  for (int j = 0; j < NS; j++) res[j] = (n[j] == 0) ? 1.0 : h;
+  for (int m = 1; m < md; m++) {
+    const double hn = fma(FF_REC_A[m] * x, h, -FF_REC_B[m] * hm);
+    hm = h;
+    h = hn;
+#pragma unroll
+    for (int j = 0; j < NS; j++) res[j] = (n[j] == m + 1) ? h : res[j];
+  }
+}
+template <int NS>
+FF_D void ff_poly_row_reg(const int* nx, const int* ny, double x, double y, int md, double* row) {
+  double hy[NS];
+  ff_herm_rec_n<NS>(nx, x, md, row);
+  ff_herm_rec_n<NS>(ny, y, md, hy);
+#pragma unroll
+  for (int j = 0; j < NS; j++) row[j] *= hy[j];
+}
+template <int NS>
+FF_D double ff_slater_polydet_reg(const int* nx, const int* ny, const double* x, int md) {
+  double D[NS][NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) ff_poly_row_reg<NS>(nx, ny, x[2 * i], x[2 * i + 1], md, D[i]);
+  return ff_det_reg<NS>(D);
 }
 
 // one row of the Slater matrix: phi_j(x, y), j = 0..NS-1

@@ -254,6 +254,135 @@ ff_mcmc_spin_kernel(int64_t B, const int* __restrict__ tab_up, const int* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The Philox-fed chain of the two-lanes-per-walker layout above (throughput mode; the noise-fed template stays the reference's
+// arithmetic, operation for operation).  Same stream, same walkers as ff_rng_fill + ff_mcmc_spin_kernel<NS, true>
+// (test_mcmc_full_size_properties); what differs is how a step is evaluated (~925 wave-instructions per step):
+//  * the decision u < |psi(x')|^2 / |psi(x)|^2 (src/base_dist.py:66-68) is taken as
+//        u e^{R' - R} (P_up P_dn)^2 < (P'_up P'_dn)^2,   R = sum_i r_i^2,  P = det[h_nx_j(x_i) h_ny_j(y_i)]
+//    with P the determinant of the POLYNOMIAL parts of the orbitals (the Gaussians of a row factor out of the determinant):
+//    no exp per particle, no log per determinant, and the serial tail LU -> log -> exp -> compare of a step becomes
+//    determinant -> multiply -> compare -- the left side is formed while the determinant is;
+//  * determinants up to 3 x 3 in closed form (no pivot search, no reciprocal);
+//  * the walker's Philox blocks are dealt over its two lanes: lane 0 evaluates quads 0 .. mid, lane 1 the quads behind and the
+//    block of the uniform; for odd NS the second half of the middle quad and the uniform change lanes by one DPP swap
+//    (two blocks per lane and step at NS = 3 where every lane evaluated three);
+//  * step s + 1's normals are drawn while step s is decided (they depend on nothing of it).
+// log|psi|^2 of the final walker is evaluated once at the end by the same routine as everywhere else.
+template <int NS>
+__global__ void __launch_bounds__(128)
+ff_mcmc_spin_philox_kernel(int64_t B, const int* __restrict__ tab_up, const int* __restrict__ tab_dn, const int* __restrict__ wstate,
+                           int steps, double tau, const double* __restrict__ g0, uint64_t seed, int64_t woff,
+                           double* __restrict__ x_out, double* __restrict__ logp_out, int* __restrict__ acc_count) {
+  constexpr int MS = 2 * NS, M = 2 * MS, n = 2 * NS;
+  constexpr bool ODD = (NS & 1) != 0;
+  constexpr int MID = (NS - 1) / 2;                          // odd NS: the quad whose halves belong to different spins
+  constexpr int NB = ODD ? (NS + 1) / 2 : NS / 2 + 1;        // Philox blocks per lane and step
+  __shared__ int s_md;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t b = gid >> 1;
+  const int sp = (int)(gid & 1), off = sp * MS;
+  if (threadIdx.x == 0) s_md = 0;
+  __syncthreads();
+  const bool live = b < B;
+  if (!live) b = B - 1;
+  const int st = wstate ? wstate[b] : 0;
+  const int* __restrict__ tab = sp ? tab_dn : tab_up;
+  int oo[2 * NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) ff_orb_decode(tab[st * NS + j], oo[j], oo[NS + j]);
+  int md = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * NS; j++) md = oo[j] > md ? oo[j] : md;
+  atomicMax(&s_md, md);
+  __syncthreads();
+  md = FF_UNIFORM(s_md);
+
+  const uint64_t wid = (uint64_t)(woff + b);
+  auto swap32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };
+  // this spin's normals of one step (z[i]: coordinate off + i of the walker) and the walker's uniform of that step
+  auto draw = [&](uint32_t step, double* z, double& u) {
+    ff_u4 R[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      uint32_t slot;
+      if constexpr (ODD) slot = sp ? (uint32_t)(k < NB - 1 ? MID + 1 + k : n) : (uint32_t)k;
+      else slot = (k < NB - 1) ? (uint32_t)(sp * (NS / 2) + k) : (uint32_t)n;
+      R[k] = ff_philox(seed, wid, step, slot);
+    }
+    auto word = [&](int pair, int c) -> uint32_t {     // word c of pair `pair` of this lane's own blocks (static indices)
+      const ff_u4& r = R[pair >> 1];
+      return (pair & 1) ? (c ? r.w : r.z) : (c ? r.y : r.x);
+    };
+    uint32_t uh, ul;
+    if constexpr (ODD) {
+      const ff_u4& last = R[NB - 1];       // lane 0: the middle quad (its second half is lane 1's first pair); lane 1: the uniform's block
+      const uint32_t r0 = swap32(sp ? last.x : last.z), r1 = swap32(sp ? last.y : last.w);
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const uint32_t a0 = word(j, 0), a1 = word(j, 1);
+        const uint32_t b0 = j == 0 ? r0 : word(j > 0 ? j - 1 : 0, 0), b1 = j == 0 ? r1 : word(j > 0 ? j - 1 : 0, 1);
+        ff_normal_pair32(sp ? b0 : a0, sp ? b1 : a1, z[2 * j], z[2 * j + 1]);
+      }
+      uh = sp ? last.x : r0; ul = sp ? last.y : r1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; j++) ff_normal_pair32(word(j, 0), word(j, 1), z[2 * j], z[2 * j + 1]);
+      uh = R[NB - 1].x; ul = R[NB - 1].y;
+    }
+    u = ff_uniform_words(uh, ul);
+  };
+
+  double x[MS], zq[MS], uq = 0.0;
+  if (g0 != nullptr) {              // ff_mcmc_continue: explicit initial walkers
+#pragma unroll
+    for (int i = 0; i < MS; i++) x[i] = g0[b * M + off + i];
+  } else {
+    draw(0u, x, uq);
+  }
+  if (steps > 0) draw(1u, zq, uq);
+  double Rc = 0.0;
+#pragma unroll
+  for (int i = 0; i < MS; i++) Rc = fma(x[i], x[i], Rc);
+  double PP2;
+  {
+    const double P = ff_slater_polydet_reg<NS>(oo, oo + NS, x, md), PP = P * ff_swap1(P);
+    PP2 = PP * PP;
+  }
+  int nacc = 0;
+  for (int s = 0; s < steps; s++) {
+    double nx[MS];
+#pragma unroll
+    for (int i = 0; i < MS; i++) nx[i] = ff_add_rn(x[i], ff_mul_rn(tau, zq[i]));     // two roundings, as the noise-fed kernel
+    const double u = uq;
+    if (s + 1 < steps) draw((uint32_t)(s + 2), zq, uq);
+    double Rn = 0.0;
+#pragma unroll
+    for (int i = 0; i < MS; i++) Rn = fma(nx[i], nx[i], Rn);
+    const double dR = Rc - Rn, dRt = dR + ff_swap1(dR);
+    const double lhs = u * ff_exp(fmin(fmax(-dRt, -700.0), 708.0)) * PP2;
+    const double P = ff_slater_polydet_reg<NS>(oo, oo + NS, nx, md), PPn = P * ff_swap1(P), PPn2 = PPn * PPn;
+    // IEEE comparisons: a NaN on either side rejects; e^{R - R'} below the double range is the reference's p = 0 (reject)
+    const bool acc = (dRt >= -708.0) & (lhs < PPn2);
+    if (acc) {
+#pragma unroll
+      for (int i = 0; i < MS; i++) x[i] = nx[i];
+      Rc = Rn;
+      PP2 = PPn2;
+      nacc++;
+    }
+  }
+  const double L0 = ff_slater_logabsdet_reg<NS>(oo, oo + NS, x, md);
+  const double logp = 2.0 * (L0 + ff_swap1(L0));
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < MS; i++) x_out[b * M + off + i] = x[i];
+  if (sp == 0) {
+    if (logp_out) logp_out[b] = logp;
+    if (acc_count) acc_count[b] = nacc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Metropolis chain of ONE spin species (ndown = 0: the finite-temperature runs, src/BetaFermionHO2D.py) with TWO lanes per
 // walker.  One lane per walker is one wave per SIMD at 65 536 walkers and nothing hides its serial chain; there is no second
 // species to split off here, so the lanes split the PARTICLES: lane h of a walker owns the Philox quads q = h, h + 2, ...
@@ -325,35 +454,86 @@ ff_mcmc_pair_kernel(int64_t B, const int* __restrict__ tab_up, const int* __rest
     }
     return 2.0 * (0.0 + ff_lu_logabsdet_reg<NS>(Dfull));
   };
+  // determinant (up to its sign) of the polynomial parts of the orbitals, same exchange of rows
+  auto polydet = [&](const double* xs) -> double {
+    double Dm[NPL][NS];
+#pragma unroll
+    for (int sl = 0; sl < NPL; sl++) ff_poly_row_reg<NS>(oo, oo + NS, xs[2 * sl], xs[2 * sl + 1], md, Dm[sl]);
+    double Dfull[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int q = i >> 1, owner = q & 1, sl = 2 * (q >> 1) + (i & 1);
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const double mine = Dm[sl][j], other = ff_swap1(mine);
+        Dfull[i][j] = (h == owner) ? mine : other;
+      }
+    }
+    return ff_det_reg<NS>(Dfull);
+  };
 
   if (NOISE || g0 != nullptr) load(g0 + b * M, xm);
   else draw(0u, xm, false);
-  double logp = logprob(xm);
   int nacc = 0;
-  double gq[MPL], uq = 0.0;
-  if (NOISE && steps > 0) { load(g + b * M, gq); uq = u[b]; }
-  for (int s = 0; s < steps; s++) {
-    double ucur = 0.0;
-    if (NOISE) {
+  double logp;
+  if constexpr (NOISE) {
+    logp = logprob(xm);
+    double gq[MPL], uq = 0.0;
+    if (steps > 0) { load(g + b * M, gq); uq = u[b]; }
+    for (int s = 0; s < steps; s++) {
+      double ucur = 0.0;
 #pragma unroll
       for (int i = 0; i < MPL; i++) nxm[i] = ff_add_rn(xm[i], ff_mul_rn(tau, gq[i]));
       ucur = uq;
       if (s + 1 < steps) { load(g + ((int64_t)(s + 1) * B + b) * M, gq); uq = u[(int64_t)(s + 1) * B + b]; }
-    } else {
-      draw((uint32_t)(s + 1), nxm, true);
-    }
-    const double nl = logprob(nxm);
-    const double dlp = nl - logp;
-    const double p = !(dlp == dlp) ? dlp : (dlp < -708.0 ? 0.0 : ff_exp(fmin(dlp, 708.0)));
-    const double uu = NOISE ? ucur : ff_uniform(seed, wid, (uint32_t)(s + 1), (uint32_t)NS);
-    const bool acc = uu < p;
-    if (acc) {
+      const double nl = logprob(nxm);
+      const double dlp = nl - logp;
+      const double p = !(dlp == dlp) ? dlp : (dlp < -708.0 ? 0.0 : ff_exp(fmin(dlp, 708.0)));
+      const double uu = ucur;
+      const bool acc = uu < p;
+      if (acc) {
 #pragma unroll
-      for (int i = 0; i < MPL; i++) xm[i] = nxm[i];
-      logp = nl;
-      nacc++;
+        for (int i = 0; i < MPL; i++) xm[i] = nxm[i];
+        logp = nl;
+        nacc++;
+      }
+      if (accept && live && h == 0) accept[(int64_t)s * B + b] = acc ? 1 : 0;
     }
-    if (accept && live && h == 0) accept[(int64_t)s * B + b] = acc ? 1 : 0;
+  } else {
+    // Philox-fed chain: the decision as u e^{R' - R} P^2 < P'^2 on the determinant of the polynomial parts (see
+    // ff_mcmc_spin_philox_kernel); the walkers are those of the branch above on the materialised stream
+    auto r2sum = [&](const double* xs) -> double {       // this lane's share of sum_i r_i^2 (absent particles: none)
+      double r = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < NPL; sl++) { const double t = fma(xs[2 * sl], xs[2 * sl], xs[2 * sl + 1] * xs[2 * sl + 1]); r += (pid(sl) < NS) ? t : 0.0; }
+      return r;
+    };
+    double Rc = r2sum(xm);
+    double P2 = polydet(xm);
+    P2 *= P2;
+    double uq = 0.0;
+    if (steps > 0) { draw(1u, nxm, false); uq = ff_uniform(seed, wid, 1u, (uint32_t)NS); }
+    for (int s = 0; s < steps; s++) {
+      double cur[MPL];
+#pragma unroll
+      for (int i = 0; i < MPL; i++) cur[i] = ff_add_rn(xm[i], ff_mul_rn(tau, nxm[i]));
+      const double uu = uq;
+      // step s + 1's normals and uniform: they depend on nothing of this step
+      if (s + 1 < steps) { draw((uint32_t)(s + 2), nxm, false); uq = ff_uniform(seed, wid, (uint32_t)(s + 2), (uint32_t)NS); }
+      const double Rn = r2sum(cur), dR = Rc - Rn, dRt = dR + ff_swap1(dR);
+      const double lhs = uu * ff_exp(fmin(fmax(-dRt, -700.0), 708.0)) * P2;
+      double Pn2 = polydet(cur);
+      Pn2 *= Pn2;
+      const bool acc = (dRt >= -708.0) & (lhs < Pn2);
+      if (acc) {
+#pragma unroll
+        for (int i = 0; i < MPL; i++) xm[i] = cur[i];
+        Rc = Rn;
+        P2 = Pn2;
+        nacc++;
+      }
+    }
+    logp = logprob(xm);
   }
   if (!live) return;
 #pragma unroll
@@ -871,6 +1051,10 @@ extern void ff_set_error(const char* msg);
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 static inline unsigned ff_grid(int64_t B, int block) { return (unsigned)((B + block - 1) / block); }
 
+// FF_MCMC_CLASSIC=1 (diagnostic, read once): the Philox-fed chains evaluate every step like the noise-fed ones (Gaussians,
+// pivoted LU, log, exp) -- the A/B partner of the determinant-ratio kernels; the walkers are the same either way
+static bool ff_mcmc_classic() { static const bool v = getenv("FF_MCMC_CLASSIC") != nullptr; return v; }
+
 template <int NU, int ND>
 static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, const int* tu, const int* td, const int* ws,
                         int steps, double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff,
@@ -882,9 +1066,12 @@ static void launch_mcmc(bool noise, void* stream, int64_t B, int nup, int ndn, c
       if (noise)
         FF_LAUNCH((ff_mcmc_spin_kernel<NU, true>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, g, u, seed, woff,
                   x_out, logp_out, accept, acc_count);
-      else
+      else if (ff_mcmc_classic())
         FF_LAUNCH((ff_mcmc_spin_kernel<NU, false>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, g, u, seed, woff,
                   x_out, logp_out, accept, acc_count);
+      else
+        FF_LAUNCH((ff_mcmc_spin_philox_kernel<NU>), ff_grid(2 * B, 128), 128, stream, B, tu, td, ws, steps, tau, g0, seed, woff,
+                  x_out, logp_out, acc_count);
       return;
     }
   }

@@ -12,7 +12,8 @@
  *  - `stream` is a hipStream_t (0 = default stream); every call only enqueues work, no hidden sync;
  *  - the library allocates no memory: callers pass workspaces where a size query exists.  ff_eloc / ff_eloc_sensitivities
  *    with ff_ode.walker_class set (up to 6 particles, d = 2) run two kernels side by side -- the second on a side stream the
- *    library creates once per device and thread, forked from and joined to `stream` by events inside the call;
+ *    library creates on the first such call on a device (one per device, shared by the process; ff_shutdown releases them),
+ *    forked from and joined to `stream` by events inside the call;
  *  - return value: 0 ok, 1 invalid argument, 2 no native instantiation for this configuration,
  *    3 HIP launch failure; ff_last_error() gives a message.  No C++ exception crosses the ABI.
  *  - orbitals are identified by their index k into HO2D().orbitals (src/orbitals.py:81,
@@ -74,9 +75,28 @@ typedef struct ff_ode {
   int32_t sens_tol_class;
   int32_t walker_h_uniform;   /* nonzero: walker_h_init holds ONE entry, the first step size of every walker (a statistic of an
                                  earlier call on other walkers of the same distribution, e.g. the mean of its walker_h_out) */
+  /* Local-energy pass with walker_class set, up to 6 particles in d = 2 (0 = the library's default for each).  Walkers of class
+   * >= heavy_class (a particle passing the origin: 0.4 % of a batch, 20-30 steps each) are integrated by the one-walker-per-wave
+   * kernel, started first, at heavy_tol x (rtol, atol), beside the throughput kernel that takes everyone else -- which kernel
+   * integrates a walker depends on its own class only.  Defaults: heavy_class 12, heavy_tol 0.3; heavy_class < 0: no routing.
+   * sum_weight: weight of the two scalar components Delta and lap_x Delta in the error norm of the matrix-core kernel
+   * (4-6 particles), which carries each as ONE number where the column and row kernels carry per-lane partial sums (default 4;
+   * 1: the plain RMS norm -- fewer steps near a kink, E_loc error up to 3e-6 there). */
+  int32_t heavy_class;
+  double heavy_tol;
+  double sum_weight;
 } ff_ode;
 
-int ff_version(void);   /* 102; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 103; changes whenever a struct of this header changes layout (the Python binding checks it) */
+/* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
+ * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
+ * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
+int ff_shutdown(void);
+/* There is no ff_comm_init / _allreduce / _destroy (SURVEY 8b's minimum set names them): the multi-GPU estimator needs two
+ * all-reduces of <= 2.4 KB per iteration and the host side (fermiflow_amd/dist.py) issues them through torch.distributed's
+ * "nccl" backend (= RCCL) on the device buffers ff_reduce_energy / ff_beta_state_partials / ff_cnf_adjoint* fill.  A caller
+ * that drives this ABI without torch sums those buffers over its ranks with its own communicator between the same calls;
+ * the library itself never communicates. */
 /* order (B) = walker indices sorted by descending cost (ties in a fixed order; classes above 31 count as 31); cost (B) >= 0, e.g. ff_ode.walker_cost. */
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);

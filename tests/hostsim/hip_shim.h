@@ -56,6 +56,11 @@ inline int hipEventCreateWithFlags(hipEvent_t* e, unsigned) { static int one; *e
 inline int hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline int hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline int hipGetDevice(int* d) { *d = 0; return 0; }
+inline int hipSetDevice(int) { return 0; }
+inline int hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline int hipEventDestroy(hipEvent_t) { return 0; }
+inline int hipStreamDestroy(hipStream_t) { return 0; }
+inline int hipStreamSynchronize(hipStream_t) { return 0; }
 inline int hipDeviceGetAttribute(int* v, int, int) { *v = 2; return 0; }   // the simulator pretends to have two CUs
 
 template <class T> inline T ff_sim_atomic_add(T* p, T v) {
@@ -93,6 +98,10 @@ inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+inline float __builtin_amdgcn_sinf(float x) { return (float)sin(6.283185307179586 * (double)x); }    // v_sin_f32: argument in revolutions
+inline float __builtin_amdgcn_cosf(float x) { return (float)cos(6.283185307179586 * (double)x); }
 inline unsigned long long wall_clock64() {      // 100 MHz, as the GPU's constant clock
   return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }

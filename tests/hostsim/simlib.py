@@ -22,7 +22,7 @@ class FFOde(C.Structure):
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
-                ("walker_h_uniform", C.c_int32)]
+                ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double)]
 
 
 def build():
@@ -166,10 +166,11 @@ def mlp(r, w1, b1, w2):
 _WARM = {}     # set by warm(h_init=..., h_scale=..., h_out=...) for the next calls (keeps the wrappers' signatures short)
 
 
-def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, wclass=None, sens_tol=1.0, sens_class=0, h_scale_loose=0.0):
+def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, wclass=None, sens_tol=1.0, sens_class=0, h_scale_loose=0.0,
+         heavy_class=0, heavy_tol=0.0, sum_weight=0.0):
     _WARM.clear()
     _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps, wclass=wclass, sens_tol=sens_tol, sens_class=sens_class,
-                 h_scale_loose=h_scale_loose)
+                 h_scale_loose=h_scale_loose, heavy_class=heavy_class, heavy_tol=heavy_tol, sum_weight=sum_weight)
 
 
 def _ode(t0, t1, rtol, atol, steps=None, order=None):
@@ -177,7 +178,8 @@ def _ode(t0, t1, rtol, atol, steps=None, order=None):
     qi = q
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
                  q(_WARM.get("h_out")), qi(_WARM.get("wclass")), float(_WARM.get("sens_tol", 1.0)), float(_WARM.get("h_scale_loose", 0.0)),
-                 int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))))
+                 int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))), int(_WARM.get("heavy_class", 0)),
+                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)))
 
 
 def walker_order(cost):

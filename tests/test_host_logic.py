@@ -185,3 +185,75 @@ def test_plain_parameter_state_dict_loads_as_a_cold_sweep_state():
     assert b._h_flow is None and b._dev == {}
     assert "_extra_state" not in bare
     b.load_state_dict(a.state_dict())      # and the full one still loads
+
+
+def test_potentials_are_never_silently_reinterpreted():
+    """VMC.potential_plan: the stock CoulombPairPotential(Z) / HO() are fused into the native finish; any
+    other pair or trap potential keeps the reference's generic semantics (its own V(x) is called, src/VMC.py:51-53) instead of
+    being treated as Z = 0 / as a harmonic trap; an object without V raises."""
+    import fermiflow_amd as ff
+    from fermiflow_amd.VMC import potential_plan
+    from fermiflow_amd.potentials import PairPotential, SPPotential
+    assert potential_plan(ff.CoulombPairPotential(2.0), ff.HO()) == (2.0, True, [])
+    assert potential_plan(ff.CoulombPairPotential(0.5), None) == (0.5, False, [])
+
+    class Yukawa(PairPotential):
+        def v(self, rij):
+            return torch.exp(-rij) / rij
+
+    class Quartic(SPPotential):
+        def V(self, x):
+            return (x ** 4).sum(dim=(-2, -1))
+
+    class ScreenedCoulomb(ff.CoulombPairPotential):      # a SUBCLASS may override v(): not the stock formula any more
+        def v(self, rij):
+            return self.Z / (rij + 1.0)
+
+    y, q, s = Yukawa(), Quartic(), ScreenedCoulomb(2.0)
+    assert potential_plan(y, ff.HO()) == (0.0, True, [y])
+    assert potential_plan(ff.CoulombPairPotential(2.0), q) == (2.0, False, [q])
+    assert potential_plan(s, q) == (0.0, False, [s, q])
+    # the generic pair potential's V(x) is the reference's formula (sum over i < j of v(r_ij))
+    x = torch.randn(5, 4, 2, dtype=torch.float64)
+    want = sum(torch.exp(-(x[:, i] - x[:, j]).norm(dim=-1)) / (x[:, i] - x[:, j]).norm(dim=-1) for i in range(4) for j in range(i + 1, 4))
+    assert torch.allclose(y.V(x), want)
+    with pytest.raises(TypeError):
+        potential_plan(object(), ff.HO())
+    with pytest.raises(TypeError):
+        potential_plan(None, ff.HO())
+    with pytest.raises(TypeError):
+        potential_plan(ff.CoulombPairPotential(1.0), SPPotential())
+
+
+def test_routing_controls_travel_in_ff_ode_not_in_the_environment():
+    """heavy_class / heavy_tol / sum_weight are ff_ode fields (ABI 103): two callers in one process can choose differently, and the
+    library's sources read no accuracy knob from the environment (the remaining getenv calls select kernels for A/B timing)."""
+    from fermiflow_amd import _lib
+    o = _lib.ode(0.0, 1.0, 1e-6, 1e-8, heavy_class=-1, heavy_tol=0.1, sum_weight=16.0)
+    assert (o.heavy_class, o.heavy_tol, o.sum_weight) == (-1, 0.1, 16.0)
+    o = _lib.ode(0.0, 1.0, 1e-6, 1e-8)
+    assert (o.heavy_class, o.heavy_tol, o.sum_weight) == (0, 0.0, 0.0)
+    csrc = os.path.join(ROOT, "fermiflow_amd", "csrc")
+    envs = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".inc")):
+            envs |= set(re.findall(r'getenv\("(\w+)"\)', open(os.path.join(csrc, f)).read()))
+    assert not {e for e in envs if "TOL" in e or "HEAVY" in e or "SUMW" in e or "WEIGHT" in e}, envs
+    assert _lib.lib().ff_shutdown() == 0          # nothing created yet: a no-op, and callable without a GPU
+
+
+def test_adjoint_workspace_serves_either_kernel_family():
+    """ff_cnf_adjoint_workspace_bytes no longer depends on the mutable kernel family -- the size is the larger of the two
+    layouts, so a family switch between the query and the call cannot overrun the caller's buffer."""
+    from fermiflow_amd import _lib
+    import ctypes as C
+    lib = _lib.lib()
+    q = lambda: lib.ff_cnf_adjoint_workspace_bytes(C.c_int64(4096), 6, 2, 50, 50)
+    prev = lib.ff_set_kernel_family(0)
+    try:
+        a = q()
+        lib.ff_set_kernel_family(1)
+        b = q()
+    finally:
+        lib.ff_set_kernel_family(prev)
+    assert a == b and a > 0
