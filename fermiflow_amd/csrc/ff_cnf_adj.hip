@@ -329,14 +329,47 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       double in[NV];
       const double h = S.h;
       {
-        // y + hsel * sum_k a_k k_k with the stage's tableau row (wave-uniform row: scalar loads, no literals)
+        // y + hsel * sum_k a_k k_k with the stage's tableau row, as a (wave-uniform) switch over literal rows: the row used to come
+        // from the constant table FF_ATAB by scalar loads issued where they were needed -- 1 600 of the 5 100 cycles of a
+        // wave-evaluation were that wait (s_memtime stamps, profiles/r04_b_adjoint_stamps.json).  Same products in the same
+        // order, the zero entries of a row dropped (fma(0, k, x) = x): bit-identical stage inputs.
         const double hsel = (s == -1) ? h0v * S.dir : h;
-        const double* __restrict__ arow = FF_ATAB[s + 2];
-        const double a0 = hsel * arow[0], a1 = hsel * arow[1], a2 = hsel * arow[2], a3 = hsel * arow[3], a4 = hsel * arow[4],
-                     a5 = hsel * arow[5];
 #pragma unroll
-        for (int v = 0; v < NV; v++)
-          in[v] = fma(a5, k5[v], fma(a4, k4[v], fma(a3, k3[v], fma(a2, k2[v], fma(a1, k1[v], fma(a0, k0[v], y[v]))))));
+        for (int v = 0; v < NV; v++) in[v] = y[v];
+        switch (s) {
+          case -1:
+#pragma unroll
+            for (int v = 0; v < NV; v++) in[v] = fma(hsel, k0[v], y[v]);
+            break;
+          case 1:
+#pragma unroll
+            for (int v = 0; v < NV; v++) in[v] = fma(hsel * FF_A10, k0[v], y[v]);
+            break;
+          case 2:
+#pragma unroll
+            for (int v = 0; v < NV; v++) in[v] = fma(hsel * FF_A21, k1[v], fma(hsel * FF_A20, k0[v], y[v]));
+            break;
+          case 3:
+#pragma unroll
+            for (int v = 0; v < NV; v++) in[v] = fma(hsel * FF_A32, k2[v], fma(hsel * FF_A31, k1[v], fma(hsel * FF_A30, k0[v], y[v])));
+            break;
+          case 4:
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+              in[v] = fma(hsel * FF_A43, k3[v], fma(hsel * FF_A42, k2[v], fma(hsel * FF_A41, k1[v], fma(hsel * FF_A40, k0[v], y[v]))));
+            break;
+          case 5:
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+              in[v] = fma(hsel * FF_A54, k4[v], fma(hsel * FF_A53, k3[v], fma(hsel * FF_A52, k2[v], fma(hsel * FF_A51, k1[v], fma(hsel * FF_A50, k0[v], y[v])))));
+            break;
+          case 6:
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+              in[v] = fma(hsel * FF_B5, k5[v], fma(hsel * FF_B4, k4[v], fma(hsel * FF_B3, k3[v], fma(hsel * FF_B2, k2[v], fma(hsel * FF_B0, k0[v], y[v])))));
+            break;
+          default: break;      // -2, 0: the state itself
+        }
       }
       FF_STAMP(0);
       __syncthreads();
@@ -496,7 +529,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         double pe = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double e = h * (FF_ATAB[9][0] * k0[v] + FF_ATAB[9][2] * k2[v] + FF_ATAB[9][3] * k3[v] + FF_ATAB[9][4] * k4[v] + FF_ATAB[9][5] * k5[v] + FF_E6 * out[v]);
+          const double e = h * (FF_E0 * k0[v] + FF_E2 * k2[v] + FF_E3 * k3[v] + FF_E4 * k4[v] + FF_E5 * k5[v] + FF_E6 * out[v]);
           const double t = e * ff_rcp(fma(fmax(fabs(y[v]), fabs(in[v])), rtol, atol));
           pe = fma(t, t, pe);
         }
@@ -517,7 +550,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
             const int qg = rq_id[sl] & 15;
             const int t = ((rq_id[sl] >> 8) & 15) != 15 ? 0 : 1;
             const double hw = s_hw[qg];
+#ifndef FF_ADJ_NODEP      // (timing experiments only: the parameter gradient is then wrong)
             ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
+#endif
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }
         }

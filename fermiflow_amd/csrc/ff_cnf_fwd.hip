@@ -1094,14 +1094,24 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 // finish the walker.
 // slots of Q: [0,M) g0 | [M, M+3n) S (particle-major) | then T_up (2 nup^2), T_dn (2 ndn^2) | last two: 2 log|det| per spin
 // equal (or single) determinant sizes known at compile time: everything in registers (ff_slater_fixed)
+// With the fused finish (ff_fwd_args::fin) the throughput kernel writes the local energies itself; what is left for the two kernels
+// below are the walkers the routed pass sent to the one-walker-per-wave kernel (class >= heavy_class), whose sensitivities are in the
+// workspace -- unless the table kernels raised the off-table event and the (unrouted, fused) direct kernel redid every walker.
+struct ff_fin_filter {
+  const int32_t* wclass;     // NULL: every walker
+  int heavy_class;
+  const double* evt;         // with wclass: skip everything if *evt == evt_id
+  double evt_id;
+  FF_D bool skip(int64_t b) const { return wclass != nullptr && (wclass[b] < heavy_class || *evt == evt_id); }
+};
 template <int NS>
 __global__ void __launch_bounds__(128)
 ff_eloc_slater_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
-                            const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
+                            const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q, ff_fin_filter flt) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t b = gid >> 1;
   const int sp = (int)(gid & 1);
-  if (b >= B) return;
+  if (b >= B || flt.skip(b)) return;
   const int n = nup + ndn, M = 2 * n, st = wstate ? wstate[b] : 0;
   const int64_t nqs = M + 3 * n + 2 * (nup * nup + ndn * ndn) + 2;   // slots per walker
   const int lpq = M + 3 * n + 2 * (nup * nup + ndn * ndn) + sp;
@@ -1134,7 +1144,7 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
                         const double* __restrict__ Q, const double* __restrict__ Jt, const double* __restrict__ kbar,
                         const double* __restrict__ dD, const double* __restrict__ delta, const double* __restrict__ Lpart,
                         double* __restrict__ logp, double* __restrict__ grad, double* __restrict__ lap,
-                        double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0) {
+                        double* __restrict__ V, double* __restrict__ eloc, double* __restrict__ glogp0, ff_fin_filter flt) {
   FF_DYN_LDS(ff_fin_lds);
   const int n = nup + ndn, M = 2 * n, G = FF_WAVE / M;
   const int lane = threadIdx.x, g = lane / M, i = lane - g * M;
@@ -1147,8 +1157,9 @@ ff_eloc_contract_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, cons
   const int64_t ngroups = (B + G - 1) / G;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t b0 = grp * G, b = b0 + g;
-    const bool valid = ingrp && b < B;
+    const bool valid = ingrp && b < B && !flt.skip(b);
     const int nw = (int)((B - b0) < G ? (B - b0) : G);       // walkers of this wave
+    if (flt.wclass && !__ballot(valid)) continue;            // (filtered finish: most groups hold no walker of the heavy route)
     __syncthreads();
     {   // the wave's J^T block: one contiguous span, 16-byte loads (M*M is even, so the span is whole pairs)
       const double2* __restrict__ J2 = reinterpret_cast<const double2*>(Jt + b0 * M * M);
@@ -1284,6 +1295,10 @@ static ff_side_lane* ff_side() {
   return &l;
 }
 enum { FF_ROUTE_NONE = 0, FF_ROUTE_DONE = 1, FF_ROUTE_FAILED = 2 };
+// What the local-energy dispatch of THIS host thread did, for ff_eloc to read back right after it: did the kernel it chose take the
+// fused finish (ff_fwd_args::fin), and was the pass routed (then the walkers of class >= heavy_class still need the finish kernels).
+struct ff_eloc_feedback { bool fused, routed; const double* evt; double evt_id; };
+static thread_local ff_eloc_feedback t_eloc_fb = {false, false, nullptr, 0.0};
 // launch_table(stream, args): the table kernel of the throughput family.
 // FF_ROUTE_DONE: both launches are enqueued and joined (the caller's fallback launch then redoes EVERY walker should it have to run:
 // heavy_mode stays 0 in its arguments).  FF_ROUTE_NONE: nothing was launched -- no classes, routing switched off, no side stream, or
@@ -1373,6 +1388,9 @@ static int launch_mfma(void* stream, const ff_fwd_args& a) {
   const int routed = launch_routed(stream, N, D, a, table);
   if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
   if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
+  t_eloc_fb.fused = a.fin.on && N % 2 == 0 && D == 2;      // (what the kernel's epilogue tests)
+  t_eloc_fb.routed = routed == FF_ROUTE_DONE;
+  t_eloc_fb.evt = a.evt; t_eloc_fb.evt_id = a.evt_id;
   const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
   FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), (unsigned)(ngroups < cap1 ? ngroups : cap1), FF_WAVE, stream, a);
   return FF_OK;
@@ -1504,9 +1522,18 @@ size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
   return sizeof(double) * ff_eloc_ws_doubles(B, (size_t)n, (size_t)d);
 }
 
+static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
+                                   void* workspace, int32_t* stats, const ff_fwd_args::ff_fin_args* fin);
+
 /* pass 1 of ff_eloc: the fused sensitivity integration (results stay in `workspace`) */
 int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
                           void* workspace, int32_t* stats) {
+  return eloc_sensitivities_impl(stream, B, n, d, net, ode, x, workspace, stats, nullptr);
+}
+
+static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
+                                   void* workspace, int32_t* stats, const ff_fwd_args::ff_fin_args* fin) {
+  t_eloc_fb = {false, false, nullptr, 0.0};
   int st = check_common(B, n, d, net, ode);
   if (st) return st;
   FF_CHECK(x && workspace, FF_EINVAL, "ff_eloc_sensitivities: null pointer");
@@ -1524,6 +1551,7 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   a.heavy_class = ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT : ode->heavy_class;      // (< 0: no routing)
   a.heavy_tol = ode->heavy_tol > 0.0 ? ode->heavy_tol : FF_HEAVY_TOL_DEFAULT;
   a.sum_w = ode->sum_weight > 0.0 ? ode->sum_weight : FF_SUM_WEIGHT_DEFAULT;
+  if (fin) a.fin = *fin;
   static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
   if (use_queue) {
     if (hipMemsetAsync(w.queue, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
@@ -1532,11 +1560,24 @@ int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* n
   return dispatch_fwd<2>(stream, n, d, a);
 }
 
+static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                            const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                            double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                            double* glogp0_out, ff_fin_filter flt);
+
 /* pass 2 of ff_eloc: Slater gradient/Hessian contraction, potentials, E_loc */
 int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
                    const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
                    double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
                    double* glogp0_out) {
+  return eloc_finish_impl(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc, z_out,
+                          dlogp_out, glogp0_out, ff_fin_filter{nullptr, 0, nullptr, 0.0});
+}
+
+static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                            const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                            double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                            double* glogp0_out, ff_fin_filter flt) {
   const int n = nup + ndn;
   FF_CHECK(B >= 0 && nup >= 0 && ndn >= 0 && n > 0 && x && workspace, FF_EINVAL, "ff_eloc_finish: bad argument");
   FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc_finish: null orbital table");
@@ -1548,7 +1589,7 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
   {
     const int nsf = (nup == ndn || ndn == 0) ? nup : (nup == 0 ? ndn : 0);   // one determinant size for both spin species
     const unsigned sgrid = (unsigned)((2 * B + 127) / 128);
-#define FF_SF(NS_) case NS_: FF_LAUNCH((ff_eloc_slater_fixed_kernel<NS_>), sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q); break;
+#define FF_SF(NS_) case NS_: FF_LAUNCH((ff_eloc_slater_fixed_kernel<NS_>), sgrid, 128, stream, B, nup, ndn, tab_up, tab_dn, walker_state, (const double*)w.z0, w.Q, flt); break;
     switch (nsf) {
       FF_SF(1) FF_SF(2) FF_SF(3) FF_SF(4)
       default:      // larger or unequal determinants: sixteen lanes per determinant (ff_ho3d.hip)
@@ -1562,7 +1603,7 @@ int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab
     const int64_t ng = (B + Gf - 1) / Gf;
     FF_LAUNCH_LDS(ff_eloc_contract_kernel, (unsigned)(ng < 32768 ? ng : 32768), FF_WAVE, ff_contract_lds_bytes(nup, ndn), stream, B, nup, ndn, Z, use_ho, x,
               (const double*)w.Q, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
-              (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out);
+              (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out, flt);
   }
   FF_LAUNCH_CHECK();
   if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
@@ -1575,10 +1616,32 @@ int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, co
             double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
             double* glogp0_out, void* workspace, int32_t* stats) {
   FF_CHECK(nup >= 0 && ndn >= 0 && nup + ndn > 0, FF_EINVAL, "ff_eloc: bad particle numbers");
-  int st = ff_eloc_sensitivities(stream, B, nup + ndn, 2, net, ode, x, workspace, stats);
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc: null orbital table");
+  // Offer the fused finish: a sensitivity kernel that implements it (the matrix-core kernel, nup = ndn: config 2) writes logp,
+  // grad, lap, V, E_loc and grad_z logp0 from its epilogue, and J^T (8 M^2 bytes per walker) never leaves the chip.
+  ff_fwd_args::ff_fin_args fin = {};
+  const int n = nup + ndn;
+  fin.on = (nup == ndn && nup >= 1 && nup <= 3) ? 1 : 0;
+  fin.nup = nup; fin.ndn = ndn; fin.use_ho = use_ho; fin.tab_up = tab_up; fin.tab_dn = tab_dn; fin.wstate = walker_state; fin.Z = Z;
+  fin.logp = logp; fin.grad = grad; fin.lap = lap; fin.V = V; fin.eloc = eloc; fin.glogp0 = glogp0_out;
+  int st = eloc_sensitivities_impl(stream, B, n, 2, net, ode, x, workspace, stats, &fin);
   if (st) return st;
-  return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
-                        z_out, dlogp_out, glogp0_out);
+  const ff_eloc_feedback fb = t_eloc_fb;
+  if (B == 0) return FF_OK;
+  if (!fb.fused)
+    return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
+                          z_out, dlogp_out, glogp0_out);
+  if (fb.routed) {    // the walkers of the heavy route: their sensitivities are in the workspace
+    st = eloc_finish_impl(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc, nullptr,
+                          nullptr, glogp0_out, ff_fin_filter{ode->walker_class, ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT : ode->heavy_class,
+                                                             fb.evt, fb.evt_id});
+    if (st) return st;
+  }
+  const size_t M = (size_t)n * 2;
+  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, 2);
+  if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  return FF_OK;
 }
 
 }  // extern "C"

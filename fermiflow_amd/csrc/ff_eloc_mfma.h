@@ -533,8 +533,211 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       FF_STAMP(6);
       FF_SCHED_FENCE();
     }
+    // ---------------------------------------------------------------------- fused finish (ff_eloc, nup = ndn; wave-uniform branch)
+    // What ff_eloc_slater_fixed_kernel + ff_eloc_contract_kernel did from the workspace, on the walker's sixteen lanes while J is
+    // still on chip (src/utils.py:56-63, src/VMC.py:48-55):
+    //   grad_x logp = J^T g0 - grad Delta                       g0 = grad_z logp0(z(t0)),  H0 = its Hessian
+    //   lap_x logp  = tr(H0 S) + g0 . kbar - lap Delta          S = J J^T: the product the right-hand side forms on the matrix cores
+    // -- sum_i u_i^T H0 u_i over the columns u_i of J IS tr(H0 J J^T), so no lane ever needs a column of J.  One lane per particle
+    // builds its row of the Slater tables (Hermite functions and both derivatives from one recurrence pass; the 3 x 3, 2 x 2 or 1 x 1
+    // inverse by the adjugate) and contracts it with S; J^T g0 is the transposed-block quad reduction of (grad Delta)' = -J^T g; the
+    // potential comes from the radius lanes on x.  (ff_slater_fixed, the routine of the stand-alone finish, costs 55 us per 131 072
+    // determinants: coefficient-table loads by a per-lane index and 256 registers -- inlined here it took 0.5 ms per launch.)
+    bool fin_done = false;
+    if constexpr (N % 2 == 0 && D == 2) {
+      if (A.fin.on) {
+        constexpr int NSF = N / 2;
+        fin_done = true;
+        int ln = lane;
+        FF_OPAQUE(ln);
+        const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c, tl = 16 * c + 4 * w + r;
+        const bool owner = p < M;
+        {   // S = J J^T of the final J -> s_A[w]
+          double Jt[NB];
+#pragma unroll
+          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(y.get(1 + e), tl);
+          double* Sw = s_A[w];
+#pragma unroll
+          for (int I = 0; I < MB; I++) {
+#pragma unroll
+            for (int Kc = I; Kc < MB; Kc++) {
+              double acc = 0.0;
+#pragma unroll
+              for (int K = 0; K < MB; K++) acc = ff_mfma4(Jt[I * MB + K], Jt[Kc * MB + K], acc);
+              Sw[(4 * I + r) * AS + 4 * Kc + c] = acc;
+              if (Kc != I) Sw[(4 * Kc + c) * AS + 4 * I + r] = acc;
+            }
+          }
+        }
+        const double y0 = y.get(0);                      // z_p (owner lanes), Delta (p = PDL), lap Delta (p = PLP)
+        if (owner) s_z[w][p] = y0;
+        __syncthreads();
+        // Particle lanes: lane i16 = 4r + c < N of a walker owns particle i16 (spin i16 / NSF): its row of the Slater matrix, of the
+        // gradient tables T_c[a][b] = sum_j d_c phi_j(r_a) Dinv[j][b] and its same-particle Hessian sums S3; the rows
+        // meet in LDS (the record area is free here), every lane inverts its spin's matrix itself (adjugate, <= 3 x 3).
+        const int i16 = 4 * r + c;
+        const bool pl = i16 < N;
+        const int sp = pl ? i16 / NSF : 0, al = pl ? i16 - sp * NSF : 0, off = sp * NSF;
+        constexpr int FS = 6 * NSF * NSF;                  // per walker: D [2][NSF][NSF] | T [2][2][NSF][NSF]
+        double* const fD = s_rec + w * FS + sp * NSF * NSF;
+        double* const fT = s_rec + w * FS + 2 * NSF * NSF + sp * 2 * NSF * NSF;
+        int deg[2 * NSF];
+        {
+          const int32_t* tab = sp ? A.fin.tab_dn : A.fin.tab_up;
+          const int st = (A.fin.wstate && valid) ? A.fin.wstate[b] : 0;
+#pragma unroll
+          for (int j = 0; j < NSF; j++) ff_orb_decode(tab[st * NSF + j], deg[j], deg[NSF + j]);
+        }
+        int md = 1;
+        {
+          int mx = 0;
+#pragma unroll
+          for (int j = 0; j < 2 * NSF; j++) mx = deg[j] > mx ? deg[j] : mx;
+          for (int dgr = 7; dgr >= 2; dgr--)
+            if (__ballot(pl && mx >= dgr)) { md = dgr; break; }
+        }
+        const double zx = s_z[w][pl ? 2 * i16 : 0], zy = s_z[w][pl ? 2 * i16 + 1 : 1];
+        double ph[NSF], pgx[NSF], pgy[NSF], pxx[NSF], pxy[NSF], pyy[NSF];
+        {
+          double hx[NSF], hx1[NSF], hx2[NSF], hy[NSF], hy1[NSF], hy2[NSF];
+          ff_herm_rec_d2<NSF>(deg, zx, md, hx, hx1, hx2);
+          ff_herm_rec_d2<NSF>(deg + NSF, zy, md, hy, hy1, hy2);
+          const double gs = ff_gauss2d_fast(zx, zy);
+#pragma unroll
+          for (int j = 0; j < NSF; j++) {      // psi(x) = e^{-x^2/2} h(x): psi' = h' - x h, psi'' = h'' - 2 x h' + (x^2 - 1) h  (times the Gaussian)
+            const double px1 = fma(-zx, hx[j], hx1[j]), py1 = fma(-zy, hy[j], hy1[j]);
+            const double px2 = fma(fma(zx, zx, -1.0), hx[j], fma(-2.0 * zx, hx1[j], hx2[j]));
+            const double py2 = fma(fma(zy, zy, -1.0), hy[j], fma(-2.0 * zy, hy1[j], hy2[j]));
+            const double gx = gs * hx[j], gy = gs * hy[j];
+            ph[j] = gx * hy[j];
+            pgx[j] = gs * px1 * hy[j]; pgy[j] = gx * py1;
+            pxx[j] = gs * px2 * hy[j]; pxy[j] = gs * px1 * py1; pyy[j] = gx * py2;
+          }
+        }
+        if (pl) {
+#pragma unroll
+          for (int j = 0; j < NSF; j++) fD[al * NSF + j] = ph[j];
+        }
+        __syncthreads();
+        double lp0 = 0.0, trhs = 0.0;
+        double Tx[NSF], Ty[NSF], S3[3] = {0.0, 0.0, 0.0};
+        {
+          double Dm[NSF][NSF], Di[NSF][NSF];
+#pragma unroll
+          for (int a2 = 0; a2 < NSF; a2++)
+#pragma unroll
+            for (int j = 0; j < NSF; j++) Dm[a2][j] = fD[a2 * NSF + j];
+          const double det = ff_inv_small<NSF>(Dm, Di);
+          lp0 = (pl && al == 0) ? 2.0 * ff_log(fabs(det)) : 0.0;
+#pragma unroll
+          for (int bb2 = 0; bb2 < NSF; bb2++) {
+            double tx = 0.0, ty = 0.0;
+#pragma unroll
+            for (int j = 0; j < NSF; j++) { tx = fma(pgx[j], Di[j][bb2], tx); ty = fma(pgy[j], Di[j][bb2], ty); }
+            Tx[bb2] = tx; Ty[bb2] = ty;
+          }
+#pragma unroll
+          for (int j = 0; j < NSF; j++) {
+            double dja = Di[j][0];        // Dinv[j][al]: static select (no runtime-indexed register array)
+#pragma unroll
+            for (int a2 = 1; a2 < NSF; a2++) dja = (al == a2) ? Di[j][a2] : dja;
+            S3[0] = fma(pxx[j], dja, S3[0]); S3[1] = fma(pxy[j], dja, S3[1]); S3[2] = fma(pyy[j], dja, S3[2]);
+          }
+        }
+        if (pl) {
+          double txa = Tx[0], tya = Ty[0];
+#pragma unroll
+          for (int a2 = 1; a2 < NSF; a2++) { txa = (al == a2) ? Tx[a2] : txa; tya = (al == a2) ? Ty[a2] : tya; }
+          s_kb[w][2 * i16] = 2.0 * txa;           // g0 = grad_z logp0: 2 T_c[a][a]
+          s_kb[w][2 * i16 + 1] = 2.0 * tya;
+#pragma unroll
+          for (int bb2 = 0; bb2 < NSF; bb2++) { fT[al * NSF + bb2] = Tx[bb2]; fT[NSF * NSF + al * NSF + bb2] = Ty[bb2]; }
+        }
+        __syncthreads();
+        if (pl) {     // this particle's share of tr(H0 S): same-particle block with S3, cross blocks -T_ac (x) T_ca
+          const double* Sm = s_A[w];
+          const int ia = 2 * i16;
+          double q = S3[0] * Sm[ia * AS + ia] + 2.0 * S3[1] * Sm[ia * AS + ia + 1] + S3[2] * Sm[(ia + 1) * AS + ia + 1];
+#pragma unroll
+          for (int cc = 0; cc < NSF; cc++) {
+            const int ic = 2 * (off + cc);
+            const double tcx = fT[cc * NSF + al], tcy = fT[NSF * NSF + cc * NSF + al];
+            q -= Tx[cc] * (tcx * Sm[ia * AS + ic] + tcy * Sm[ia * AS + ic + 1]) + Ty[cc] * (tcx * Sm[(ia + 1) * AS + ic] + tcy * Sm[(ia + 1) * AS + ic + 1]);
+          }
+          trhs = 2.0 * q;
+        }
+        __syncthreads();
+        // grad_x logp: component p of J^T g0 (rows 4I + r on the lane, r across the walker's quads), minus grad Delta
+        double dd = 0.0;
+#pragma unroll
+        for (int K = 0; K < MB; K++) {
+          double t = 0.0;
+#pragma unroll
+          for (int I = 0; I < MB; I++) t = fma(s_kb[w][4 * I + r], y.get(1 + I * MB + K), t);
+          t += ff_lane_read(t, ln ^ 16);
+          t += ff_lane_read(t, ln ^ 32);
+          dd = (r == K) ? t : dd;
+        }
+        const double g0p = owner ? s_kb[w][p] : 0.0;
+        const double gradp = owner ? dd - y.get(IDD) : 0.0;
+        const double lapv = walker_sum(trhs + (owner ? g0p * y.get(IK) : 0.0) - (p == PLP ? y0 : 0.0));
+        const double logpv = walker_sum(lp0 - (p == PDL ? y0 : 0.0));
+        const double g2 = walker_sum(gradp * gradp);
+        // V(x) = sum_{i<j} Z / r_ij + (1/2) sum_i r_i^2 on the radius lanes (src/potentials.py:13, 23-47)
+        const double xp = ff_opt_load(A.y_in, valid && owner, b * M + p, A.y_in, 0.25 * (p + 1) + 0.125 * ((p * 7) % 5));
+        __syncthreads();
+        if (owner) s_z[w][p] = xp;
+        __syncthreads();
+        double vl = 0.0;
+#pragma unroll
+        for (int qk = 0; qk < NQ; qk++) {
+          int id = rq_id[qk];
+          FF_OPAQUE(id);
+          const bool act = id >= 0;
+          const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
+          const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
+          const int bb = pair ? bb0 : a;
+          double r2 = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+            const double d = s_z[w][a * D + cc] - (pair ? s_z[w][bb * D + cc] : 0.0);
+            r2 = fma(d, d, r2);
+          }
+          double rr, ri;
+          ff_sqrt_rcp(r2, rr, ri);
+          const double term = pair ? A.fin.Z * ri : (A.fin.use_ho ? 0.5 * r2 : 0.0);
+          vl += act ? term : 0.0;
+        }
+        // (without mu the one-body radii have no slot: the trap term is then taken by the coordinate lanes)
+        if (!has_mu && A.fin.use_ho && owner) vl = fma(0.5 * xp, xp, vl);
+        const double Vv = walker_sum(vl);
+        if (valid) {
+          ctl_t C; C.get(s_ctl[w]);
+          const ff_stepper& S = C.S;
+          const bool failed = S.fail != 0;
+          const double bad = failed ? __builtin_nan("") : 0.0;
+          if (owner) {
+            A.y_out[b * M + p] = y0 + bad;
+            if (A.fin.grad) A.fin.grad[b * M + p] = gradp + bad;
+            if (A.fin.glogp0) A.fin.glogp0[b * M + p] = g0p + bad;
+          }
+          if (p == PDL) {
+            A.dl_out[b] = y0 + bad;
+            if (A.fin.logp) A.fin.logp[b] = logpv + bad;
+            if (A.fin.lap) A.fin.lap[b] = lapv + bad;
+            if (A.fin.V) A.fin.V[b] = Vv;
+            if (A.fin.eloc) A.fin.eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv + bad;
+          }
+          if (r == 0 && c == 0) {
+            if (A.h_out) A.h_out[b] = C.hmax_acc > 0.0 ? C.hmax_acc : C.hwarm;
+            if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
+            if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
+          }
+        }
+      }
+    }
     // ---------------------------------------------------------------------- results
-    if (valid) {
+    if (valid && !fin_done) {
       ctl_t C; C.get(s_ctl[w]);
       const ff_stepper& S = C.S;
       const double hmax_acc = C.hmax_acc, hwarm = C.hwarm;

@@ -40,6 +40,16 @@ struct ff_fwd_args {
   int heavy_mode, heavy_class;
   double heavy_tol;        // tolerances of the heavy launch: heavy_tol x (rtol, atol)  (ff_ode.heavy_tol)
   double sum_w;            // ff_ode.sum_weight: error-norm weight of Delta and lap Delta in the matrix-core kernel
+  // Fused finish (ff_eloc; kernels that implement it: ff_eloc_mfma_kernel for nup = ndn): with fin.on the sensitivity kernel
+  // contracts J, kbar, grad Delta and lap Delta with the Slater gradient / Hessian at z(t0) in its epilogue and writes logp, grad,
+  // lap, V, E_loc (src/VMC.py:46-55) and grad_z logp0 itself -- J^T never goes to HBM (Jt, kbar, dD, Lpart are not written;
+  // y_out = z(t0) and dl_out = Delta still are: the adjoint reads them).  Any output pointer may be NULL.
+  struct ff_fin_args {
+    int on, nup, ndn, use_ho;
+    const int32_t *tab_up, *tab_dn, *wstate;
+    double Z;
+    double *logp, *grad, *lap, *V, *eloc, *glogp0;
+  } fin;
 };
 
 // Kernels for walkers that do not fit one wave's column / row layouts (n > 12 in d = 2, n > 4 in d = 3): ff_wide.hip.

@@ -153,22 +153,6 @@ FF_D double ff_pow02(double x, float e) {
   return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)x));
 }
 
-// The tableau as a table, one row per stage index of the RHS loops (s = -2..6 -> row s + 2), for kernels whose state is
-// so small that holding ~30 tableau literals in scalar registers costs more than the arithmetic (tabulated adjoint):
-// stage input = y + hsel * sum_k FF_ATAB[row][k] * k_k   (row 1: the probe step of the initial-step heuristic);
-// row 9: the error weights E0..E5 (E6 multiplies the stage-6 slope).
-__constant__ double FF_ATAB[10][6] = {
-    {0, 0, 0, 0, 0, 0},
-    {1, 0, 0, 0, 0, 0},
-    {0, 0, 0, 0, 0, 0},
-    {FF_A10, 0, 0, 0, 0, 0},
-    {FF_A20, FF_A21, 0, 0, 0, 0},
-    {FF_A30, FF_A31, FF_A32, 0, 0, 0},
-    {FF_A40, FF_A41, FF_A42, FF_A43, 0, 0},
-    {FF_A50, FF_A51, FF_A52, FF_A53, FF_A54, 0},
-    {FF_B0, 0, FF_B2, FF_B3, FF_B4, FF_B5},
-    {FF_E0, 0, FF_E2, FF_E3, FF_E4, FF_E5}};
-
 // Wave-wide OR of per-lane flag words (bit 0: still integrating, bit 1: just rejected a step); wave-uniform result.
 // Two ballots -- no LDS traffic, no barrier (64 lanes OR-ing into one LDS word serialise: that cost ~10 % of the
 // local-energy kernel).

@@ -94,6 +94,61 @@ FF_D double ff_herm_rec(int n, double x, int md) {
   return res;
 }
 
+// h_n, h_n', h_n'' of the normalised Hermite polynomials of degrees n[0..NS) at x from ONE pass of the recurrence, with
+//   h_n' = sqrt(2 n) h_{n-1},   h_n'' = 2 sqrt(n (n - 1)) h_{n-2}
+// -- no coefficient-table loads (ff_herm's Horner fetches 8 coefficients per polynomial from constant memory by a per-lane index),
+// no private arrays.  md: wave-uniform bound of the degrees (scalar trip count).
+__constant__ double FF_HD1[8] = {0.0, 1.4142135623730951, 2.0, 2.4494897427831779, 2.8284271247461903, 3.1622776601683795,
+                                 3.4641016151377544, 3.7416573867739413};                         // sqrt(2 n)
+__constant__ double FF_HD2[8] = {0.0, 0.0, 2.8284271247461903, 4.8989794855663558, 6.9282032302755088, 8.9442719099991592,
+                                 10.954451150103322, 12.961481396815721};                          // 2 sqrt(n (n - 1))
+template <int NS>
+FF_D void ff_herm_rec_d2(const int* n, double x, int md, double* h, double* h1, double* h2) {
+  double hm2 = 0.0, hm1 = 1.0, hc = FF_REC_A[0] * x;      // h_{m-1}, h_m, h_{m+1} at m = 0
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    h[j] = (n[j] == 0) ? 1.0 : hc;
+    h1[j] = (n[j] == 0) ? 0.0 : FF_HD1[1];
+    h2[j] = 0.0;
+  }
+  for (int m = 1; m < md; m++) {
+    const double hn = fma(FF_REC_A[m] * x, hc, -FF_REC_B[m] * hm1);
+    hm2 = hm1; hm1 = hc; hc = hn;
+    const double d1 = FF_HD1[m + 1] * hm1, d2 = FF_HD2[m + 1] * hm2;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      const bool sel = n[j] == m + 1;
+      h[j] = sel ? hc : h[j]; h1[j] = sel ? d1 : h1[j]; h2[j] = sel ? d2 : h2[j];
+    }
+  }
+}
+
+// inverse (by the adjugate) and determinant of a register-resident matrix up to 3 x 3: Ainv[j][b], no pivot search, one reciprocal
+template <int NS>
+FF_D double ff_inv_small(const double (&A)[NS][NS], double (&Ai)[NS][NS]) {
+  static_assert(NS >= 1 && NS <= 3, "closed-form inverse up to 3 x 3");
+  if constexpr (NS == 1) {
+    Ai[0][0] = 1.0 / A[0][0];
+    return A[0][0];
+  } else if constexpr (NS == 2) {
+    const double det = fma(A[0][0], A[1][1], -A[0][1] * A[1][0]), id = 1.0 / det;
+    Ai[0][0] = A[1][1] * id; Ai[0][1] = -A[0][1] * id; Ai[1][0] = -A[1][0] * id; Ai[1][1] = A[0][0] * id;
+    return det;
+  } else {
+    const double c00 = fma(A[1][1], A[2][2], -A[1][2] * A[2][1]), c01 = fma(A[1][2], A[2][0], -A[1][0] * A[2][2]),
+                 c02 = fma(A[1][0], A[2][1], -A[1][1] * A[2][0]);
+    const double det = fma(A[0][0], c00, fma(A[0][1], c01, A[0][2] * c02)), id = 1.0 / det;
+    Ai[0][0] = c00 * id; Ai[1][0] = c01 * id; Ai[2][0] = c02 * id;
+    Ai[0][1] = fma(A[0][2], A[2][1], -A[0][1] * A[2][2]) * id;
+    Ai[1][1] = fma(A[0][0], A[2][2], -A[0][2] * A[2][0]) * id;
+    Ai[2][1] = fma(A[0][1], A[2][0], -A[0][0] * A[2][1]) * id;
+    Ai[0][2] = fma(A[0][1], A[1][2], -A[0][2] * A[1][1]) * id;
+    Ai[1][2] = fma(A[0][2], A[1][0], -A[0][0] * A[1][2]) * id;
+    Ai[2][2] = fma(A[0][0], A[1][1], -A[0][1] * A[1][0]) * id;
+    return det;
+  }
+}
+
 // nx/ny: the orbitals' Hermite degrees, decoded once by the caller (ff_orb_decode) outside its step loop;
 // md: a wave-uniform upper bound of those degrees.
 // |det D| of a register-resident NS x NS matrix (destroyed): LU with partial pivoting, the product of the pivots

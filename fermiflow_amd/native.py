@@ -201,9 +201,10 @@ def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, 
 
 
 def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker_state=None, want_stats=False,
-         pass1_events=None, walker_cost=None, walker_order=None, **warm):
-    """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity kernel
-    only (bench.py times the dominant kernel with it)."""
+         pass1_events=None, walker_cost=None, walker_order=None, two_pass=False, **warm):
+    """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity pass
+    (bench.py times the dominant kernel with it).  two_pass: ff_eloc_sensitivities + ff_eloc_finish as separate calls with the
+    sensitivities in the workspace between them (the path every kernel without a fused finish takes anyway)."""
     x = L.dev(x, name="x")
     B, n, d = x.shape[0], nup + ndn, x.shape[2]
     f = dict(dtype=torch.float64, device=x.device)
@@ -219,15 +220,25 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
     if pass1_events is not None:
         pass1_events[0].record()
-    L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),
-            "ff_eloc_sensitivities")
-    if pass1_events is not None:
-        pass1_events[1].record()
-    finish = L.lib().ff_eloc_finish3d if d == 3 else L.lib().ff_eloc_finish      # d = 3: HO3D orbital tables (csrc/ff_ho3d.hip)
-    L.check(finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
-                                   L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(ws), L.ptr(out["logp"]), L.ptr(out["grad"]),
-                                   L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None,
-                                   None, L.ptr(out["glogp0"])), "ff_eloc_finish")
+    if d == 2 and not two_pass:
+        # one call: the library fuses the finish into the sensitivity kernel where that kernel implements it (then the second
+        # event of pass1_events closes the whole pass: nothing is left to run behind it but the few walkers of the heavy route)
+        L.check(L.lib().ff_eloc(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)), net.ref(),
+                                C.byref(o), L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(out["logp"]), L.ptr(out["grad"]),
+                                L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None, None, L.ptr(out["glogp0"]), L.ptr(ws),
+                                L.ptr(st)), "ff_eloc")
+        if pass1_events is not None:
+            pass1_events[1].record()
+    else:
+        L.check(L.lib().ff_eloc_sensitivities(L.stream(), L.i64(B), n, d, net.ref(), C.byref(o), L.ptr(x), L.ptr(ws), L.ptr(st)),
+                "ff_eloc_sensitivities")
+        if pass1_events is not None:
+            pass1_events[1].record()
+        finish = L.lib().ff_eloc_finish3d if d == 3 else L.lib().ff_eloc_finish      # d = 3: HO3D orbital tables (csrc/ff_ho3d.hip)
+        L.check(finish(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)),
+                       L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(ws), L.ptr(out["logp"]), L.ptr(out["grad"]),
+                       L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None,
+                       None, L.ptr(out["glogp0"])), "ff_eloc_finish")
     if want_stats:
         out["stats"] = st
     return out
