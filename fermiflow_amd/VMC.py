@@ -150,10 +150,13 @@ class _Sweep:
                 hprev, uniform = self._h_flow, True
         x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=cost,
                                 walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg, walker_h_uniform=uniform)
-        if warm:
-            self._h_flow = hg if per_walker_h else hg.mean().reshape(1)
+        if warm and not per_walker_h:
+            order, self._h_flow = native.walker_order(cost, hval=hg)      # the schedule and the mean accepted step from the same launches
+        else:
+            order = native.walker_order(cost)
+            if warm:
+                self._h_flow = hg
         he = torch.empty_like(hg) if warm else None
-        order = native.walker_order(cost)
         self._mark(ev, "generate")
         p1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if prof is not None else None
         Z, use_ho, extra = potential_plan(self.pair_potential, self.sp_potential)
@@ -391,9 +394,12 @@ class GSVMC(_Sweep, torch.nn.Module):
             # from E on the device (ff_cnf_adjoint_energy) -- nothing here waits for the host
             prev = self._dev.get("E")
             shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
-            sums = native.reduce_energy(Eloc, r["logp"], shift)
-            D.all_reduce_sum_(sums)
-            est = native.energy_finish(sums, shift, batch)        # [E, sum (e - E)^2, mean(logp (e - E))]
+            if not D._active():
+                _, est = native.energy_estimate(Eloc, r["logp"], shift, batch)       # one launch: sums and finish (nothing to all-reduce)
+            else:
+                sums, _ = native.energy_estimate(Eloc, r["logp"], shift, 0)
+                D.all_reduce_sum_(sums)
+                est = native.energy_finish(sums, shift, batch)    # [E, sum (e - E)^2, mean(logp (e - E))]
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
             go = None

@@ -1120,7 +1120,54 @@ ff_eloc_slater_fixed_kernel(int64_t B, int nup, int ndn, const int* __restrict__
   double zl[2 * NS], T[2 * NS * NS], S[3 * NS];
 #pragma unroll
   for (int k = 0; k < 2 * NS; k++) zl[k] = z0[b * M + 2 * off + k];
-  const double lp0 = ff_slater_fixed<NS>((sp ? tab_dn : tab_up) + st * NS, zl, T, S);
+  double lp0;
+  if constexpr (NS <= 3) {
+    // up to 3 x 3: Hermite functions and both derivatives from one recurrence pass per coordinate, the inverse by the adjugate
+    // (ff_slater_fixed -- Horner on the coefficient table by a per-lane index, Gauss-Jordan with a pivot search -- takes 55 us per
+    // 131 072 determinants at NS = 3 and every register; this takes a tenth)
+    const int* orb = (sp ? tab_dn : tab_up) + st * NS;
+    int deg[2 * NS], md = 1;
+#pragma unroll
+    for (int j = 0; j < NS; j++) { ff_orb_decode(orb[j], deg[j], deg[NS + j]); }
+#pragma unroll
+    for (int j = 0; j < 2 * NS; j++) md = deg[j] > md ? deg[j] : md;
+    double Dm[NS][NS], Di[NS][NS], gx[NS][NS], gy[NS][NS], hxx[NS][NS], hxy[NS][NS], hyy[NS][NS];
+#pragma unroll
+    for (int a = 0; a < NS; a++) {
+      const double zx = zl[2 * a], zy = zl[2 * a + 1];
+      double hx[NS], hx1[NS], hx2[NS], hy[NS], hy1[NS], hy2[NS];
+      ff_herm_rec_d2<NS>(deg, zx, md, hx, hx1, hx2);
+      ff_herm_rec_d2<NS>(deg + NS, zy, md, hy, hy1, hy2);
+      const double gs = ff_gauss2d(zx, zy);
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const double px1 = fma(-zx, hx[j], hx1[j]), py1 = fma(-zy, hy[j], hy1[j]);
+        const double px2 = fma(fma(zx, zx, -1.0), hx[j], fma(-2.0 * zx, hx1[j], hx2[j]));
+        const double py2 = fma(fma(zy, zy, -1.0), hy[j], fma(-2.0 * zy, hy1[j], hy2[j]));
+        const double ex = gs * hx[j], ey = gs * hy[j];
+        Dm[a][j] = ex * hy[j];
+        gx[a][j] = gs * px1 * hy[j]; gy[a][j] = ex * py1;
+        hxx[a][j] = gs * px2 * hy[j]; hxy[a][j] = gs * px1 * py1; hyy[a][j] = ex * py2;
+      }
+    }
+    lp0 = log(fabs(ff_inv_small<NS>(Dm, Di)));
+#pragma unroll
+    for (int a = 0; a < NS; a++) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int bq = 0; bq < NS; bq++) {
+        double tx = 0.0, ty = 0.0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) { tx = fma(gx[a][j], Di[j][bq], tx); ty = fma(gy[a][j], Di[j][bq], ty); }
+        T[a * NS + bq] = tx; T[NS * NS + a * NS + bq] = ty;
+      }
+#pragma unroll
+      for (int j = 0; j < NS; j++) { s0 = fma(hxx[a][j], Di[j][a], s0); s1 = fma(hxy[a][j], Di[j][a], s1); s2 = fma(hyy[a][j], Di[j][a], s2); }
+      S[3 * a] = s0; S[3 * a + 1] = s1; S[3 * a + 2] = s2;
+    }
+  } else {
+    lp0 = ff_slater_fixed<NS>((sp ? tab_dn : tab_up) + st * NS, zl, T, S);
+  }
 #pragma unroll
   for (int a = 0; a < NS; a++) {
     Q[b * nqs + (2 * (off + a))] = 2.0 * T[a * NS + a];
@@ -1294,6 +1341,12 @@ static ff_side_lane* ff_side() {
   }
   return &l;
 }
+extern "C" {
+static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                            const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                            double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                            double* glogp0_out, ff_fin_filter flt);
+}
 enum { FF_ROUTE_NONE = 0, FF_ROUTE_DONE = 1, FF_ROUTE_FAILED = 2 };
 // What the local-energy dispatch of THIS host thread did, for ff_eloc to read back right after it: did the kernel it chose take the
 // fused finish (ff_fwd_args::fin), and was the pass routed (then the walkers of class >= heavy_class still need the finish kernels).
@@ -1321,6 +1374,17 @@ static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F lau
   // placed first: a persistent grid takes every register file it finds
   if (ff_wide_eloc_heavy(stream, n, d, h, 1024) != FF_OK) { (void)hipGetLastError(); return FF_ROUTE_NONE; }
   launch_table(side->stream, l);
+  // With the fused finish the throughput kernel writes its walkers' local energies itself; the heavy route's walkers leave their
+  // sensitivities in the workspace and take the two finish kernels, filtered by class -- enqueued HERE, behind the heavy kernel on
+  // the caller's stream and in front of the join: the heavy kernel ends well before the throughput kernel does (0.53 against
+  // 0.82 ms at config 2), so their 46 us run in its shadow.  (Should the table kernels raise the off-table event, the unrouted
+  // fused direct kernel behind the join redoes every walker and overwrites these outputs.)
+  if (a.fin.on && a.fin.workspace) {
+    const ff_fwd_args::ff_fin_args& f = a.fin;
+    if (eloc_finish_impl(stream, a.B, f.nup, f.ndn, f.tab_up, f.tab_dn, f.wstate, f.Z, f.use_ho, a.y_in, f.workspace, f.logp, f.grad, f.lap,
+                         f.V, f.eloc, nullptr, nullptr, f.glogp0, ff_fin_filter{a.wclass, a.heavy_class, a.evt, a.evt_id}) != FF_OK)
+      (void)hipGetLastError();      // (falls through to the join; the failure resurfaces in the caller's launch check)
+  }
   const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(side->join, side->stream) == hipSuccess &&
                   hipStreamWaitEvent((hipStream_t)stream, side->join, 0) == hipSuccess;
   if (!ok) {
@@ -1480,9 +1544,7 @@ int ff_radial_table_build(void* stream, const ff_net* net, double* table) {
   FF_CHECK(net && table, FF_EINVAL, "ff_radial_table_build: null pointer");
   FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
            "ff_radial_table_build: bad net");
-  FF_LAUNCH(ff_table_header_kernel, 1, 64, stream, *net, table);
-  FF_LAUNCH_CHECK();
-  FF_LAUNCH(ff_table_build_kernel, (unsigned)((2 * FF_TAB_NMAX + 127) / 128), 128, stream, *net, table);
+  FF_LAUNCH(ff_table_kernel, FF_TAB_GRID, 128, stream, *net, table);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }
@@ -1560,11 +1622,6 @@ static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const 
   return dispatch_fwd<2>(stream, n, d, a);
 }
 
-static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
-                            const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
-                            double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
-                            double* glogp0_out, ff_fin_filter flt);
-
 /* pass 2 of ff_eloc: Slater gradient/Hessian contraction, potentials, E_loc */
 int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
                    const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
@@ -1623,7 +1680,7 @@ int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, co
   const int n = nup + ndn;
   fin.on = (nup == ndn && nup >= 1 && nup <= 3) ? 1 : 0;
   fin.nup = nup; fin.ndn = ndn; fin.use_ho = use_ho; fin.tab_up = tab_up; fin.tab_dn = tab_dn; fin.wstate = walker_state; fin.Z = Z;
-  fin.logp = logp; fin.grad = grad; fin.lap = lap; fin.V = V; fin.eloc = eloc; fin.glogp0 = glogp0_out;
+  fin.logp = logp; fin.grad = grad; fin.lap = lap; fin.V = V; fin.eloc = eloc; fin.glogp0 = glogp0_out; fin.workspace = workspace;
   int st = eloc_sensitivities_impl(stream, B, n, 2, net, ode, x, workspace, stats, &fin);
   if (st) return st;
   const ff_eloc_feedback fb = t_eloc_fb;
@@ -1631,12 +1688,7 @@ int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, co
   if (!fb.fused)
     return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
                           z_out, dlogp_out, glogp0_out);
-  if (fb.routed) {    // the walkers of the heavy route: their sensitivities are in the workspace
-    st = eloc_finish_impl(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc, nullptr,
-                          nullptr, glogp0_out, ff_fin_filter{ode->walker_class, ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT : ode->heavy_class,
-                                                             fb.evt, fb.evt_id});
-    if (st) return st;
-  }
+  // (routed pass: the walkers of the heavy route were finished inside launch_routed, in the shadow of the throughput kernel)
   const size_t M = (size_t)n * 2;
   ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, 2);
   if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;

@@ -49,6 +49,7 @@ struct ff_fwd_args {
     const int32_t *tab_up, *tab_dn, *wstate;
     double Z;
     double *logp, *grad, *lap, *V, *eloc, *glogp0;
+    void* workspace;      // host side only: the caller's ff_eloc workspace (finish of the walkers of the heavy route)
   } fin;
 };
 

@@ -64,57 +64,82 @@ FF_D void ff_sigma_derivs(double s, double* out) {
 #define FF_DEP_ROW 12                       // T_0 .. T_11
 
 #ifdef FF_RADIAL_BUILD_KERNELS   // defined by the one translation unit that owns ff_radial_table_build
-// header: grid spacing from the stiffest first-layer weight (single workgroup)
-__global__ void __launch_bounds__(64) ff_table_header_kernel(ff_net net, double* __restrict__ tab) {
-  __shared__ double sm[64];
+// The whole table in ONE launch (round 3: a single-workgroup header kernel + a one-lane-per-node build kernel, 5 + 18 us in front of
+// every sweep).  Every workgroup derives the header -- grid spacing from the stiffest first-layer weight -- itself (the same
+// hundred loads and the same arithmetic everywhere), workgroup 0 stores it; FOUR lanes share a node, each summing every fourth
+// hidden unit, joined by a quad reduction in a fixed order: the sequential chain of H sigmoid evaluations per lane was the kernel.
+#define FF_TAB_NODES_PER_WG 32
+#ifndef FF_TAB_GRID
+#define FF_TAB_GRID 256                     // one workgroup per CU: 2 x 2049 nodes (h = 1/64) in one round, 2 x 16385 in four
+#endif
+__global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __restrict__ tab) {
+  __shared__ double sm[128];
+  const int tid = threadIdx.x;
   double w = 0.0;
-  for (int h = threadIdx.x; h < net.He; h += 64) w = fmax(w, fabs(net.ew1[h]));
-  for (int h = threadIdx.x; h < net.Hm; h += 64) w = fmax(w, fabs(net.mw1[h]));
-  sm[threadIdx.x] = w;
+  for (int h = tid; h < net.He; h += 128) w = fmax(w, fabs(net.ew1[h]));
+  for (int h = tid; h < net.Hm; h += 128) w = fmax(w, fabs(net.mw1[h]));
+  if (!(w == w)) w = __builtin_inf();      // fmax drops NaN: a NaN weight must make the table unusable
+  for (int h = tid; h < net.He; h += 128) if (!(net.ew1[h] == net.ew1[h])) w = __builtin_inf();
+  for (int h = tid; h < net.Hm; h += 128) if (!(net.mw1[h] == net.mw1[h])) w = __builtin_inf();
+  sm[tid] = w;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int q = 1; q < 64; q++) w = fmax(w, sm[q]);
-    // (w h/2)^6/720 <~ 1e-15  <=>  w h <= 0.06
-    int lg = 6;
-    while (lg < FF_TAB_MAXLOG && w * ldexp(1.0, -lg) > 0.06) lg++;
-    const bool bad = !(w * ldexp(1.0, -lg) <= 0.06);   // also catches NaN weights
+  for (int q = 64; q > 0; q >>= 1) {
+    if (tid < q) sm[tid] = fmax(sm[tid], sm[tid + q]);
+    __syncthreads();
+  }
+  w = sm[0];
+  // (w h/2)^6/720 <~ 1e-15  <=>  w h <= 0.06
+  int lg = 6;
+  while (lg < FF_TAB_MAXLOG && w * ldexp(1.0, -lg) > 0.06) lg++;
+  const bool bad = !(w * ldexp(1.0, -lg) <= 0.06);
+  const double hstep = ldexp(1.0, -lg);
+  const int nodes = 32 * (1 << lg) + 1;
+  if (blockIdx.x == 0 && tid == 0) {
     tab[0] = ldexp(1.0, lg);
-    tab[1] = ldexp(1.0, -lg);
-    tab[2] = (double)(32 * (1 << lg) + 1);
+    tab[1] = hstep;
+    tab[2] = (double)nodes;
     tab[3] = bad ? 1.0 : 0.0;
     tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.6) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
     for (int q = 5; q < FF_TAB_HDR; q++) tab[q] = 0.0;
   }
-}
-
-// one lane per (net, node): f^(0..8)(r_j) = sum_h w2 w1^n sigma^(n)(w1 r_j + b1)
-__global__ void __launch_bounds__(128) ff_table_build_kernel(ff_net net, double* __restrict__ tab) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = idx / FF_TAB_NMAX, j = idx - t * FF_TAB_NMAX;
-  const int nodes = (int)tab[2];
-  if (t > 1 || j >= nodes || tab[3] != 0.0) return;
-  const int H = t ? net.Hm : net.He;
-  const double* w1 = t ? net.mw1 : net.ew1;
-  const double* b1 = t ? net.mb1 : net.eb1;
-  const double* w2 = t ? net.mw2 : net.ew2;
-  const double r = (double)j * tab[1];
-  double acc[9];
+  if (bad) return;
+  // f^(0..8)(r_j) = sum_h w2 w1^n sigma^(n)(w1 r_j + b1): quad q of the launch takes the nodes q, q + (quads of the launch), ... of
+  // the 2 x nodes (net, node) pairs; its lanes the hidden units h = tid % 4, + 4, ...
+  const int part = tid & 3;
+  const int nquads = (int)gridDim.x * FF_TAB_NODES_PER_WG;
+  for (int idx = blockIdx.x * FF_TAB_NODES_PER_WG + (tid >> 2); idx - (tid >> 2) < 2 * nodes; idx += nquads) {     // (workgroup-uniform trip count)
+    const int t = idx >= nodes ? 1 : 0, j = idx - t * nodes;
+    const bool live = idx < 2 * nodes;         // (whole quads are live or not: the quad reduction below is uniform per quad)
+    const int H = live ? (t ? net.Hm : net.He) : 0;
+    const double* w1 = t ? net.mw1 : net.ew1;
+    const double* b1 = t ? net.mb1 : net.eb1;
+    const double* w2 = t ? net.mw2 : net.ew2;
+    const double r = (double)j * hstep;
+    double acc[9];
 #pragma unroll
-  for (int n = 0; n < 9; n++) acc[n] = 0.0;
-  for (int h = 0; h < H; h++) {
-    const double s = ff_sigmoid(fma(w1[h], r, b1[h]));
-    double sd[9], wp = w2[h];
-    ff_sigma_derivs<8>(s, sd);
+    for (int n = 0; n < 9; n++) acc[n] = 0.0;
+    for (int h = part; h < H; h += 4) {
+      const double s = ff_sigmoid(fma(w1[h], r, b1[h]));
+      double sd[9], wp = w2[h];
+      ff_sigma_derivs<8>(s, sd);
+#pragma unroll
+      for (int n = 0; n < 9; n++) {
+        acc[n] = fma(wp, sd[n], acc[n]);
+        wp *= w1[h];
+      }
+    }
 #pragma unroll
     for (int n = 0; n < 9; n++) {
-      acc[n] = fma(wp, sd[n], acc[n]);
-      wp *= w1[h];
+      acc[n] += ff_swap1(acc[n]);
+      acc[n] += ff_swap2(acc[n]);
+    }
+    if (live && part == 0) {
+      double* row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + j) * FF_TAB_ROW;
+#pragma unroll
+      for (int n = 0; n < 9; n++) row[n] = acc[n];
+      row[9] = 0.0;
     }
   }
-  double* row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + j) * FF_TAB_ROW;
-#pragma unroll
-  for (int n = 0; n < 9; n++) row[n] = acc[n];
-  row[9] = 0.0;
 }
 
 #endif  // FF_RADIAL_BUILD_KERNELS

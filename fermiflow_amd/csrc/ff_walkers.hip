@@ -894,14 +894,82 @@ ff_energy_sums_kernel(int64_t B, const double* __restrict__ e, const double* __r
   if (t < 4) out[t] = sm[t][0];
 }
 
+// The same four sums from many workgroups (one workgroup reads 1 MB at one CU's bandwidth: 19 us at 65 536 walkers): workgroup k
+// reduces walkers [k FF_EST_SEG, (k + 1) FF_EST_SEG) with a fixed tree and stores its partials; the workgroup that finishes LAST
+// (a counter in the workspace) adds the partials in workgroup order -- one fixed order whoever is last -- and, with n_global > 0
+// (single rank: nothing to all-reduce), goes on to E, the centred sum of squares and the surrogate (ff_energy_finish).  It
+// leaves the counter at zero: the workspace is zeroed by the caller ONCE, before its first use.
+#define FF_EST_SEG 1024
+#define FF_EST_THREADS 256
+FF_D void ff_energy_finish_values(const double* sums, double shift, double n, double* est) {
+  const double d = sums[0] / n;                       // E - c
+  est[0] = shift + d;
+  est[1] = sums[1] - sums[0] * d;                     // sum (e - E)^2 = sum (e - c)^2 - n (E - c)^2
+  est[2] = (sums[3] - d * sums[2]) / n;               // mean(logp (e - E))
+}
+__global__ void __launch_bounds__(FF_EST_THREADS)
+ff_energy_estimate_kernel(int64_t B, const double* __restrict__ e, const double* __restrict__ logp, const double* __restrict__ shift_dev,
+                          double n_global, double* __restrict__ sums4, double* __restrict__ est3, double* __restrict__ part,
+                          unsigned* __restrict__ counter) {
+  __shared__ double sm[4][FF_EST_THREADS];
+  __shared__ unsigned s_last;
+  const double shift = ff_finite_shift(shift_dev[0]);
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int64_t j0 = (int64_t)blockIdx.x * FF_EST_SEG;
+  int w0 = 1;
+  while (w0 * 2 < nt) w0 *= 2;      // largest power of two below the block size
+  double a = 0.0, q = 0.0, l = 0.0, m = 0.0;
+  for (int k = t; k < FF_EST_SEG && j0 + k < B; k += nt) {
+    const double v = e[j0 + k] - shift, lp = logp[j0 + k];
+    a += v; q = fma(v, v, q); l += lp; m = fma(lp, v, m);
+  }
+  sm[0][t] = a; sm[1][t] = q; sm[2][t] = l; sm[3][t] = m;
+  __syncthreads();
+  for (int w = w0; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) sm[k][t] += sm[k][t + w];
+    }
+    __syncthreads();
+  }
+  if (t < 4) part[(int64_t)blockIdx.x * 4 + t] = sm[t][0];
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // the last workgroup: partials in workgroup order (thread t takes k = t, t + nt, ... and the tree joins them -- the same
+  // association for every run)
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = t; k < (int)gridDim.x; k += nt) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) s4[c] += part[(int64_t)k * 4 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) sm[c][t] = s4[c];
+  __syncthreads();
+  for (int w = w0; w > 0; w >>= 1) {
+    if (t < w && t + w < nt) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) sm[k][t] += sm[k][t + w];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double tot[4] = {sm[0][0], sm[1][0], sm[2][0], sm[3][0]};
+#pragma unroll
+    for (int c = 0; c < 4; c++) sums4[c] = tot[c];
+    if (n_global > 0.0 && est3) ff_energy_finish_values(tot, shift, n_global, est3);
+    *counter = 0u;
+  }
+}
+
 // est = [E, sum (e - E)^2, sum logp (e - E) / n] from the (all-reduced) sums of ff_energy_sums_kernel over n walkers
 __global__ void ff_energy_finish_kernel(const double* __restrict__ sums, const double* __restrict__ shift_dev, double n,
                                         double* __restrict__ est) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double d = sums[0] / n;                 // E - c
-  est[0] = ff_finite_shift(shift_dev[0]) + d;
-  est[1] = sums[1] - sums[0] * d;
-  est[2] = (sums[3] - d * sums[2]) / n;
+  ff_energy_finish_values(sums, ff_finite_shift(shift_dev[0]), n, est);
 }
 
 // Per-state sums of the finite-temperature estimator (src/VMC.py:164-169: the per-state baseline of gradF_theta, and the
@@ -1127,25 +1195,46 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
 #define FF_ORD_SEG 2048
 FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
 
-// pass 1: per-segment histogram
+// pass 1: per-segment histogram (+ optionally the segment's sum of hval, fixed tree: the sweeps want the mean accepted step of
+// the flow pass, and a torch mean() was two more launches)
 __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t B, const int32_t* __restrict__ cost,
-                                                                        unsigned* __restrict__ hist) {
+                                                                        unsigned* __restrict__ hist, const double* __restrict__ hval,
+                                                                        double* __restrict__ hsum) {
   __shared__ unsigned h[FF_ORD_BINS];
+  __shared__ double sh[FF_ORD_THREADS];
   const int t = threadIdx.x;
   if (t < FF_ORD_BINS) h[t] = 0;
   __syncthreads();
   const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
-  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) atomicAdd(&h[ff_ord_row(cost[j0 + k])], 1u);
+  double acc = 0.0;
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
+    atomicAdd(&h[ff_ord_row(cost[j0 + k])], 1u);
+    if (hval) acc += hval[j0 + k];
+  }
+  sh[t] = acc;
   __syncthreads();
   if (t < FF_ORD_BINS) hist[(int64_t)blockIdx.x * FF_ORD_BINS + t] = h[t];
+  if (hval) {
+    for (int q = FF_ORD_THREADS / 2; q > 0; q >>= 1) {
+      if (t < q) sh[t] += sh[t + q];
+      __syncthreads();
+    }
+    if (t == 0) hsum[blockIdx.x] = sh[0];
+  }
 }
 
 // pass 2: position = (walkers in more expensive rows) + (same row, earlier segments) + (same row and segment, earlier
 // (thread, index)); the last term from per-thread counters, so no atomics decide an order
 __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t B, const int32_t* __restrict__ cost,
                                                                         const unsigned* __restrict__ hist, int nseg,
-                                                                        int32_t* __restrict__ order) {
+                                                                        int32_t* __restrict__ order, const double* __restrict__ hsum,
+                                                                        double* __restrict__ hmean) {
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
+  if (hmean && blockIdx.x == 0 && threadIdx.x == 0) {      // the segments' sums in segment order: one fixed summation order
+    double a = 0.0;
+    for (int k = 0; k < nseg; k++) a += hsum[k];
+    hmean[0] = a / (double)B;
+  }
   __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
   __shared__ unsigned base[FF_ORD_BINS];
   const int t = threadIdx.x, seg = blockIdx.x;
@@ -1306,20 +1395,29 @@ int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, co
   return FF_OK;
 }
 
+// [nseg][BINS] histogram | nseg segment sums of hval
 size_t ff_walker_order_workspace_bytes(int64_t B) {
-  return sizeof(unsigned) * FF_ORD_BINS * (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
+  const size_t nseg = (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
+  return sizeof(unsigned) * FF_ORD_BINS * nseg + sizeof(double) * nseg;
 }
 
-int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {
+int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean) {
   FF_CHECK(B >= 0 && (B == 0 || (cost && order && workspace)), FF_EINVAL, "ff_walker_order: bad argument");
+  FF_CHECK((hval == nullptr) == (hmean == nullptr), FF_EINVAL, "ff_walker_order_mean: hval and hmean go together");
   FF_CHECK(B < ((int64_t)1 << 31), FF_EUNSUPPORTED, "ff_walker_order: B >= 2^31");
   if (B == 0) return FF_OK;
   const int nseg = (int)((B + FF_ORD_SEG - 1) / FF_ORD_SEG);
-  FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace);
+  double* hsum = (double*)((unsigned*)workspace + (size_t)FF_ORD_BINS * nseg);
+  FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace, hval, hsum);
   FF_LAUNCH_CHECK();
-  FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order);
+  FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order,
+            (const double*)hsum, hmean);
   FF_LAUNCH_CHECK();
   return FF_OK;
+}
+
+int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {
+  return ff_walker_order_mean(stream, B, cost, order, workspace, nullptr, nullptr);
 }
 
 int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, const double* shift_dev, double shift_dev_scale,
@@ -1340,6 +1438,23 @@ int ff_stream_delay(void* stream, double microseconds) {
 int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4) {
   FF_CHECK(B > 0 && e && logp && shift_dev && sums4, FF_EINVAL, "ff_reduce_energy: bad argument");
   FF_LAUNCH(ff_energy_sums_kernel, 1, FF_RBLOCK(1024), stream, B, e, logp, shift_dev, sums4);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+size_t ff_energy_estimate_workspace_bytes(int64_t B) {
+  const size_t nb = (size_t)((B + FF_EST_SEG - 1) / FF_EST_SEG > 0 ? (B + FF_EST_SEG - 1) / FF_EST_SEG : 1);
+  return sizeof(double) * (4 * nb + 1);
+}
+
+int ff_energy_estimate(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, int64_t n_global,
+                       double* sums4, double* est3, void* workspace) {
+  FF_CHECK(B > 0 && e && logp && shift_dev && sums4 && workspace && n_global >= 0 && (n_global == 0 || est3), FF_EINVAL,
+           "ff_energy_estimate: bad argument");
+  const unsigned nb = (unsigned)((B + FF_EST_SEG - 1) / FF_EST_SEG);
+  double* part = (double*)workspace + 1;       // [0]: the counter (zero between calls) | partial sums
+  FF_LAUNCH(ff_energy_estimate_kernel, nb, FF_RBLOCK(FF_EST_THREADS), stream, B, e, logp, shift_dev, (double)n_global, sums4, est3, part,
+            (unsigned*)workspace);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

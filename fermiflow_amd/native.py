@@ -244,15 +244,22 @@ def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker
     return out
 
 
-def walker_order(cost):
-    """ff_walker_order: int32 permutation, most expensive walkers first (cost: int32 per-walker step counts)."""
+def walker_order(cost, hval=None):
+    """ff_walker_order: int32 permutation, most expensive walkers first (cost: int32 per-walker step counts).
+    hval (float64, B): ff_walker_order_mean -- returns (order, 1-element tensor mean(hval)) from the same two launches."""
     cost = cost.contiguous()
     if cost.dtype != torch.int32 or not cost.is_cuda:
         raise ValueError("cost must be an int32 device tensor")
     order = torch.empty_like(cost)
-    ws = torch.empty(max(1, L.lib().ff_walker_order_workspace_bytes(L.i64(cost.numel())) // 4), dtype=torch.int32, device=cost.device)
-    L.check(L.lib().ff_walker_order(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws)), "ff_walker_order")
-    return order
+    ws = torch.empty(max(1, (L.lib().ff_walker_order_workspace_bytes(L.i64(cost.numel())) + 7) // 8), dtype=torch.float64, device=cost.device)
+    if hval is None:
+        L.check(L.lib().ff_walker_order(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws)), "ff_walker_order")
+        return order
+    hval = L.dev(hval, name="hval")
+    hmean = torch.empty(1, dtype=torch.float64, device=cost.device)
+    L.check(L.lib().ff_walker_order_mean(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean)),
+            "ff_walker_order_mean")
+    return order, hmean
 
 
 def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0, out=None):
@@ -278,6 +285,26 @@ def reduce_energy(e, logp, shift_dev):
     out = torch.empty(4, dtype=torch.float64, device=e.device)
     L.check(L.lib().ff_reduce_energy(L.stream(), L.i64(e.numel()), L.ptr(e), L.ptr(logp), L.ptr(shift_dev), L.ptr(out)), "ff_reduce_energy")
     return out
+
+
+_EST_WS = {}      # (device, B) -> zero-initialised workspace of ff_energy_estimate (its counter is left at zero by every call)
+
+
+def energy_estimate(e, logp, shift_dev, n_global):
+    """ff_energy_estimate: (sums4, est3) in one launch; n_global = 0: sums4 only (est3 is None) -- all-reduce it, then energy_finish."""
+    e = L.dev(e, name="e"); logp = L.dev(logp, name="logp"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
+    B = e.numel()
+    key = (str(e.device), B)
+    ws = _EST_WS.get(key)
+    if ws is None:
+        if len(_EST_WS) > 64:
+            _EST_WS.clear()
+        ws = _EST_WS[key] = torch.zeros(L.lib().ff_energy_estimate_workspace_bytes(L.i64(B)) // 8, dtype=torch.float64, device=e.device)
+    sums = torch.empty(4, dtype=torch.float64, device=e.device)
+    est = torch.empty(3, dtype=torch.float64, device=e.device) if n_global else None
+    L.check(L.lib().ff_energy_estimate(L.stream(), L.i64(B), L.ptr(e), L.ptr(logp), L.ptr(shift_dev), L.i64(n_global), L.ptr(sums), L.ptr(est),
+                                       L.ptr(ws)), "ff_energy_estimate")
+    return sums, est
 
 
 def energy_finish(sums4, shift_dev, n_global):

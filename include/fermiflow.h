@@ -100,6 +100,9 @@ int ff_shutdown(void);
 /* order (B) = walker indices sorted by descending cost (ties in a fixed order; classes above 31 count as 31); cost (B) >= 0, e.g. ff_ode.walker_cost. */
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);
+/* ff_walker_order that also returns hmean[0] = mean of hval (B) -- the sweeps open the next flow pass with the mean step size this
+ * one accepted (ff_ode.walker_h_uniform), and the two launches of the schedule read the per-walker arrays anyway.  Fixed tree. */
+int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean);
 const char* ff_last_error(void);
 /* Kernel family of the fused CNF kernels (ff_cnf_generate, ff_cnf_delta_logp, ff_eloc_sensitivities, ff_cnf_adjoint*):
  * 0 (default) = by particle number -- one wave per walker group up to 12 particles in d = 2 / 4 in d = 3, one walker per
@@ -250,6 +253,14 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
 int ff_stream_delay(void* stream, double microseconds);
 int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4);
 int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3);
+/* The same estimator in ONE launch of many workgroups (ff_reduce_energy is a single workgroup: 19 us at 65 536 walkers): sums4 as
+ * ff_reduce_energy; with n_global > 0 -- a single rank, nothing to add from elsewhere -- est3 as ff_energy_finish as well, else
+ * (n_global = 0) the caller all-reduces sums4 and calls ff_energy_finish.  Partial sums of fixed segments, added in segment order by
+ * whichever workgroup finishes last: deterministic.  workspace: ff_energy_estimate_workspace_bytes(B) bytes that the caller zeroes
+ * ONCE before the first call; every call leaves its counter at zero again. */
+size_t ff_energy_estimate_workspace_bytes(int64_t B);
+int ff_energy_estimate(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, int64_t n_global,
+                       double* sums4, double* est3, void* workspace);
 
 /* ---- three dimensions (groundwork for a 3-D trap; no upstream counterpart: src/orbitals.py:56 and src/base_dist.py:62
  * hard-code d = 2).  Orbital index k of HO3D: list order "for n in range(8) for nx in range(n+1) for ny in range(n+1-nx):

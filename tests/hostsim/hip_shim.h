@@ -18,6 +18,7 @@
 // ---- the FF_* macros of ff_common.h / ff_ode.h / ff_cnf_adj.hip that carry an #ifndef (host forms)
 #define FF_RBLOCK(n) 4                                       // tiny reduction workgroups: thread creation is what costs here
 #define FF_OPAQUE(x) asm volatile("" : "+m"(x))              // an opaque value of any type ("+v" is a GPU register class)
+#define FF_TAB_GRID 16                                       // (radial table build: 16 x 128 host threads per call)
 #define FF_DEPR_EX 2
 #define FF_DEPR_TY 2
 #ifdef FF_HOSTSIM_TRACE      // FF_TRACE_STEPS=1 prints every accept / reject decision of ff_stepper
@@ -42,6 +43,7 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline int hipGetLastError() { return 0; }
+inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline const char* hipGetErrorString(int) { return "hostsim"; }
 inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return 0; }
 #define hipMemcpyDeviceToDevice 3

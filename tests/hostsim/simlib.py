@@ -182,12 +182,16 @@ def _ode(t0, t1, rtol, atol, steps=None, order=None):
                  float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)))
 
 
-def walker_order(cost):
+def walker_order(cost, hval=None):
     cost = _i(cost); order = np.empty_like(cost)
     lib().ff_walker_order_workspace_bytes.restype = C.c_size_t
-    ws = np.zeros(lib().ff_walker_order_workspace_bytes(C.c_int64(len(cost))) // 4, dtype=np.int32)
-    _ck(lib().ff_walker_order(None, C.c_int64(len(cost)), _p(cost), _p(order), _p(ws)))
-    return order
+    ws = np.zeros((lib().ff_walker_order_workspace_bytes(C.c_int64(len(cost))) + 7) // 8)
+    if hval is None:
+        _ck(lib().ff_walker_order(None, C.c_int64(len(cost)), _p(cost), _p(order), _p(ws)))
+        return order
+    hval = _d(hval); hm = np.empty(1)
+    _ck(lib().ff_walker_order_mean(None, C.c_int64(len(cost)), _p(cost), _p(order), _p(ws), _p(hval), _p(hm)))
+    return order, hm[0]
 
 
 def cnf_generate(z, net, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, steps=None, order=None):
@@ -232,6 +236,17 @@ def reduce_energy(e, logp, shift):
     e = _d(e); logp = _d(logp); sh = np.array([shift], dtype=np.float64); out = np.empty(4)
     _ck(lib().ff_reduce_energy(None, C.c_int64(len(e)), _p(e), _p(logp), _p(sh), _p(out)))
     return out
+
+
+def energy_estimate(e, logp, shift, n_global, ws=None):
+    """ff_energy_estimate: (sums4, est3 or None, workspace) -- pass the returned workspace to the next call (zeroed once)."""
+    e = _d(e); logp = _d(logp); sh = np.array([shift], dtype=np.float64)
+    lib().ff_energy_estimate_workspace_bytes.restype = C.c_size_t
+    if ws is None:
+        ws = np.zeros(lib().ff_energy_estimate_workspace_bytes(C.c_int64(len(e))) // 8)
+    sums = np.empty(4); est = np.empty(3) if n_global else None
+    _ck(lib().ff_energy_estimate(None, C.c_int64(len(e)), _p(e), _p(logp), _p(sh), C.c_int64(n_global), _p(sums), _p(est), _p(ws)))
+    return sums, est, ws
 
 
 def energy_finish(sums4, shift, n):

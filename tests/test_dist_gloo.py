@@ -1,5 +1,5 @@
 """world_size-2 CPU tests (gloo) of the data-parallel sweep reductions: the SAME kernels and the same call order as
-GSVMC._sweep / BetaVMC._sweep (fermiflow_amd/VMC.py) -- ff_reduce_energy -> all_reduce_sum_ -> ff_energy_finish, and
+GSVMC._sweep / BetaVMC._sweep (fermiflow_amd/VMC.py) -- ff_energy_estimate -> all_reduce_sum_ -> ff_energy_finish, and
 ff_reduce_moments + ff_beta_state_partials -> all_reduce_sum_ -> ff_beta_finish -- with the kernels' host build
 (tests/hostsim) standing in for the GPU: two ranks holding the halves of a walker batch must produce the single-process E,
 E_std, surrogate value, F, S, logits gradient and per-state baseline.  Plus rank-0 parameter / state-list authority."""
@@ -32,7 +32,8 @@ def _gs_worker(rank, world, port, eloc_all, logp_all, shift, out):
     from tests.hostsim import simlib as S
     B = len(eloc_all)
     off, cnt = D.shard(B)
-    sums = torch.from_numpy(S.reduce_energy(eloc_all[off:off + cnt], logp_all[off:off + cnt], shift))      # this rank's four sums
+    # this rank's four sums: ff_energy_estimate with n_global = 0, as GSVMC._sweep calls it when there is something to all-reduce
+    sums = torch.from_numpy(S.energy_estimate(eloc_all[off:off + cnt], logp_all[off:off + cnt], shift, 0)[0])
     D.all_reduce_sum_(sums)
     est = S.energy_finish(sums.numpy(), shift, B)                                                         # identical on every rank
     out[rank] = est

@@ -713,3 +713,26 @@ def test_wide_adjoint_far_radii_take_the_overflow_list():
     assert st[3] == 0
     np.testing.assert_allclose(gx, gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
     np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
+
+
+def test_one_launch_estimator_and_schedule_with_mean():
+    """Round-4 launch diet.  ff_energy_estimate: the four estimator sums from many workgroups, joined in segment order by the
+    workgroup that finishes last, and -- single rank -- E, the centred sum of squares and the surrogate in the same launch: equal
+    to ff_reduce_energy + ff_energy_finish; the workspace counter is back at zero after every call (ragged and tiny batches too).
+    ff_walker_order_mean: the cost-ordered schedule plus the mean of a per-walker array from the same two launches."""
+    rng = np.random.default_rng(3)
+    for B in (1, 5, 1024, 1025, 5000):
+        e = rng.normal(size=B) * 7 + 30; lp = rng.normal(size=B) * 3 - 20
+        for shift in (0.0, 29.5, float("nan")):
+            want = S.reduce_energy(e, lp, shift)
+            sums, est, ws = S.energy_estimate(e, lp, shift, B)
+            np.testing.assert_allclose(sums, want, rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(est, S.energy_finish(want, shift, B), rtol=1e-12, atol=1e-9)
+            assert ws.view(np.uint32)[0] == 0
+            sums2, est2, _ = S.energy_estimate(e, lp, shift, 0, ws=ws)            # second call on the same workspace, sums only
+            assert (sums2 == sums).all() and est2 is None
+        assert abs(est[0] - e.mean()) < 1e-12 * abs(e.mean()) and abs(est[1] - ((e - e.mean()) ** 2).sum()) < 1e-9 * B
+    for B in (7, 2048, 4100):
+        cost = rng.integers(0, 40, size=B).astype(np.int32); h = rng.random(B)
+        order, hm = S.walker_order(cost, hval=h)
+        assert (order == S.walker_order(cost)).all() and abs(hm - h.mean()) < 1e-14
