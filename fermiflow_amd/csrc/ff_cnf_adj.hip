@@ -221,6 +221,9 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
 #ifndef FF_ADJ_WPS
 #define FF_ADJ_WPS 1     // waves per SIMD the tabulated adjoint is compiled for (A/B knob: tools/probes/adj_ab.py)
 #endif
+#ifndef FF_ADJ_WPW
+#define FF_ADJ_WPW 2     // waves per workgroup of the tabulated adjoint (1: the single-wave workgroups of rounds 1-3)
+#endif
 // Walkers per wave of the tabulated adjoint.  The forward kernels pack 64 / M walkers into a wave; here every lane also
 // carries the six stage records of its radii, and at 6 particles (5 walkers x 21 radii = 105 radii: two per lane) that
 // put the kernel at 360 registers.  With THREE walkers (63 radii: one per lane) it takes 292 and is exactly as fast
@@ -233,8 +236,16 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
 template <int N, int D> struct ff_adjtab_geom { static constexpr int G = (N * D == 12) ? FF_ADJ_G12 : ff_geom<N, D>::G; };
 static int adj_tab_G(int n, int d) { return n * d == 12 ? FF_ADJ_G12 : (n * d > 0 && n * d <= FF_WAVE ? (FF_WAVE / (n * d) > 16 ? 16 : FF_WAVE / (n * d)) : 0); }
 
-template <int N, int D>
-__global__ void __launch_bounds__(FF_WAVE, FF_ADJ_WPS)
+// WPW waves per workgroup.  A wave at 290 registers and 33 KB of LDS (27 KB of it the deposit table) is alone on its SIMD, and
+// every phase of its right-hand side -- radial-table fetch, LDS round trips, dependent fp64 issue -- is exposed: 5 100 cycles per
+// evaluation of three walkers (round 4 measurement, s_memtime; without deposits 0.555 ms per launch at one wave per SIMD, 0.404 at
+// two).  With WPW = 2 the two waves of a workgroup integrate their OWN walker groups independently -- no workgroup barrier inside
+// the loop, only wave-level LDS ordering (FF_WAVE_SYNC) -- and SHARE the workgroup's deposit table: four workgroups per CU are
+// then eight waves.  Floating-point LDS atomics of two waves in an arbitrary order would cost the bit-reproducibility of the
+// gradient, so deposits take turns: wave v performs its k-th deposit phase when the ticket counter reads 2 k + v (or the other
+// wave has finished), i.e. A0 B0 A1 B1 ... -- a fixed order whatever the timing; the right-hand sides in between overlap freely.
+template <int N, int D, int WPW>
+__global__ void __launch_bounds__(FF_WAVE * WPW, WPW > 1 ? WPW : FF_ADJ_WPS)
 ff_ode_adjtab_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = ff_adjtab_geom<N, D>::G, P = Gm::P, R = Gm::RA;
@@ -242,25 +253,29 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
 
-  __shared__ double s_z[G][M], s_kb[G][M], s_err[G][M], s_ad[G], s_hw[G];
+  __shared__ double s_z_[WPW][G][M], s_kb_[WPW][G][M], s_err_[WPW][G][M], s_ad_[WPW][G], s_hw_[WPW][G];
   // T[g][a][j][3][D]: what partner j (j = a: the one-body term) contributes to particle a's rows of v, Dv^T[lambda] and
   // grad div -- written by the radius lanes, summed by the component lanes (row padded against bank conflicts)
   constexpr int TROW = N * 3 * D + 1;
-  __shared__ double s_T[G][N][TROW];
+  __shared__ double s_T_[WPW][G][N][TROW];
   __shared__ double s_W[2][FF_DEP_NLDS][FF_DEP_LROW];
-  __shared__ int s_pa[R], s_pb[R], s_any;
+  __shared__ int s_pa[R], s_pb[R], s_any_[WPW];
+  __shared__ int s_turn, s_done[2];
 
-  const int lane = threadIdx.x;
+  const int wv = WPW > 1 ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & (FF_WAVE - 1);
+  auto& s_z = s_z_[wv]; auto& s_kb = s_kb_[wv]; auto& s_err = s_err_[wv]; auto& s_ad = s_ad_[wv]; auto& s_hw = s_hw_[wv];
+  auto& s_T = s_T_[wv]; int& s_any = s_any_[wv];
   const int g = lane / M, i = lane % M;
   const bool ingrp = g < G;
   const int gg = ingrp ? g : 0;
   const int ai = i / D, ci = i % D;
-  for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += FF_WAVE) (&s_W[0][0][0])[e] = 0.0;
-  if (lane == 0) {
+  for (int e = threadIdx.x; e < 2 * FF_DEP_NLDS * FF_DEP_LROW; e += FF_WAVE * WPW) (&s_W[0][0][0])[e] = 0.0;
+  if (threadIdx.x == 0) {
     int p = 0;
     for (int a = 0; a < N; a++)
       for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
     for (int a = 0; a < N; a++) { if (P + a < R) { s_pa[P + a] = a; s_pb[P + a] = -1; } }
+    s_turn = 0; s_done[0] = 0; s_done[1] = 0;
   }
   __syncthreads();
   const int He = A.net.He, Hm = A.net.Hm;
@@ -283,12 +298,13 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   const int64_t ngroups = (A.B + G - 1) / G;
   __shared__ int s_st[4];   // ODE statistics of this workgroup's walkers (LDS: nothing loop-carried in registers)
   if (threadIdx.x < 4) s_st[threadIdx.x] = 0;
+  int my_turn = wv;         // ticket of this wave's next deposit phase: wv, wv + 2, ...
   double* const ovf = A.trows + (size_t)gridDim.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;   // Wtot region: [2][NTOT][ROW]
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int64_t grp = (int64_t)blockIdx.x * WPW + wv; grp < ngroups; grp += (int64_t)gridDim.x * WPW) {
     const int64_t bq = grp * G + g;
     const bool valid = ingrp && bq < A.B;
     const int64_t b = ff_opt_load(A.order, valid, bq, A.z_in, (int32_t)bq);
@@ -316,11 +332,11 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
 
     auto group_sum = [&](double part) -> double {
       if (ingrp) s_err[g][i] = part;
-      __syncthreads();
+      FF_WAVE_SYNC();
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < M; j++) t += s_err[gg][j];
-      __syncthreads();
+      FF_WAVE_SYNC();
       return t;
     };
 
@@ -372,9 +388,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
       }
       FF_STAMP(0);
-      __syncthreads();
+      FF_WAVE_SYNC();
       if (ingrp) { s_z[g][i] = in[0]; s_kb[g][i] = in[1]; }
-      __syncthreads();
+      FF_WAVE_SYNC();
       FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase (lane <-> radius)
       ff_rec cur[NSLOT];
@@ -435,7 +451,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           }
         }
       }
-      __syncthreads();
+      FF_WAVE_SYNC();
       nev++;
       FF_STAMP(2);
       // ------------------------------------------------------------------ component phase: sum the own rows
@@ -472,7 +488,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         h0v = S.h0(d0, d1v);
         s = -1;
         // every walker of the wave brings its own first step: no probe evaluation
-        if (!ff_wave_or(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
+        if (!ff_wave_or_w(&s_any, lane, (!S.done && !warm) ? 1 : 0)) {
           S.habs = fmin(hwarm, S.interval);
           S.plan();
           s = 1;
@@ -543,7 +559,15 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
         // step size of every walker whose step was accepted (0 otherwise), for the lanes that hold its radii
         if (ingrp && i == 0) s_hw[g] = acc ? h : 0.0;
-        __syncthreads();
+        FF_WAVE_SYNC();
+#ifndef FF_ADJ_NOTICKET      // (timing experiments only: without the turns the sum order, hence the last bits, depend on timing)
+        if constexpr (WPW > 1) {      // this wave's turn at the shared table (A0 B0 A1 B1 ...; a finished partner waives its turns)
+          while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn &&
+                 !__hip_atomic_load(&s_done[1 - wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+            __builtin_amdgcn_s_sleep(1);
+          FF_WAVE_SYNC();
+        }
+#endif
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) {
           if (rq_id[sl] >= 0) {
@@ -556,8 +580,13 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }
         }
+        if constexpr (WPW > 1) {      // deposits landed (lgkmcnt(0)): hand the table on
+          FF_WAVE_SYNC();
+          if (lane == 0) __hip_atomic_store(&s_turn, my_turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          my_turn += 2;
+        }
         S.plan();
-        const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
+        const int any = ff_wave_or_w(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
@@ -573,17 +602,22 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
-    __syncthreads();
+    FF_WAVE_SYNC();
   }
 #ifdef FF_STAMPS
   if (A.stats && lane == 0)
     for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
 #endif
   if (off_any) *A.off_table = 1.0;
+  if constexpr (WPW > 1) {
+    FF_WAVE_SYNC();
+    if (lane == 0) __hip_atomic_store(&s_done[wv], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();      // (the one workgroup barrier: every wave has made its last deposit)
   // flush the workgroup-private coefficient table
   {
     double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    for (int e = lane; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
+    for (int e = threadIdx.x; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE * WPW) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
   }
   __syncthreads();
   if (A.stats && threadIdx.x == 0 && (s_st[0] || s_st[3])) {
@@ -750,7 +784,7 @@ static size_t adj_ws_doubles(bool wide, int64_t B, int n, int d, int He, int Hm)
   if (wide) return ff_wide_supported(n, d) ? adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1 : 0;
   const bool narrow = (d == 2 && n >= 1 && n <= 12) || (d == 3 && n >= 2 && n <= 4);
   const int G = adj_G(n, d);
-  return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d)) + 1 : 0;
+  return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d) * FF_ADJ_WPW) + 1 : 0;
 }
 
 // The larger of the two families' layouts: which family a call uses is decided when it runs (ff_set_kernel_family / FF_WIDE may
@@ -805,7 +839,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     const int Gq = wide ? 1 : adj_G(n, d);
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
-    a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d));
+    a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);
   }
   if (hipMemsetAsync(workspace, 0, sizeof(double) * adj_ws_doubles(wide, B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
   int G = 0;
@@ -820,7 +854,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   } else
   // both variants are enqueued; on the device exactly one of them runs, chosen by the radial-table header
   // (no table / weights too stiff for the deposit grid -> direct evaluation), so the host never has to look at it
-#define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_>), adj_grid(a.B, ff_adjtab_geom<N_, D_>::G), FF_WAVE, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
+#define FF_ND(N_, D_) if (n == N_ && d == D_) { if (net->radial_table) FF_LAUNCH((ff_ode_adjtab_kernel<N_, D_, FF_ADJ_WPW>), adj_grid(a.B, ff_adjtab_geom<N_, D_>::G * FF_ADJ_WPW), FF_WAVE * FF_ADJ_WPW, stream, a); launch_adj<N_, D_>(stream, a); G = ff_geom<N_, D_>::G; }
   FF_ND(6, 2) else FF_ND(3, 2) else FF_ND(12, 2) else FF_ND(2, 2) else FF_ND(4, 2) else FF_ND(5, 2) else FF_ND(8, 2) else FF_ND(10, 2)
   else FF_ND(1, 2) else FF_ND(7, 2) else FF_ND(9, 2) else FF_ND(11, 2) else FF_ND(2, 3) else FF_ND(3, 3) else FF_ND(4, 3)
 #undef FF_ND
@@ -833,7 +867,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk * G, P, (const double*)a.rows, grad_params);
   FF_LAUNCH_CHECK();
   if (net->radial_table) {
-    const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d));     // workgroups (= private tables) of the tabulated kernel
+    const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);     // workgroups (= private tables) of the tabulated kernel
     double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_EX - 1) / FF_DEPR_EX), FF_DEPR_EX * FF_DEPR_TY, stream, *net,
               (const double*)a.off_table, ntab, (const double*)a.trows, wtot);

@@ -32,6 +32,18 @@
 #define FF_DYN_LDS(name) extern __shared__ double name[]
 #endif
 
+// Barrier among the lanes of ONE wave, for workgroups whose waves run independently of each other (the two-wave tabulated
+// adjoint): LDS operations of a wave execute in program order, so all it takes is that the compiler keeps them in order and
+// that they have completed -- a workgroup-scope fence (s_waitcnt), no s_barrier.  In a single-wave workgroup this is
+// __syncthreads().
+#ifndef FF_WAVE_SYNC
+#define FF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#endif
+#ifndef FF_HAVE_WAVE_BALLOT
+#define ff_wave_ballot(pred) __ballot(pred)      // (on the GPU a ballot IS per wave; the host simulator's needs to know which wave)
+#endif
+
 // a value the program knows to be wave-uniform -> scalar register (lets loops on it be scalar loops)
 #define FF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 

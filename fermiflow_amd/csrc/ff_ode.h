@@ -161,6 +161,12 @@ FF_D int ff_wave_or(int* s_any, int lane, int flags) {
   return (b1 ? 1 : 0) | (b2 ? 2 : 0);
 }
 
+// the same for workgroups whose waves do not run in lockstep (ff_wave_ballot: the caller's own wave)
+FF_D int ff_wave_or_w(int* s_any, int lane, int flags) {
+  const unsigned long long b1 = ff_wave_ballot((flags & 1) != 0), b2 = ff_wave_ballot((flags & 2) != 0);
+  return (b1 ? 1 : 0) | (b2 ? 2 : 0);
+}
+
 #ifndef FF_STEP_TRACE
 #define FF_STEP_TRACE(t, h, err, acc) do { } while (0)
 #endif

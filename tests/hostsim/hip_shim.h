@@ -28,6 +28,9 @@
 struct ff_sim_dim3 { unsigned x = 1, y = 1, z = 1; };
 inline thread_local ff_sim_dim3 threadIdx, blockIdx, blockDim, gridDim;
 inline pthread_barrier_t* ff_sim_bar = nullptr;
+// workgroups of several INDEPENDENT waves (the two-wave tabulated adjoint): one barrier per wave of 64 "lanes"
+inline pthread_barrier_t ff_sim_wave_bar[16];
+#define FF_WAVE_SYNC() pthread_barrier_wait(&ff_sim_wave_bar[threadIdx.x >> 6])
 
 #define __global__
 #define __device__
@@ -44,6 +47,9 @@ typedef int hipError_t;
 #define hipSuccess 0
 inline int hipGetLastError() { return 0; }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+template <class T> inline T __hip_atomic_load(T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+template <class T, class V> inline void __hip_atomic_store(T* p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 inline const char* hipGetErrorString(int) { return "hostsim"; }
 inline int hipMemsetAsync(void* p, int v, size_t n, void*) { memset(p, v, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
@@ -130,6 +136,18 @@ inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
 }
 // wave vote (the kernels only ask whether any lane of a single-wave workgroup voted yes)
 static std::atomic<int> ff_sim_vote{0};
+// the same vote among the 64 lanes of the caller's own wave only (waves of a workgroup that do not run in lockstep)
+static std::atomic<int> ff_sim_wave_vote[16];
+inline unsigned long long ff_wave_ballot(bool pred) {
+  const unsigned w = threadIdx.x >> 6;
+  FF_WAVE_SYNC();
+  if ((threadIdx.x & 63) == 0) ff_sim_wave_vote[w].store(0);
+  FF_WAVE_SYNC();
+  if (pred) ff_sim_wave_vote[w].fetch_or(1);
+  FF_WAVE_SYNC();
+  return (unsigned long long)ff_sim_wave_vote[w].load();
+}
+#define FF_HAVE_WAVE_BALLOT
 inline unsigned long long __ballot(bool pred) {
   __syncthreads();
   if (threadIdx.x == 0) ff_sim_vote.store(0);
@@ -191,6 +209,8 @@ inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
   pthread_barrier_t bar;
   pthread_barrier_init(&bar, nullptr, block);
   ff_sim_bar = &bar;
+  const unsigned nwave = (block + 63) / 64;
+  for (unsigned w = 0; w < nwave && w < 16; w++) pthread_barrier_init(&ff_sim_wave_bar[w], nullptr, (block - 64 * w) < 64 ? (block - 64 * w) : 64);
   for (unsigned b = 0; b < grid; b++) {
     std::vector<std::thread> th;
     th.reserve(block);
@@ -202,6 +222,7 @@ inline void ff_sim_launch(K kernel, unsigned grid, unsigned block, A... args) {
     for (auto& x : th) x.join();
   }
   pthread_barrier_destroy(&bar);
+  for (unsigned w = 0; w < nwave && w < 16; w++) pthread_barrier_destroy(&ff_sim_wave_bar[w]);
   ff_sim_bar = nullptr;
 }
 #define FF_LAUNCH(kernel, grid, block, stream, ...) ff_sim_launch(kernel, (unsigned)(grid), (unsigned)(block), __VA_ARGS__)
