@@ -105,9 +105,12 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES"))
 
 
-def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
+def pmc_counters(kernel_substr, argv, passes=PMC_PASSES, child_args=("--steps", "2", "--warmup", "1", "--no-extras")):
     """Per-launch averages of hardware counters of one kernel, from `rocprofv3 --pmc` child passes of this script (counters
-    in their own runs, no tracing; --steps 2 --no-extras).  Returns (dict counter -> value per launch, None) or (None, reason)."""
+    in their own runs, no tracing; --steps 2 --no-extras).  Returns (dict counter -> value per launch, None) or (None, reason).
+    kernel_substr may be a tuple: the counters of all those kernels are added up and divided by the launches of the FIRST one
+    (a pass that runs as several kernels side by side: the routed local-energy pass)."""
+    names = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     import csv
     import glob
     import shutil
@@ -121,7 +124,7 @@ def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
         d = tempfile.mkdtemp(prefix="ffpmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
         cmd = [exe, "--pmc"] + list(ctrs) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + \
-              ["--steps", "2", "--warmup", "1", "--no-extras"]
+              list(child_args)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
         except Exception as e:      # noqa: BLE001
@@ -133,14 +136,15 @@ def pmc_counters(kernel_substr, argv, passes=PMC_PASSES):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 c = row["Counter_Name"]
-                if kernel_substr in row["Kernel_Name"] and c in tot:
-                    tot[c] += float(row["Counter_Value"]); cnt[c] += 1
+                if c in tot and any(nm in row["Kernel_Name"] for nm in names):
+                    tot[c] += float(row["Counter_Value"])
+                    cnt[c] += 1 if names[0] in row["Kernel_Name"] else 0
         shutil.rmtree(d, ignore_errors=True)
         for c in ctrs:
             if cnt[c]:
                 out[c] = tot[c] / cnt[c]
         if ctrs[0] in ("FETCH_SIZE", "WRITE_SIZE") and ctrs[0] not in out:
-            return None, f"kernel {kernel_substr} not in the {ctrs[0]} pass"
+            return None, f"kernel {names[0]} not in the {ctrs[0]} pass"
     return out, None
 
 
@@ -169,6 +173,8 @@ def main():
     ap.add_argument("--cpu-walkers", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone kernel legs, the PMC passes and the CPU baseline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--standalone-leg", action="store_true",
+                    help="(child passes) run only the stand-alone HBM-bound kernels -- parity-mode Metropolis sweep, potential -- three times and exit")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -234,6 +240,16 @@ def main():
         B_glob = wpg * n_gpus
     torch.manual_seed(1234)      # same Philox key on every rank; streams are separated by the global walker index
 
+    if args.standalone_leg:      # what roofline_hbm / roofline_pairwise time, for the counter passes (rocprofv3 --pmc -- bench.py --standalone-leg)
+        tu_, td_ = model._tables(dev)
+        g0, g, u = native.rng_fill(wpg, n, 100, 7, dev)
+        xp = torch.randn(16 * wpg, n, 2, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            native.mcmc_sample_noise(tu_, td_, nup, ndown, g0, g, u)
+            native.potential(xp, args.Z, True)
+        torch.cuda.synchronize()
+        return
+
     def step():
         g = model(B_glob)
         opt.zero_grad()
@@ -267,6 +283,44 @@ def main():
     w_head = (tuple(t.detach().cpu().numpy().copy() for t in (_v.eta.fc1.weight, _v.eta.fc1.bias, _v.eta.fc2.weight)),
               tuple(t.detach().cpu().numpy().copy() for t in (_v.mu.fc1.weight, _v.mu.fc1.bias, _v.mu.fc2.weight)))
     beta_head = (model.F, model.F_std, model.S) if wl == "beta" else None
+
+    # ---- reference-semantics leg (VERDICT r03 next #3c): one tolerance for every component of every walker (sens_tol = 1), no
+    #      routing by cost class (heavy_class < 0), Hairer's cold start for all three integrations -- what the policy in
+    #      config.workload buys, and what it costs in accuracy: max E_loc error of both against a 1e-11 solve on the same base walkers
+    ref_leg = None
+    if wl == "gsvmc" and not args.no_extras:
+        def eloc_error(z):
+            g_ = model.forward_from(z, batch=B_glob)
+            x_, e_ = model.x, model.Eloc.clone()
+            tu_, td_ = model._tables(dev)
+            tight = native.eloc(tu_, td_, nup, ndown, gs.cnf.v_wrapper.v.net(), x_, 0.0, 1.0, 1e-11, 1e-13, args.Z, True)["eloc"]
+            del g_
+            return ((e_ - tight).abs() / tight.abs()).max().item()
+        with torch.no_grad():
+            zr = model.basedist.sample(model.orbitals_up, model.orbitals_down, (wpg,))
+        err_policy = eloc_error(zr)
+        saved = (model.sens_tol, model.heavy_class, model.warm_start)
+        model.sens_tol, model.heavy_class, model.warm_start = 1.0, -1, False
+        err_ref = eloc_error(zr)
+        kr = max(2, args.steps // 2)
+        for _ in range(3):
+            step()
+        model.profile = {}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(kr):
+            step()
+        fence()
+        dtr = time.perf_counter() - t0
+        pr, model.profile = model.profile, None
+        model.sens_tol, model.heavy_class, model.warm_start = saved
+        ref_leg = {"policy": "sens_tol = 1 (one tolerance for every component), no routing by cost class, cold (Hairer) start of every integration",
+                   "steps": kr, "ms_per_step": dtr / kr * 1e3, "value": B_glob * 100 * kr / dtr,
+                   "rhs_evals_per_walker": sum(int(st_[0].item()) for st_ in pr["eloc_stats"]) / kr / wpg,
+                   "eloc_max_rel_err_vs_1e-11_solve": err_ref, "headline_policy_eloc_max_rel_err": err_policy,
+                   "bar": 1e-5}
+        for _ in range(2):
+            step()      # (the warm-start state of the headline policy again, before the next leg)
 
     # ---- second leg: the same measurement on a flow that has been trained for a while (the headline's weights are held in
     #      place by the tiny learning rate: its ODE step counts are the best case)
@@ -334,7 +388,14 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / wpg,
                 "flop_per_walker_eval": flop_per_eval, "radial_functions": radial,
-                "algorithmic_bytes": wpg * 8 * (M + M * M + 4 * M + 1)}
+                # with the fused finish (matrix-core kernel, nup = ndown) J^T stays on chip: x in; z, grad, grad_z logp0 and five scalars out
+                "algorithmic_bytes": wpg * 8 * ((4 * M + 5) if (kind == "mfma" and nup == ndown) else (M + M * M + 4 * M + 1))}
+    # every kernel of the pass between the two events (routing: the heavy walkers' kernel and their two finish kernels run beside /
+    # in the shadow of the throughput kernel): their counters are added up
+    pass_kernels = [kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0]]
+    if kind in ("mfma", "columns") and dim == 2 and n <= 6 and model.heavy_class >= 0 and model.sens_tol > 1.0 and radial == "table":
+        pass_kernels += ["ff_wide_eloc_kernel<2, 1, true, double>"] + (["ff_eloc_slater_fixed_kernel", "ff_eloc_contract_kernel"] if (kind == "mfma" and nup == ndown) else [])
+    roofline["kernels_of_the_pass"] = pass_kernels
 
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",
            "value": B_glob * 100 * args.steps / dt, "unit": "walker-steps/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -352,6 +413,8 @@ def main():
            "E": E_head, "E_std": Estd_head, "stages_ms": stages, "roofline": roofline}
     if trained is not None:
         out["trained_leg"] = trained
+    if ref_leg is not None:
+        out["reference_semantics_leg"] = ref_leg
     if wl == "beta":
         out.update(F=beta_head[0], F_std=beta_head[1], S=beta_head[2])
 
@@ -387,20 +450,26 @@ def main():
             flop_adj = R * FLOP_ADJ_RADIUS + M * FLOP_ADJ_LANE
             a_adj = adj_evals * flop_adj / (ms_adj * 1e-3) / 1e12
             out["roofline_adjoint"] = {
-                "kernel": f"ff_ode_adjtab_kernel<{n}, 2> + deposit reduce/contract (theta-gradient adjoint, whole ff_cnf_adjoint call)",
+                "kernel": f"ff_ode_adjtab_kernel<{n}, 2, 2> + deposit reduce/contract (theta-gradient adjoint, whole ff_cnf_adjoint call)",
                 "bound": "fp64-valu", "achieved": a_adj, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_adj / PEAK_FP64_TFLOPS,
                 "avg_launch_ms": ms_adj, "rhs_evals_per_walker": adj_evals / wpg, "flop_per_walker_eval": flop_adj,
-                "note": "instruction-issue and LDS-atomic bound: per accepted step 5 records per radius go into the deposit table"}
-            flop_mc = n * FLOP_MCMC_STEP_PER_PARTICLE
+                "note": "LDS-atomic and latency bound: two independent waves per workgroup share the deposit table (ticketed deposits); per "
+                        "accepted step 5 records per radius go into it -- a third of the kernel (0.38 ms without deposits)"}
+            ratio_kernel = (nup == ndown and 1 <= nup <= 6) or (ndown == 0 and 2 <= nup <= 6)
+            # the determinant-ratio kernels (round 4) do less than the reference's step: no exp per particle, no log per determinant
+            # -- priced at what they execute: proposal 4 n, r^2 sums 4 n, polynomial rows ~5 n, determinants ~n_s^3,
+            # one exp (~30), fp32 Box-Muller 12 per pair of normals
+            flop_mc = (n * FLOP_MCMC_STEP_PER_PARTICLE) if not ratio_kernel else (4 * n + 4 * n + 5 * n + 2 * max(nup, ndown) ** 3 + 60 + 12 * n)
             a_mc = wpg * 100 * flop_mc / (ms_mc * 1e-3) / 1e12
             out["roofline_mcmc"] = {
-                "kernel": (f"ff_mcmc_spin_kernel<{nup}, false>" if nup == ndown and 1 <= nup <= 6 and wl != "beta" else f"ff_mcmc_kernel<{nup}, {ndown}, false>") +
-                          " (Philox + Box-Muller on chip, the production sampler)",
+                "kernel": (f"ff_mcmc_spin_philox_kernel<{nup}>" if nup == ndown and 1 <= nup <= 6 else
+                           (f"ff_mcmc_pair_kernel<{nup}, false>" if ratio_kernel else f"ff_mcmc_kernel<{nup}, {ndown}, false>")) +
+                          " (Philox + fp32 Box-Muller on chip, determinant-ratio accept test: the production sampler)",
                 "bound": "fp64-valu", "achieved": a_mc, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_mc / PEAK_FP64_TFLOPS,
                 "avg_launch_ms": ms_mc, "walker_steps_per_s": wpg * 100 / (ms_mc * 1e-3), "flop_per_walker_step": flop_mc,
                 "hbm_bytes_per_walker": 2 * (8 * M + 8),
-                "note": "instruction-issue bound (integer Philox rounds, log / sincos of Box-Muller, serial LU chain); HBM sees 208 B per "
-                        "walker per SWEEP, i.e. nothing"}
+                "note": "instruction-issue bound, half of the instructions are the generator's integer rounds (two Philox4x32-10 blocks per lane "
+                        "and step); HBM sees 208 B per walker per SWEEP, i.e. nothing"}
         if wl == "gsvmc":
             # ---- the HBM-bound kernel of the path: parity-mode Metropolis sweep (noise streamed from HBM)
             S = 100
@@ -410,7 +479,7 @@ def main():
             del g0, g, u
             out["roofline_hbm"] = {"kernel": (f"ff_mcmc_spin_kernel<{nup}, true>" if nup == ndown and 1 <= nup <= 6 else f"ff_mcmc_kernel<{nup}, {ndown}, true>") + " (parity mode: explicit noise)",
                                    "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
+                                   "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes": nbytes, "avg_launch_ms": ms,
                                    "walker_steps_per_s": wpg * S / (ms * 1e-3)}
             # ---- the stand-alone pairwise kernels (potentials.py / equivariant_funs.py entry points; inside the sweep these
             #      terms are fused into the ODE kernels): Coulomb + trap energy is HBM-bound, backflow v + div is fp64-bound
@@ -425,19 +494,34 @@ def main():
             out["roofline_pairwise"] = {
                 "potential": {"kernel": "ff_potential_stream_kernel (HO + Coulomb pairs)", "bound": "hbm", "walkers": Bp, "avg_launch_ms": ms_p,
                               "achieved": bytes_p / (ms_p * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": bytes_p / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                              "frac": bytes_p / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes": bytes_p},
                 "backflow": {"kernel": "ff_backflow_kernel (v and div v, direct sigmoids)", "bound": "fp64-valu", "walkers": wpg,
                              "avg_launch_ms": ms_b, "achieved": flop_b / (ms_b * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS,
                              "unit": "TFLOP/s", "frac": flop_b / (ms_b * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
                              "note": "fp64 VALU (exp/rcp chains); no MFMA: 1->H->1 layers"}}
             del xp
+            # counters of the two HBM-bound kernels (north star: "rocprof must show achieved HBM GB/s on the pairwise kernel"):
+            # FETCH_SIZE / WRITE_SIZE passes of `bench.py --standalone-leg`, bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950)
+            if not args.no_pmc and os.environ.get("FF_BENCH_CHILD") != "1":
+                os.environ["FF_BENCH_CHILD"] = "1"
+                argv0 = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--nup", str(nup), "--ndown", str(ndown)]
+                for tgt, kn, ms_k in ((out["roofline_hbm"], out["roofline_hbm"]["kernel"].split(" (")[0], ms),
+                                      (out["roofline_pairwise"]["potential"], "ff_potential_stream_kernel", ms_p)):
+                    ctr, why = pmc_counters(kn, argv0, passes=(("FETCH_SIZE",), ("WRITE_SIZE",)), child_args=("--standalone-leg",))
+                    if ctr is None:
+                        tgt["traffic_source"] = f"unavailable: {why}"
+                    else:
+                        tgt["traffic"] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
+                        tgt["hbm_GBs_from_counters"] = tgt["traffic"] / (ms_k * 1e-3) / 1e9
+                        tgt["traffic_source"] = "rocprofv3 --pmc child passes (bench.py --standalone-leg): bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950)"
+                del os.environ["FF_BENCH_CHILD"]
         # ---- counters of the dominant kernel, measured now: rocprofv3 --pmc child passes of this script (HBM bytes = 2 x FETCH_SIZE
         #      + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md; then the issue / wait / LDS / matrix-core counters)
         if not args.no_pmc and os.environ.get("FF_BENCH_CHILD") != "1":
             os.environ["FF_BENCH_CHILD"] = "1"
             argv = ["--workload", wl, "--walkers-per-gpu", str(wpg), "--Z", str(args.Z), "--lr", str(args.lr), "--nup", str(nup),
                     "--ndown", str(ndown), "--sens-bits", str(sens_bits)]
-            ctr, why = pmc_counters(kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0], argv)
+            ctr, why = pmc_counters(tuple(pass_kernels), argv)
             if ctr is None:
                 roofline["traffic_source"] = f"unavailable: {why}"
             else:

@@ -168,11 +168,23 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       grp = s_next;
     }
     if (grp >= ngroups) break;
-    const int64_t bq = grp * G + w;
-    const bool inb = bq < A.B;
-    const int64_t b = ff_opt_load(A.order, inb, bq, A.y_in, (int32_t)bq);
-    // routing by cost class (launch_mfma): with heavy_mode = 2 the walkers of class >= heavy_class belong to another launch
-    const bool valid = inb && !(A.heavy_mode == 2 && ff_opt_load(A.wclass, inb, b, A.y_in, (int32_t)0) >= A.heavy_class);
+    // which walker this lane serves: derived from the (scalar) group index wherever it is needed -- here and again behind the
+    // evaluation loop -- so that no per-lane copy of it is live through the loop (at 256 registers such values are spilled around it:
+    // with the fused finish the scratch traffic of ~50 of them showed as 120 MB of HBM writes per launch)
+    auto walker_of = [&](int wq, int64_t& bw, bool& vw) {
+      const int64_t bq = grp * G + wq;
+      const bool inb = bq < A.B;
+      bw = ff_opt_load(A.order, inb, bq, A.y_in, (int32_t)bq);
+      // routing by cost class (launch_mfma): with heavy_mode = 2 the walkers of class >= heavy_class belong to another launch
+      vw = inb && !(A.heavy_mode == 2 && ff_opt_load(A.wclass, inb, bw, A.y_in, (int32_t)0) >= A.heavy_class);
+    };
+    int lgp = lane;
+    FF_OPAQUE(lgp);
+    const int r = lgp >> 4, w = (lgp >> 2) & 3, c = lgp & 3, p = 4 * r + c;
+    const bool owner = p < M;
+    int64_t b;
+    bool valid;
+    walker_of(w, b, valid);
     // Dormand-Prince storage as in ff_ode_fwd_kernel: y, c0..c2 (k0..k2, then the inputs of stages 4, 5 and y_new), c3 (error)
     double c0[NV], c1[NV], c2[NV];
     ff_jsplit_vec<NB, 3> y(&s_cv[0][0], lane), c3(&s_cv[NB][0], lane);
@@ -552,6 +564,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         FF_OPAQUE(ln);
         const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c, tl = 16 * c + 4 * w + r;
         const bool owner = p < M;
+        int64_t b;
+        bool valid;
+        walker_of(w, b, valid);
         {   // S = J J^T of the final J -> s_A[w]
           double Jt[NB];
 #pragma unroll
@@ -737,7 +752,15 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       }
     }
     // ---------------------------------------------------------------------- results
-    if (valid && !fin_done) {
+    if (!fin_done) {
+     int ln = lane;
+     FF_OPAQUE(ln);
+     const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c;
+     const bool owner = p < M;
+     int64_t b;
+     bool valid;
+     walker_of(w, b, valid);
+     if (valid) {
       ctl_t C; C.get(s_ctl[w]);
       const ff_stepper& S = C.S;
       const double hmax_acc = C.hmax_acc, hwarm = C.hwarm;
@@ -762,6 +785,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
       }
+     }
     }
     __syncthreads();
   }

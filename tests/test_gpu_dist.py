@@ -159,3 +159,20 @@ def test_bench_gpus_2_refuses_a_one_gpu_box_and_runs_two_ranks_over_gloo():
     rc3, weak, err3 = _bench(["--gpus", "2"] + common, {"FF_BENCH_BACKEND": "gloo"})
     assert rc3 == 0, err3[-2000:]
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["global_walkers"] == 8192
+
+
+def test_eight_ranks_strong_scaling_dry_run():
+    """the first 8-GPU run should be boring.  bench.py --gpus 8 --scaling strong at the headline's global
+    batch (65 536 walkers, 8 192 per rank) with eight gloo ranks sharing the one GPU of the test box: the self-launch path, the
+    shard arithmetic, both estimator all-reduces and the rank-0 parameter sync at the real width -- E and E_std must equal the
+    one-rank values to reduction-order noise (the walkers are the same: Philox counters are global walker indices)."""
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("written for a one-GPU box (the driver measures the real curve)")
+    common = ["--steps", "2", "--warmup", "1", "--no-extras", "--walkers-per-gpu", "65536"]
+    rc1, one, err1 = _bench(["--gpus", "1"] + common)
+    assert rc1 == 0, err1[-2000:]
+    rc8, eight, err8 = _bench(["--gpus", "8", "--scaling", "strong"] + common, {"FF_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert rc8 == 0, err8[-2000:]
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_walkers"] == 65536
+    assert abs(eight["E"] - one["E"]) < 1e-12 * abs(one["E"]), (eight["E"], one["E"])
+    assert abs(eight["E_std"] - one["E_std"]) < 1e-10 * one["E_std"]

@@ -21,6 +21,6 @@ open("/tmp/ff_kernel_usage.hip", "w").write(head + inst)
 PY
 extra=()
 for a in "$@"; do case "$a" in -*) extra+=("$a");; esac; done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast --cuda-device-only -I"$csrc" "${extra[@]}" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -mllvm -disable-machine-licm --cuda-device-only -I"$csrc" "${extra[@]}" \
   -c /tmp/ff_kernel_usage.hip -o /tmp/ff_kernel_usage.o -Rpass-analysis=kernel-resource-usage 2>&1 \
   | grep -E "VGPRs:|AGPRs|Scratch|LDS Size|Occupancy" | sed 's/.*remark: [^ ]* *//; s/\[-Rpass.*//' | paste - - - - - | tail -1

@@ -9,10 +9,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-KERNELS = {"local-energy sensitivities (two-wave matrix-core kernel)": "ff_eloc_mfma_kernel<6, 2, true, 2>",
+KERNELS = {"local-energy sensitivities + fused finish (two-wave matrix-core kernel)": "ff_eloc_mfma_kernel<6, 2, true, 2>",
            "local-energy sensitivities (walkers of cost class >= 12)": "ff_wide_eloc_kernel<2, 1, true, double>",
-           "theta-gradient adjoint": "ff_ode_adjtab_kernel<6, 2>",
-           "Metropolis sampler (beside the adjoint)": "ff_mcmc_spin_kernel<3, false>",
+           "heavy route: Slater table": "ff_eloc_slater_fixed_kernel<3>",
+           "heavy route: contraction": "ff_eloc_contract_kernel",
+           "theta-gradient adjoint (two waves per workgroup)": "ff_ode_adjtab_kernel<6, 2, 2>",
+           "Metropolis sampler (beside the adjoint)": "ff_mcmc_spin_philox_kernel<3>",
            "flow": "ff_ode_fwd_kernel<6, 2, 0, true>"}
 PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
           ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_INSTS_VALU"),
