@@ -261,7 +261,10 @@ class GSVMC(_Sweep, torch.nn.Module):
         # started on a side stream a moment after the adjoint kernel and runs beside it on the same SIMDs (292 + 164 registers;
         # DESIGN.md 6).  Same seeds in the same order, hence the same walkers as without it; the prefetched walkers travel in
         # checkpoints.
-        self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1") != "0"
+        # Measured (round 4, with the determinant-ratio samplers): it pays at 6 particles (1.67 -> 1.61 ms per iteration: the adjoint
+        # and the sampler fit one SIMD together) and costs at 12 and beyond (6.65 against 6.45 ms at 12 particles, 145 against 139 ms
+        # at configs[4]: both kernels fill the SIMDs on their own and only slow each other down) -- default on up to 8 particles.
+        self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1" if nup + ndown <= 8 else "0") != "0"
         self._z_next = None          # (walkers, event on the side stream, nloc, CPU generator state after their seed was drawn)
         self._side = None
 

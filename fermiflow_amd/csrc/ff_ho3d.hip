@@ -204,10 +204,12 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
   // pivot of a column is found by ONE 32-bit maximum over the group's 16 lanes (DPP): key = |entry| rounded to float with the lane
   // index in the low four bits (equal keys: the lower lane) -- a pivot that is within 2^-19 of the largest entry instead of the
   // largest changes the rounding of log|det|, not its value.  |det| is the product of the pivots (one log per determinant).
-  auto logabsdet = [&](const double* xx) -> double {
+  // detprod(xx, true): the product of the pivots of the species' Slater matrix, the entries with their Gaussians; (xx, false): of its
+  // polynomial part h_nx(x) h_ny(y) [h_nz(z)] alone (the Gaussian of a row factors out of the determinant: the Philox-fed chain)
+  auto detprod = [&](const double* xx, bool with_gauss) -> double {
     double A[NS];
-    double gs;
-    if constexpr (D == 2) gs = ff_gauss2d(xx[0], xx[1]); else gs = ff_gauss3d(xx);
+    double gs = 1.0;
+    if (with_gauss) { if constexpr (D == 2) gs = ff_gauss2d(xx[0], xx[1]); else gs = ff_gauss3d(xx); }
 #pragma unroll
     for (int c = 0; c < D; c++) {
       double hm = 1.0, h = FF_REC_A[0] * xx[c];
@@ -260,8 +262,9 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
       }
       __syncthreads();
     }
-    return log(fabs(prod));
+    return prod;
   };
+  auto logabsdet = [&](const double* xx) -> double { return log(fabs(detprod(xx, true))); };
   // log p of the walker = 2 (log|det up| + log|det down|): the two groups of a walker exchange their sums
   auto logprob = [&](const double* xx) -> double {
     const double mysum = logabsdet(xx);
@@ -286,6 +289,86 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
   };
 
   double x[D], nx[D];
+  if constexpr (!NOISE) {
+    // Philox-fed chain (round 4), the same stream and the same walkers as ff_rng_fill + the noise-fed branch below:
+    //  * the walker's Philox blocks -- ceil(M / 4) quads of normals and the block of the uniform -- are dealt over its 32 lanes, one
+    //    each, and meet in LDS (every lane used to evaluate the blocks of its own coordinates and the uniform's: up to three per
+    //    lane and step, six times the walker's sixteen);
+    //  * the decision u < |psi(x')|^2 / |psi(x)|^2 is taken as u e^{R' - R} (P_up P_dn)^2 < (P'_up P'_dn)^2 on the determinants of the
+    //    polynomial parts of the orbitals, R = sum r_i^2 (ff_mcmc_spin_philox_kernel): no exp per particle, no log per determinant.
+    __shared__ double s_nrm[2][64], s_uu[2];
+    const int wk = lane >> 5, L = lane & 31, nq = (M + 3) >> 2;
+    auto draw = [&](uint32_t step) {
+      if (L < nq) {
+        const ff_u4 rw = ff_philox(seed, wid, step, (uint32_t)L);
+        double z4[4];
+        ff_normal_pair32(rw.x, rw.y, z4[0], z4[1]);
+        ff_normal_pair32(rw.z, rw.w, z4[2], z4[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_nrm[wk][4 * L + k] = z4[k];
+      } else if (L == nq) {
+        s_uu[wk] = ff_uniform(seed, wid, step, D == 2 ? (uint32_t)n : 0xffffu);
+      }
+      __syncthreads();
+    };
+    // sum over the walker's 32 lanes, taken from its first lane so that every lane holds the same bits
+    auto wsum = [&](double v) -> double {
+#define FF_DPP_ADD(a, ctrl) ((a) + __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(a), ctrl, 0xF, 0xF, true), \
+                                                   __builtin_amdgcn_mov_dpp(__double2loint(a), ctrl, 0xF, 0xF, true)))
+      v = FF_DPP_ADD(v, 0xB1); v = FF_DPP_ADD(v, 0x4E); v = FF_DPP_ADD(v, 0x124); v = FF_DPP_ADD(v, 0x128);
+#undef FF_DPP_ADD
+      v += ff_lane_read(v, lane ^ 16);
+      return ff_lane_read(v, lane & ~31);
+    };
+    auto r2 = [&](const double* xx) -> double {
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < D; c++) t = fma(xx[c], xx[c], t);
+      return mine ? t : 0.0;
+    };
+    auto polyprod2 = [&](const double* xx) -> double {      // (P_up P_dn)^2
+      const double mp = detprod(xx, false), pp = mp * ff_lane_read(mp, lane ^ 16);
+      return pp * pp;
+    };
+    if (g0 != nullptr) {
+#pragma unroll
+      for (int c = 0; c < D; c++) x[c] = g0[b * M + i0 + c];
+    } else {
+      draw(0u);
+#pragma unroll
+      for (int c = 0; c < D; c++) x[c] = s_nrm[wk][i0 + c];
+    }
+    double Rl = r2(x), PP2 = polyprod2(x);
+    int nacc = 0;
+    for (int s = 0; s < steps; s++) {
+      draw((uint32_t)(s + 1));
+#pragma unroll
+      for (int c = 0; c < D; c++) nx[c] = ff3_add_rn(x[c], ff3_mul_rn(tau, s_nrm[wk][i0 + c]));
+      const double uu = s_uu[wk];
+      const double Rn = r2(nx), dRt = wsum(Rl - Rn);
+      const double lhs = uu * exp(fmin(fmax(-dRt, -700.0), 708.0)) * PP2;
+      const double PPn2 = polyprod2(nx);
+      const bool acc = (dRt >= -708.0) & (lhs < PPn2);      // IEEE: a NaN on either side rejects (src/base_dist.py:67-68)
+      if (acc) {
+#pragma unroll
+        for (int c = 0; c < D; c++) x[c] = nx[c];
+        Rl = Rn;
+        PP2 = PPn2;
+        nacc++;
+      }
+    }
+    const double logp = logprob(x);
+    if (!live) return;
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < D; c++) x_out[b * M + i0 + c] = x[c];
+    }
+    if (sp == 0 && r == 0) {
+      if (logp_out) logp_out[b] = logp;
+      if (acc_count) acc_count[b] = nacc;
+    }
+    return;
+  }
   if (NOISE || g0 != nullptr) {
 #pragma unroll
     for (int c = 0; c < D; c++) x[c] = g0[b * M + i0 + c];

@@ -165,6 +165,25 @@ def test_mcmc_full_size_properties(dev):
     assert abs(g.mean().item()) < 1e-3 and abs(g.std().item() - 1) < 1e-3 and abs(u.mean().item() - 0.5) < 1e-3
 
 
+@pytest.mark.parametrize("nup,ndn", [(4, 3), (7, 6), (2, 5), (0, 7)])
+def test_sixteen_lane_sampler_philox_equals_noise_path(dev, nup, ndn):
+    """ff_mcmc_rows_kernel (csrc/ff_ho3d.hip: every shape outside the register-resident template list, and d = 3): its Philox-fed
+    chain -- Philox blocks dealt over the walker's 32 lanes, determinant-ratio accept test on the polynomial parts -- gives the
+    walkers of its noise-fed chain (the reference's arithmetic, == the oracle bit for bit) on the materialised stream."""
+    from fermiflow_amd import native
+    B, S, n = 1001, 30, nup + ndn
+    tu = native.orbital_table(list(range(nup)), dev) if nup else None
+    td = native.orbital_table(list(range(ndn)), dev) if ndn else None
+    g0, g, u = native.rng_fill(B, n, S, 321, dev, walker_offset=11)
+    x1, lp1, a1 = native.mcmc_sample_noise(tu, td, nup, ndn, g0, g, u)
+    x2, lp2, cnt = native.mcmc_sample(tu, td, nup, ndn, B, S, 0.1, 321, dev, walker_offset=11)
+    assert torch.equal(x1, x2) and torch.equal(a1.sum(0).to(torch.int32), cnt.to(torch.int32))
+    assert torch.equal(lp1, lp2)
+    rows = slice(100, 116)
+    xo, lo, ao = O.mcmc_noise(N(g0[rows]), N(g[:, rows]), N(u[:, rows]), nup, ndn)
+    assert (ao == N(a1[:, rows])).all() and (xo == N(x2[rows])).all()
+
+
 def test_philox_stream_is_normal_and_symmetric(dev):
     """csrc/ff_rng.h: the proposal normals are Box-Muller on 32-bit Philox words evaluated with the hardware fp32
     transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32, v_cos_f32) and promoted to fp64; each normal takes its sign from a bit of
