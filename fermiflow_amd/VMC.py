@@ -30,7 +30,7 @@ class _ScalarWithParamGrads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value, flat_grads, *params):
         ctx.flat, ctx.shapes = flat_grads, [p.shape for p in params]
-        return value.clone()
+        return value.view_as(value)      # (an alias, no copy launch; nothing ever writes to it)
 
     @staticmethod
     def backward(ctx, g):
@@ -43,6 +43,37 @@ class _ScalarWithParamGrads(torch.autograd.Function):
             out.append(scaled[off:off + n].reshape(shp))
             off += n
         return (None, None) + tuple(out)
+
+
+class _SweepScalar(torch.Tensor):
+    """What a sweep returns: the 0-dim surrogate value, attached to the autograd graph (through _ScalarWithParamGrads) like any
+    tensor -- and with a short cut for the one thing the reference's training loop does with it, `gradE.backward()`
+    (src/FermionHO2D.py:71): called without arguments on the sweep's own result it hands the pre-computed gradient views to the
+    parameters' .grad directly (accumulating if they are set), instead of running the graph -- ones_like, a multiplication by 1 and
+    their launches, 15 us of a 1.6 ms iteration.  Anything else -- a gradient argument, inputs=, create_graph, or backward() on a tensor
+    computed FROM this one -- takes the ordinary autograd path with the same result."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        fast = getattr(self, "_ff_fast", None)
+        if fast is None or gradient is not None or inputs is not None or create_graph:
+            return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
+        params, flat = fast
+        off = 0
+        for p in params:
+            n = p.numel()
+            view = flat[off:off + n].view(p.shape)
+            off += n
+            if p.requires_grad:
+                if p.grad is None:
+                    p.grad = view
+                else:
+                    p.grad.add_(view)
+
+
+def _sweep_scalar(value, flat, params):
+    out = _ScalarWithParamGrads.apply(value, flat, *params).as_subclass(_SweepScalar)
+    out._ff_fast = (list(params), flat)
+    return out
 
 
 def _flow_params(cnf):
@@ -419,7 +450,7 @@ class GSVMC(_Sweep, torch.nn.Module):
         if prof is not None:
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
-        return _ScalarWithParamGrads.apply(est[2], gp, *params)
+        return _sweep_scalar(est[2], gp, params)
 
 
 class BetaVMC(_Sweep, torch.nn.Module):
@@ -586,6 +617,6 @@ class BetaVMC(_Sweep, torch.nn.Module):
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
         pdev = self.log_state_weights.device
-        gradF_phi = _ScalarWithParamGrads.apply(est[6].to(pdev), g_phi.to(pdev), self.log_state_weights)
-        gradF_theta = _ScalarWithParamGrads.apply(est[7], gp, *params)
+        gradF_phi = _sweep_scalar(est[6].to(pdev), g_phi.to(pdev), [self.log_state_weights])
+        gradF_theta = _sweep_scalar(est[7], gp, params)
         return gradF_phi, gradF_theta

@@ -280,7 +280,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
 // Direct evaluation.  Parameter gradient: lane l integrates, for its hidden units u = l + 64 j of eta and mu, the quadrature
 //   dtheta*/dt = ca df(r)/dtheta + cb df'(r)/dtheta   summed over the radii of that net,   (ca, cb) as in the tabulated kernel,
 // with the Runge-Kutta weights of accepted steps, and adds it to the workgroup's row of A.rows (its own entries only: plain
-// read-modify-writes); ff_rows_reduce_kernel sums the rows.
+// read-modify-writes); ff_adj_reduce_kernel sums the rows.
 template <int D, int W, int NQ>
 __global__ void __launch_bounds__(FF_WAVE * W)
 ff_wide_adj_kernel(ff_adj_args A, int n) {

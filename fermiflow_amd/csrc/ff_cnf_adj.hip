@@ -114,28 +114,6 @@ ff_ode_adj_lean_kernel(ff_adj_args A) {
 #include "ff_adj_direct_body.inc"
 }
 
-// out[k] = sum over rows of rows[r][k]: one workgroup per parameter, fixed tree (deterministic)
-__global__ void __launch_bounds__(256)
-ff_rows_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows, int P, const double* __restrict__ rows,
-                      double* __restrict__ out) {
-  {
-    const double* rt = net.radial_table;
-    if (rt && rt[3] == 0.0 && rt[4] == 0.0 && *off_table == 0.0) return;
-  }
-  __shared__ double sm[256];
-  const int k = blockIdx.x;
-  double s = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += blockDim.x) s += rows[(int64_t)r * P + k];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[k] = sm[0];
-}
-
-
 // ===================================================================================================
 // Tabulated adjoint (used when net.radial_table is valid and the weights are soft enough for the deposit grid).
 // Same lane <-> coordinate / lane <-> radius mapping as the forward kernels: the derivative heads come from the radial
@@ -634,20 +612,40 @@ extern int ff_wide_supported(int n, int d);
 
 // Wtot[t][j < NLDS][k] = sum over workgroups of their private tables; j >= NLDS was added in place.
 #ifndef FF_DEPR_EX
-#define FF_DEPR_EX 16      // entries per workgroup of ff_dep_reduce_kernel (consecutive: one 128-byte segment per table)
+#define FF_DEPR_EX 16      // entries per workgroup of the deposit-table part of ff_adj_reduce_kernel (consecutive: one 128-byte segment per table)
 #define FF_DEPR_TY 16      // table subsets summed side by side
 #endif
+// ONE launch behind the adjoint kernels for both cross-workgroup sums (they were two; exactly one of them has work): workgroups
+// [0, P) sum the direct kernel's per-workgroup parameter rows (ff_rows_reduce: only if the direct kernel ran), the others the
+// tabulated kernel's private deposit tables (only if the tabulated kernel served the call)
 __global__ void __launch_bounds__(FF_DEPR_EX * FF_DEPR_TY)
-ff_dep_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nblocks, const double* __restrict__ rows,
-                     double* __restrict__ wtot) {
+ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows, int P, const double* __restrict__ prow,
+                     double* __restrict__ out, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot) {
   const double* rtab = net.radial_table;
-  if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0)) return;
+  const bool tab_served = rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0;
+  if ((int)blockIdx.x < P) {
+    if (tab_served) return;
+    __shared__ double smr[FF_DEPR_EX * FF_DEPR_TY];
+    const int k = blockIdx.x;
+    double sr = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) sr += prow[(int64_t)r * P + k];
+    smr[threadIdx.x] = sr;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) smr[threadIdx.x] += smr[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = smr[0];
+    return;
+  }
+  if (!tab_served || rows == nullptr) return;
+  const int bid = (int)blockIdx.x - P;
   // thread (tx, ty): entry e0 + tx of the tables ty, ty + TY, ... -- the 16 lanes of a row read one contiguous segment of a
   // table (the first version gave every entry its own workgroup whose lanes strode over the tables, 24.6 KB apart: 38 us for
   // 25 MB); partial sums meet in a fixed tree, so the result depends on (nblocks, TY) only: deterministic
   __shared__ double sm[FF_DEPR_TY][FF_DEPR_EX + 1];
   const int tx = threadIdx.x % FF_DEPR_EX, ty = threadIdx.x / FF_DEPR_EX;
-  const int e = blockIdx.x * FF_DEPR_EX + tx;
+  const int e = bid * FF_DEPR_EX + tx;
   constexpr int NE = 2 * FF_DEP_NLDS * FF_DEP_ROW;
   double s0 = 0.0, s1 = 0.0;
   if (e < NE) {
@@ -864,14 +862,17 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   }
   FF_LAUNCH_CHECK();
   const int nblk = (int)adj_grid(B, G);
-  FF_LAUNCH(ff_rows_reduce_kernel, (unsigned)P, FF_RBLOCK(256), stream, *net, (const double*)a.off_table, nblk * G, P, (const double*)a.rows, grad_params);
-  FF_LAUNCH_CHECK();
-  if (net->radial_table) {
+  {
     const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);     // workgroups (= private tables) of the tabulated kernel
     double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    FF_LAUNCH(ff_dep_reduce_kernel, (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_EX - 1) / FF_DEPR_EX), FF_DEPR_EX * FF_DEPR_TY, stream, *net,
-              (const double*)a.off_table, ntab, (const double*)a.trows, wtot);
+    const unsigned ndep = net->radial_table ? (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_EX - 1) / FF_DEPR_EX) : 0u;
+    FF_LAUNCH(ff_adj_reduce_kernel, (unsigned)P + ndep, FF_DEPR_EX * FF_DEPR_TY, stream, *net, (const double*)a.off_table, nblk * G, P,
+              (const double*)a.rows, grad_params, ntab, (const double*)(net->radial_table ? a.trows : nullptr), wtot);
     FF_LAUNCH_CHECK();
+  }
+  if (net->radial_table) {
+    const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);
+    double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     FF_LAUNCH(ff_dep_contract_kernel, (unsigned)(net->He + net->Hm), FF_RBLOCK(256), stream, *net, (const double*)a.off_table,
               (const double*)wtot, grad_params);
     FF_LAUNCH_CHECK();

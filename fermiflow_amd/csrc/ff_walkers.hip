@@ -787,6 +787,85 @@ ff_mlp_kernel(int64_t N, int H, const double* __restrict__ w1, const double* __r
   if (dval) dval[i] = g;
 }
 
+// value and first two derivatives of the scalar MLP at r
+FF_D void ff_mlp_point2(int H, const double* __restrict__ w1, const double* __restrict__ b1, const double* __restrict__ w2,
+                        double r, double& val, double& d1, double& d2) {
+  double s = 0.0, g = 0.0, q = 0.0;
+  for (int h = 0; h < H; h++) {
+    const double a = ff_sigmoid(fma(w1[h], r, b1[h])), sp = a * (1.0 - a), ww = w2[h] * w1[h];
+    s = fma(w2[h], a, s);
+    g = fma(ww, sp, g);
+    q = fma(ww * w1[h], sp * (1.0 - 2.0 * a), q);
+  }
+  val = s; d1 = g; d2 = q;
+}
+
+// MLP.forward / MLP.grad for any input dimension (src/MLP.py:30-45; the backflow potentials use D_in = 1: ff_mlp_kernel):
+// val[i] = fc2(sigmoid(fc1(x_i))), grad[i][:] = (fc2.weight * sigmoid') @ fc1.weight.  One lane per point.
+#define FF_MLP_DMAX 64
+__global__ void __launch_bounds__(128)
+ff_mlp_nd_kernel(int64_t N, int Din, int H, const double* __restrict__ w1, const double* __restrict__ b1, const double* __restrict__ w2,
+                 const double* __restrict__ x, double* __restrict__ val, double* __restrict__ grad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double xl[FF_MLP_DMAX], gl[FF_MLP_DMAX];
+  for (int k = 0; k < Din; k++) { xl[k] = x[i * Din + k]; gl[k] = 0.0; }
+  double s = 0.0;
+  for (int h = 0; h < H; h++) {
+    double a = b1[h];
+    for (int k = 0; k < Din; k++) a = fma(w1[(int64_t)h * Din + k], xl[k], a);
+    const double sg = ff_sigmoid(a), c = w2[h] * sg * (1.0 - sg);
+    s = fma(w2[h], sg, s);
+    if (grad) for (int k = 0; k < Din; k++) gl[k] = fma(c, w1[(int64_t)h * Din + k], gl[k]);
+  }
+  if (val) val[i] = s;
+  if (grad) for (int k = 0; k < Din; k++) grad[i * Din + k] = gl[k];
+}
+
+// Vector-Jacobian products of the backflow field for autograd through Backflow.forward / .divergence
+// (tests/test_equivariant_funs.py:25-35 of the reference differentiates v with respect to x):
+//   Aw   = (dv/dx)^T w = (dv/dx) w      (dv/dx is symmetric: blocks B = eta I + (eta'/r) rho rho^T of every pair, mu likewise)
+//   gdiv = grad_x div v                 (per pair 2 (eta'' r + (1 + D) eta') rho / r; per particle (mu'' r + (1 + D) mu') x / r)
+// One lane per walker, direct sigmoids, any n <= FF_MAX_N, d <= 3.  w / Aw or gdiv may be NULL.
+__global__ void __launch_bounds__(128)
+ff_backflow_vjp_kernel(int64_t B, int n, int d, ff_net net, const double* __restrict__ x, const double* __restrict__ w,
+                       double* __restrict__ Aw, double* __restrict__ gdiv) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int M = n * d;
+  double xl[3 * FF_MAX_N], wl[3 * FF_MAX_N], al[3 * FF_MAX_N], gl[3 * FF_MAX_N];
+  for (int i = 0; i < M; i++) { xl[i] = x[b * M + i]; wl[i] = w ? w[b * M + i] : 0.0; al[i] = 0.0; gl[i] = 0.0; }
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++) {
+      double rho[3], dw[3], r2 = 0.0, rdw = 0.0;
+      for (int c = 0; c < d; c++) { rho[c] = xl[i * d + c] - xl[j * d + c]; dw[c] = wl[i * d + c] - wl[j * d + c]; r2 = fma(rho[c], rho[c], r2); rdw = fma(rho[c], dw[c], rdw); }
+      const double r = sqrt(r2);
+      double f0, f1, f2;
+      ff_mlp_point2(net.He, net.ew1, net.eb1, net.ew2, r, f0, f1, f2);
+      const double k1 = f1 * rdw / r, gq = 2.0 * fma(f2, r, (1.0 + d) * f1) / r;
+      for (int c = 0; c < d; c++) {
+        const double t = fma(k1, rho[c], f0 * dw[c]);
+        al[i * d + c] += t; al[j * d + c] -= t;
+        gl[i * d + c] = fma(gq, rho[c], gl[i * d + c]); gl[j * d + c] = fma(-gq, rho[c], gl[j * d + c]);
+      }
+    }
+  if (net.Hm > 0)
+    for (int i = 0; i < n; i++) {
+      double r2 = 0.0, rw = 0.0;
+      for (int c = 0; c < d; c++) { r2 = fma(xl[i * d + c], xl[i * d + c], r2); rw = fma(xl[i * d + c], wl[i * d + c], rw); }
+      const double r = sqrt(r2);
+      double f0, f1, f2;
+      ff_mlp_point2(net.Hm, net.mw1, net.mb1, net.mw2, r, f0, f1, f2);
+      const double k1 = f1 * rw / r, gq = fma(f2, r, (1.0 + d) * f1) / r;
+      for (int c = 0; c < d; c++) {
+        al[i * d + c] += fma(k1, xl[i * d + c], f0 * wl[i * d + c]);
+        gl[i * d + c] = fma(gq, xl[i * d + c], gl[i * d + c]);
+      }
+    }
+  if (Aw) for (int i = 0; i < M; i++) Aw[b * M + i] = al[i];
+  if (gdiv) for (int i = 0; i < M; i++) gdiv[b * M + i] = gl[i];
+}
+
 // Backflow.forward / .divergence (src/equivariant_funs.py:83-102), any n <= FF_MAX_N, d <= 3, any H.
 // (The j == i term of the reference's "+eye" formulation cancels analytically and is skipped.)
 __global__ void __launch_bounds__(128)
@@ -1364,6 +1443,27 @@ int ff_mlp_eval(void* stream, int64_t N, int H, const double* w1, const double* 
   FF_CHECK(N >= 0 && H > 0 && w1 && b1 && w2 && r && val, FF_EINVAL, "ff_mlp_eval: bad argument");
   if (N == 0) return FF_OK;
   FF_LAUNCH(ff_mlp_kernel, ff_grid(N, 128), 128, stream, N, H, w1, b1, w2, r, val, dval);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_mlp_eval_nd(void* stream, int64_t N, int D_in, int H, const double* w1, const double* b1, const double* w2, const double* x,
+                   double* val, double* grad) {
+  FF_CHECK(N >= 0 && D_in > 0 && H > 0 && w1 && b1 && w2 && x && (val || grad), FF_EINVAL, "ff_mlp_eval_nd: bad argument");
+  FF_CHECK(D_in <= FF_MLP_DMAX, FF_EUNSUPPORTED, "ff_mlp_eval_nd: D_in > 64");
+  if (N == 0) return FF_OK;
+  FF_LAUNCH(ff_mlp_nd_kernel, ff_grid(N, 128), 128, stream, N, D_in, H, w1, b1, w2, x, val, grad);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
+int ff_backflow_vjp(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, const double* w, double* Aw, double* gdiv) {
+  FF_CHECK(B >= 0 && n > 0 && d > 0 && net && x && ((w && Aw) || gdiv) && (Aw == nullptr || w != nullptr), FF_EINVAL, "ff_backflow_vjp: bad argument");
+  FF_CHECK(net->He > 0 && net->ew1 && net->eb1 && net->ew2 && (net->Hm == 0 || (net->mw1 && net->mb1 && net->mw2)), FF_EINVAL,
+           "ff_backflow_vjp: bad net");
+  FF_CHECK(n <= FF_MAX_N && d <= 3, FF_EUNSUPPORTED, "ff_backflow_vjp: n > 24 or d > 3");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_backflow_vjp_kernel, ff_grid(B, 128), 128, stream, B, n, d, *net, x, w, Aw, gdiv);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

@@ -9,6 +9,38 @@ from . import _lib as L
 from . import native
 
 
+class _BackflowV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module):
+        xd = x.detach().contiguous()
+        ctx.module, ctx.shape = module, x.shape
+        ctx.save_for_backward(xd)
+        return native.backflow_v_div(module.net(), xd.reshape(-1, *x.shape[-2:]), need_v=True, need_div=False)[0].reshape(x.shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xd, = ctx.saved_tensors
+        Aw, _ = native.backflow_vjp(ctx.module.net(), xd.reshape(-1, *ctx.shape[-2:]), w=g.contiguous().reshape(-1, *ctx.shape[-2:]))
+        return Aw.reshape(ctx.shape), None
+
+
+class _BackflowDiv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module):
+        xd = x.detach().contiguous()
+        ctx.module, ctx.shape = module, x.shape
+        ctx.save_for_backward(xd)
+        return native.backflow_v_div(module.net(), xd.reshape(-1, *x.shape[-2:]), need_v=False, need_div=True)[1].reshape(x.shape[:-2])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xd, = ctx.saved_tensors
+        _, gd = native.backflow_vjp(ctx.module.net(), xd.reshape(-1, *ctx.shape[-2:]), need_gdiv=True)
+        return gd.reshape(ctx.shape) * g.reshape(*ctx.shape[:-2], 1, 1), None
+
+
 class Backflow(torch.nn.Module):
     def __init__(self, eta, mu=None):
         """ The argument eta must be an instance of torch.nn.Module. """
@@ -31,12 +63,13 @@ class Backflow(torch.nn.Module):
         self._net_key = None
 
     def forward(self, x):
-        v, _ = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=True, need_div=False)
-        return v
+        """v(x), differentiable with respect to x (first order: ff_backflow_vjp supplies (dv/dx)^T w); the parameters are not
+        autograd inputs here -- their gradient is the fused adjoint's business (flow.CNF)."""
+        return _BackflowV.apply(x, self)
 
     def divergence(self, x):
-        _, div = native.backflow_v_div(self.net(), x.detach().contiguous(), need_v=False, need_div=True)
-        return div
+        """div v(x) by the hand-derived formula (src/equivariant_funs.py:93-102), differentiable with respect to x."""
+        return _BackflowDiv.apply(x, self)
 
     def _e_e(self, x):
         return native.backflow_v_div(L.Net(self.eta, None, radial="exact"), x.detach().contiguous(), True, False)[0]

@@ -126,6 +126,29 @@ def mlp_eval(w1, b1, w2, r, need_grad=True):
     return val, dval
 
 
+def mlp_eval_nd(w1, b1, w2, x, need_val=True, need_grad=False):
+    """ff_mlp_eval_nd: x (N, D_in) -> val (N), grad (N, D_in)."""
+    x = L.dev(x, name="x")
+    N, Din = x.shape
+    w1, b1, w2 = L.dev(w1.reshape(-1, Din)), L.dev(b1), L.dev(w2.reshape(-1))
+    val = torch.empty(N, dtype=torch.float64, device=x.device) if need_val else None
+    grad = torch.empty_like(x) if need_grad else None
+    L.check(L.lib().ff_mlp_eval_nd(L.stream(), L.i64(N), int(Din), b1.numel(), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(x), L.ptr(val), L.ptr(grad)),
+            "ff_mlp_eval_nd")
+    return val, grad
+
+
+def backflow_vjp(net, x, w=None, need_gdiv=False):
+    """ff_backflow_vjp: ((dv/dx)^T w or None, grad_x div v or None)."""
+    x = L.dev(x, name="x")
+    B, n, d = x.shape
+    w = L.dev(w, name="w") if w is not None else None
+    Aw = torch.empty_like(x) if w is not None else None
+    gd = torch.empty_like(x) if need_gdiv else None
+    L.check(L.lib().ff_backflow_vjp(L.stream(), L.i64(B), n, d, net.ref(), L.ptr(x), L.ptr(w), L.ptr(Aw), L.ptr(gd)), "ff_backflow_vjp")
+    return Aw, gd
+
+
 def backflow_v_div(net, x, need_v=True, need_div=True):
     x = L.dev(x, name="x")
     B, n, d = x.shape

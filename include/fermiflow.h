@@ -170,6 +170,15 @@ int ff_mlp_eval(void* stream, int64_t N, int H, const double* w1, const double* 
                 const double* r, double* val, double* dval);
 /* Backflow.forward / .divergence (src/equivariant_funs.py:83-102); v (B,n,d) / div (B) may be NULL. */
 int ff_backflow_v_div(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div);
+/* MLP.forward / MLP.grad for any input dimension D_in <= 64 (src/MLP.py:30-45; tests/test_MLP.py builds MLP(15, 40)): x (N, D_in),
+ * w1 = fc1.weight (H, D_in) row-major, val (N) and grad (N, D_in) -- either may be NULL. */
+int ff_mlp_eval_nd(void* stream, int64_t N, int D_in, int H, const double* w1, const double* b1, const double* w2, const double* x,
+                   double* val, double* grad);
+/* What autograd needs to differentiate Backflow.forward / .divergence with respect to x (the reference's own check,
+ * tests/test_equivariant_funs.py:25-35, takes the divergence of v by autograd): Aw (B,n,d) = (dv/dx)^T w for a cotangent w (B,n,d)
+ * and gdiv (B,n,d) = grad_x div v.  (w, Aw) or gdiv may be NULL.  Derivatives with respect to the network parameters are the
+ * business of ff_cnf_adjoint*, not of these entry points. */
+int ff_backflow_vjp(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, const double* w, double* Aw, double* gdiv);
 /* HO.V + CoulombPairPotential(Z).V (src/potentials.py:13, 23-47); use_ho = 0 drops the trap term. */
 int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, const double* x, double* V);
 
