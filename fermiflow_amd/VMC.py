@@ -142,6 +142,8 @@ class _Sweep:
         # heavy_class < 0: no routing).  Reference semantics -- one tolerance, one kernel for every walker -- are
         # sens_tol = 1, heavy_class = -1 (FERMIFLOW_SENS_TOL=1 FERMIFLOW_HEAVY_CLASS=-1).
         self.heavy_class = int(os.environ.get("FERMIFLOW_HEAVY_CLASS", "0"))
+        # ff_ode.compact_finish (None: native.eloc decides by the size of the full workspace; FERMIFLOW_COMPACT=1/0 forces it)
+        self.compact_finish = {"1": True, "0": False}.get(os.environ.get("FERMIFLOW_COMPACT", ""), None)
         self.heavy_tol = float(os.environ.get("FERMIFLOW_HEAVY_TOL", "0"))
         self.sum_weight = float(os.environ.get("FERMIFLOW_SUM_WEIGHT", "0"))
 
@@ -197,7 +199,8 @@ class _Sweep:
                         walker_h_init=hg, walker_h_scale=self._h_scale_eloc, walker_h_out=he,
                         walker_class=cost if (self.sens_tol > 1.0 or self.heavy_class > 0) else None, sens_tol=self.sens_tol,
                         sens_tol_class=self.sens_tol_class, walker_h_scale_loose=self._h_scale_loose,
-                        heavy_class=self.heavy_class, heavy_tol=self.heavy_tol, sum_weight=self.sum_weight)
+                        heavy_class=self.heavy_class, heavy_tol=self.heavy_tol, sum_weight=self.sum_weight,
+                        compact=self.compact_finish)
         _add_generic_potentials(r, x, extra)
         self._mark(ev, "eloc")
         if prof is not None:

@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
-ABI_VERSION = 103      # ff_version() of the library this binding was written against (include/fermiflow.h)
+ABI_VERSION = 104      # ff_version() of the library this binding was written against (include/fermiflow.h)
 
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
     "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_mcmc_continue", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
     "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint", "ff_cnf_adjoint_energy", "ff_reduce_energy", "ff_energy_finish", "ff_stream_delay",
-    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_state_sums", "ff_beta_buffer_doubles", "ff_beta_state_partials", "ff_beta_finish", "ff_logprob3d", "ff_mcmc_sample_noise3d", "ff_mcmc_sample3d", "ff_eloc_finish3d", "ff_backflow_v_div_f32", "ff_walker_order_workspace_bytes", "ff_walker_order", "ff_set_kernel_family", "ff_set_sens_precision", "ff_shutdown", "ff_walker_order_mean", "ff_energy_estimate_workspace_bytes", "ff_energy_estimate", "ff_mlp_eval_nd", "ff_backflow_vjp",
+    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_state_sums", "ff_beta_buffer_doubles", "ff_beta_state_partials", "ff_beta_finish", "ff_logprob3d", "ff_mcmc_sample_noise3d", "ff_mcmc_sample3d", "ff_eloc_finish3d", "ff_backflow_v_div_f32", "ff_walker_order_workspace_bytes", "ff_walker_order", "ff_set_kernel_family", "ff_set_sens_precision", "ff_shutdown", "ff_walker_order_mean", "ff_energy_estimate_workspace_bytes", "ff_energy_estimate", "ff_mlp_eval_nd", "ff_backflow_vjp", "ff_eloc_nd", "ff_eloc_nd_workspace_bytes",
 ]
 
 
@@ -33,7 +33,8 @@ class FFOde(C.Structure):
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
-                ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double)]
+                ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double),
+                ("compact_finish", C.c_int32)]
 
 
 def lib():
@@ -51,6 +52,7 @@ def lib():
                                "(python -c 'import __graft_entry__ as g; g.build()')")
         _LIB.ff_last_error.restype = C.c_char_p
         _LIB.ff_eloc_workspace_bytes.restype = C.c_size_t
+        _LIB.ff_eloc_nd_workspace_bytes.restype = C.c_size_t
         _LIB.ff_cnf_adjoint_workspace_bytes.restype = C.c_size_t
         _LIB.ff_radial_table_bytes.restype = C.c_size_t
         _LIB.ff_walker_order_workspace_bytes.restype = C.c_size_t
@@ -134,12 +136,13 @@ class Net:
 
 def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, walker_h_init=None, walker_h_scale=1.0,
         walker_h_out=None, walker_h_uniform=False, walker_class=None, sens_tol=1.0, sens_tol_class=0,
-        walker_h_scale_loose=0.0, heavy_class=0, heavy_tol=0.0, sum_weight=0.0):
+        walker_h_scale_loose=0.0, heavy_class=0, heavy_tol=0.0, sum_weight=0.0, compact_finish=False):
     """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
     walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start);
     walker_h_uniform: walker_h_init is a 1-element tensor, the first step of every walker;
     heavy_class / heavy_tol / sum_weight: routing threshold and tolerances of the local-energy pass (0: library defaults 12, 0.3, 4;
-    heavy_class < 0: no routing)."""
+    heavy_class < 0: no routing); compact_finish: ff_eloc_nd finishes walkers in the one-walker-per-workgroup kernels' epilogue
+    (compact workspace beyond 24 coordinates; include/fermiflow.h)."""
     for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),
                           ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64),
                           ("walker_class", walker_class, torch.int32)):
@@ -148,4 +151,4 @@ def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, wa
     p = lambda t: t.data_ptr() if t is not None else None
     return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps), p(walker_cost), p(walker_order),
                  p(walker_h_init), float(walker_h_scale), p(walker_h_out), p(walker_class), float(sens_tol), float(walker_h_scale_loose),
-                 int(sens_tol_class), int(bool(walker_h_uniform)), int(heavy_class), float(heavy_tol), float(sum_weight))
+                 int(sens_tol_class), int(bool(walker_h_uniform)), int(heavy_class), float(heavy_tol), float(sum_weight), int(bool(compact_finish)))

@@ -1358,8 +1358,10 @@ static thread_local ff_eloc_feedback t_eloc_fb = {false, false, nullptr, 0.0};
 // the heavy launch was refused -- and the caller launches its table kernel for every walker.  FF_ROUTE_FAILED: the throughput
 // launch or the join failed after the heavy kernel was enqueued; both streams have been drained and the caller returns FF_ELAUNCH
 // (the outputs of this call are undefined).
+// throughput_fuses: the throughput kernel takes the fused finish -- only then may the heavy kernel finish ITS walkers itself (bit 1 of
+// fin.on): otherwise the caller's unfiltered finish kernels run over every walker and need the heavy walkers' sensitivities in the workspace.
 template <class F>
-static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F launch_table) {
+static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F launch_table, bool throughput_fuses) {
   if (!(a.evt && a.wclass && a.heavy_class > 0 && n * d <= 12 && ff_wide_supported(n, d))) return FF_ROUTE_NONE;
   std::lock_guard<std::mutex> lock(g_side_mutex);
   ff_side_lane* side = ff_side();
@@ -1369,6 +1371,7 @@ static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F lau
   }
   ff_fwd_args h = a, l = a;
   h.queue = nullptr; h.heavy_mode = 1;      // grid-stride over every walker, the light ones skipped
+  if (!throughput_fuses) h.fin.on = 0;
   if (a.heavy_tol > 0.0) { h.rtol *= a.heavy_tol; h.atol *= a.heavy_tol; }
   l.heavy_mode = 2;
   // placed first: a persistent grid takes every register file it finds
@@ -1379,7 +1382,7 @@ static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F lau
   // the caller's stream and in front of the join: the heavy kernel ends well before the throughput kernel does (0.53 against
   // 0.82 ms at config 2), so their 46 us run in its shadow.  (Should the table kernels raise the off-table event, the unrouted
   // fused direct kernel behind the join redoes every walker and overwrites these outputs.)
-  if (a.fin.on && a.fin.workspace) {
+  if (throughput_fuses && !(h.fin.on & 2) && a.fin.workspace) {      // (with bit 1 the heavy kernel finishes its walkers itself)
     const ff_fwd_args::ff_fin_args& f = a.fin;
     if (eloc_finish_impl(stream, a.B, f.nup, f.ndn, f.tab_up, f.tab_dn, f.wstate, f.Z, f.use_ho, a.y_in, f.workspace, f.logp, f.grad, f.lap,
                          f.V, f.eloc, nullptr, nullptr, f.glogp0, ff_fin_filter{a.wclass, a.heavy_class, a.evt, a.evt_id}) != FF_OK)
@@ -1407,7 +1410,7 @@ static int launch_fwd(void* stream, const ff_fwd_args& a) {
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   auto table = [&](void* st, const ff_fwd_args& aa) { FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, st, aa); };
   int routed = FF_ROUTE_NONE;
-  if constexpr (MODE == 2 && N <= 3) routed = launch_routed(stream, N, D, a, table);
+  if constexpr (MODE == 2 && N <= 3) routed = launch_routed(stream, N, D, a, table, false);
   if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
   if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
   FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
@@ -1449,10 +1452,10 @@ static int launch_mfma(void* stream, const ff_fwd_args& a) {
   auto table = [&](void* st, const ff_fwd_args& aa) {
     FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, st, aa);
   };
-  const int routed = launch_routed(stream, N, D, a, table);
+  const int routed = launch_routed(stream, N, D, a, table, (a.fin.on & 1) && N % 2 == 0 && D == 2);
   if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
   if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
-  t_eloc_fb.fused = a.fin.on && N % 2 == 0 && D == 2;      // (what the kernel's epilogue tests)
+  t_eloc_fb.fused = (a.fin.on & 1) && N % 2 == 0 && D == 2;      // (what the kernel's epilogue tests)
   t_eloc_fb.routed = routed == FF_ROUTE_DONE;
   t_eloc_fb.evt = a.evt; t_eloc_fb.evt_id = a.evt_id;
   const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
@@ -1476,7 +1479,12 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   // FF_ELOC_KERNEL = auto (default) | mfma | rows | columns forces one where it is instantiated.  auto takes the fastest
   // measured on MI355X (tools/probes/eloc_ab.py): the column sweep up to 8 particles, the row layout from 9 on (and for
   // every particle number the column sweep is not instantiated for).
-  if (ff_wide_forced() && ff_wide_supported(n, d)) return ff_wide_dispatch_fwd(MODE, stream, n, d, a);   // FF_WIDE=1: A/B and parity testing
+  auto wide = [&]() -> int {      // the one-walker-per-workgroup family; its local-energy kernels take the fused finish (bit 1 of fin.on)
+    const int st_ = ff_wide_dispatch_fwd(MODE, stream, n, d, a);
+    if (MODE == 2 && st_ == FF_OK) { t_eloc_fb.fused = (a.fin.on & 2) != 0; t_eloc_fb.routed = false; }
+    return st_;
+  };
+  if (ff_wide_forced() && ff_wide_supported(n, d)) return wide();   // FF_WIDE=1: A/B and parity testing
   static const int eloc_kind = [] {
     const char* e = getenv("FF_ELOC_KERNEL");
     return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : (!strcmp(e, "wide") ? 4 : 0))));
@@ -1485,7 +1493,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   // FF_WIDE_ELOC_FROM particles on (tools/probes/wide_c5.py; 16 384 walkers: 11 particles 2.12 against 2.68 ms, 12 particles 2.25 against 2.91; 10 particles 2.04 against 1.88)
   static const int wide_from = [] { const char* e = getenv("FF_WIDE_ELOC_FROM"); return e ? atoi(e) : 11; }();
   if (MODE == 2 && d == 2 && (eloc_kind == 4 || (eloc_kind == 0 && n >= wide_from)) && ff_wide_supported(n, d))
-    return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
+    return wide();
   static const int mfma_from = [] { const char* e = getenv("FF_MFMA_ELOC_FROM"); return e ? atoi(e) : 4; }();
   if (MODE == 2 && (eloc_kind == 1 || (eloc_kind == 0 && d == 2 && n >= mfma_from && n <= 6))) {
 #define FF_MF(N_, D_) if (n == N_ && d == D_) { const int s_ = launch_mfma<N_, D_>(stream, a); if (s_) return s_; FF_LAUNCH_CHECK(); return FF_OK; }
@@ -1510,7 +1518,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   if constexpr (MODE != 2) { FF_ND(1, 2) FF_ND(7, 2) FF_ND(9, 2) FF_ND(11, 2) FF_ND(2, 3) FF_ND(3, 3) FF_ND(4, 3) }   // (their local-energy pass is the row-layout kernel above)
 #undef FF_ND
   // everything else: one walker per workgroup (ff_wide.hip: n <= 24, n d <= 60)
-  return ff_wide_dispatch_fwd(MODE, stream, n, d, a);
+  return wide();
 }
 
 static int check_common(int64_t B, int n, int d, const ff_net* net, const ff_ode* ode) {
@@ -1583,6 +1591,9 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
 size_t ff_eloc_workspace_bytes(int64_t B, int n, int d) {
   return sizeof(double) * ff_eloc_ws_doubles(B, (size_t)n, (size_t)d);
 }
+size_t ff_eloc_nd_workspace_bytes(int64_t B, int n, int d, int compact_finish) {
+  return sizeof(double) * ff_eloc_ws_doubles(B, (size_t)n, (size_t)d, compact_finish && ff_eloc_ws_compact((size_t)n, (size_t)d));
+}
 
 static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode, const double* x,
                                    void* workspace, int32_t* stats, const ff_fwd_args::ff_fin_args* fin);
@@ -1600,7 +1611,7 @@ static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const 
   if (st) return st;
   FF_CHECK(x && workspace, FF_EINVAL, "ff_eloc_sensitivities: null pointer");
   if (B == 0) return FF_OK;
-  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, (size_t)d);
+  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, (size_t)d, fin != nullptr && (fin->on & 2) && ff_eloc_ws_compact((size_t)n, (size_t)d));
   ff_fwd_args a = {};
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
@@ -1668,32 +1679,54 @@ static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int
   return FF_OK;
 }
 
+extern "C" int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
+                                const int32_t* walker_state, double Z, int use_ho, const double* x, const void* workspace,
+                                double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+                                double* glogp0_out);      // ff_ho3d.hip
+
+int ff_eloc_nd(void* stream, int64_t B, int nup, int ndn, int d, const int32_t* tab_up, const int32_t* tab_dn,
+               const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho, const double* x,
+               double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
+               double* glogp0_out, void* workspace, int32_t* stats) {
+  FF_CHECK(nup >= 0 && ndn >= 0 && nup + ndn > 0 && (d == 2 || d == 3), FF_EINVAL, "ff_eloc: bad particle numbers or dimension");
+  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc: null orbital table");
+  FF_CHECK(nup <= FF_MAX_NS && ndn <= FF_MAX_NS, FF_EUNSUPPORTED, "ff_eloc: determinant larger than FF_MAX_NS");
+  // Offer the fused finish: a sensitivity kernel that implements it writes logp, grad, lap, V, E_loc and grad_z logp0 from its
+  // epilogue, and J^T (8 M^2 bytes per walker) never leaves the chip -- the matrix-core kernel for nup = ndown <= 3 in d = 2 (bit 0:
+  // config 2); on request (ff_ode::compact_finish: it costs time, include/fermiflow.h) the one-walker-per-workgroup kernels for every
+  // shape they serve (bit 1: configs 3-4, everything beyond 12 particles, the heavy-walker route).
+  ff_fwd_args::ff_fin_args fin = {};
+  const int n = nup + ndn;
+  const bool compact = ode && ode->compact_finish && ff_eloc_ws_compact((size_t)n, (size_t)d);
+  fin.on = ((d == 2 && nup == ndn && nup >= 1 && nup <= 3) ? 1 : 0) | ((ode && ode->compact_finish) ? 2 : 0);
+  fin.nup = nup; fin.ndn = ndn; fin.use_ho = use_ho; fin.tab_up = tab_up; fin.tab_dn = tab_dn; fin.wstate = walker_state; fin.Z = Z;
+  fin.logp = logp; fin.grad = grad; fin.lap = lap; fin.V = V; fin.eloc = eloc; fin.glogp0 = glogp0_out; fin.workspace = workspace;
+  int st = eloc_sensitivities_impl(stream, B, n, d, net, ode, x, workspace, stats, &fin);
+  if (st) return st;
+  const ff_eloc_feedback fb = t_eloc_fb;
+  if (B == 0) return FF_OK;
+  if (!fb.fused) {
+    FF_CHECK(!compact, FF_EUNSUPPORTED, "ff_eloc: compact_finish, but the kernel of this shape has no fused finish");
+    if (d == 3)
+      return ff_eloc_finish3d(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc, z_out,
+                              dlogp_out, glogp0_out);
+    return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
+                          z_out, dlogp_out, glogp0_out);
+  }
+  // (routed pass: the walkers of the heavy route were finished inside launch_routed -- by their own kernel's epilogue)
+  const size_t M = (size_t)n * d;
+  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, (size_t)d, compact);
+  if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  return FF_OK;
+}
+
 int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
             const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho, const double* x,
             double* logp, double* grad, double* lap, double* V, double* eloc, double* z_out, double* dlogp_out,
             double* glogp0_out, void* workspace, int32_t* stats) {
-  FF_CHECK(nup >= 0 && ndn >= 0 && nup + ndn > 0, FF_EINVAL, "ff_eloc: bad particle numbers");
-  FF_CHECK((nup == 0 || tab_up) && (ndn == 0 || tab_dn), FF_EINVAL, "ff_eloc: null orbital table");
-  // Offer the fused finish: a sensitivity kernel that implements it (the matrix-core kernel, nup = ndn: config 2) writes logp,
-  // grad, lap, V, E_loc and grad_z logp0 from its epilogue, and J^T (8 M^2 bytes per walker) never leaves the chip.
-  ff_fwd_args::ff_fin_args fin = {};
-  const int n = nup + ndn;
-  fin.on = (nup == ndn && nup >= 1 && nup <= 3) ? 1 : 0;
-  fin.nup = nup; fin.ndn = ndn; fin.use_ho = use_ho; fin.tab_up = tab_up; fin.tab_dn = tab_dn; fin.wstate = walker_state; fin.Z = Z;
-  fin.logp = logp; fin.grad = grad; fin.lap = lap; fin.V = V; fin.eloc = eloc; fin.glogp0 = glogp0_out; fin.workspace = workspace;
-  int st = eloc_sensitivities_impl(stream, B, n, 2, net, ode, x, workspace, stats, &fin);
-  if (st) return st;
-  const ff_eloc_feedback fb = t_eloc_fb;
-  if (B == 0) return FF_OK;
-  if (!fb.fused)
-    return ff_eloc_finish(stream, B, nup, ndn, tab_up, tab_dn, walker_state, Z, use_ho, x, workspace, logp, grad, lap, V, eloc,
-                          z_out, dlogp_out, glogp0_out);
-  // (routed pass: the walkers of the heavy route were finished inside launch_routed, in the shadow of the throughput kernel)
-  const size_t M = (size_t)n * 2;
-  ff_eloc_ws w = ff_eloc_carve(workspace, B, (size_t)n, 2);
-  if (z_out && hipMemcpyAsync(z_out, w.z0, sizeof(double) * (size_t)B * M, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
-  if (dlogp_out && hipMemcpyAsync(dlogp_out, w.dl, sizeof(double) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
-  return FF_OK;
+  return ff_eloc_nd(stream, B, nup, ndn, 2, tab_up, tab_dn, walker_state, net, ode, Z, use_ho, x, logp, grad, lap, V, eloc, z_out, dlogp_out,
+                    glogp0_out, workspace, stats);
 }
 
 }  // extern "C"

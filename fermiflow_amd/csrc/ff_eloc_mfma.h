@@ -557,7 +557,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     // determinants: coefficient-table loads by a per-lane index and 256 registers -- inlined here it took 0.5 ms per launch.)
     bool fin_done = false;
     if constexpr (N % 2 == 0 && D == 2) {
-      if (A.fin.on) {
+      if (A.fin.on & 1) {
         constexpr int NSF = N / 2;
         fin_done = true;
         int ln = lane;

@@ -45,7 +45,8 @@ struct ff_fwd_args {
   // lap, V, E_loc (src/VMC.py:46-55) and grad_z logp0 itself -- J^T never goes to HBM (Jt, kbar, dD, Lpart are not written;
   // y_out = z(t0) and dl_out = Delta still are: the adjoint reads them).  Any output pointer may be NULL.
   struct ff_fin_args {
-    int on, nup, ndn, use_ho;
+    int on;      // bit 0: the matrix-core kernel may fuse (nup = ndown <= 3), bit 1: the one-walker-per-workgroup kernels may (any shape)
+    int nup, ndn, use_ho;
     const int32_t *tab_up, *tab_dn, *wstate;
     double Z;
     double *logp, *grad, *lap, *V, *eloc, *glogp0;

@@ -14,43 +14,7 @@
 #include "ff_rng.h"
 #include "ff_eloc_ws.h"
 
-#define FF_HO3D_NORB 120        // shells 0..7 (Hermite degrees 0..7)
-#define FF_PI_M34 0.42377720812375763   // pi^(-3/4)
-
-FF_D void ff_ho3d_decode(int k, int& nx, int& ny, int& nz) {
-  int shell = 0;
-  while ((shell + 1) * (shell + 2) * (shell + 3) / 6 <= k) shell++;
-  int idx = k - shell * (shell + 1) * (shell + 2) / 6;
-  nx = ny = nz = 0;
-  for (int a = 0; a <= shell; a++) {
-    const int cnt = shell - a + 1;
-    if (idx < cnt) { nx = a; ny = idx; nz = shell - a - idx; return; }
-    idx -= cnt;
-  }
-}
-
-// phi_k at r and optionally its gradient (3) and Laplacian
-template <bool DERIV>
-FF_D void ff_orbital3d(int k, const double* r, double gauss /* pi^-3/4 exp(-r^2/2) */, double& v, double* g, double& lap) {
-  int n[3];
-  ff_ho3d_decode(k, n[0], n[1], n[2]);
-  double h[3], h1[3], h2[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) ff_herm<DERIV>(n[c], r[c], h[c], h1[c], h2[c]);
-  v = gauss * h[0] * h[1] * h[2];
-  if (DERIV) {
-    double p1[3], p2[3];   // (e^{-x^2/2} h)' / e^{-x^2/2}, (e^{-x^2/2} h)'' / e^{-x^2/2}
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      p1[c] = h1[c] - r[c] * h[c];
-      p2[c] = h2[c] - 2.0 * r[c] * h1[c] + (r[c] * r[c] - 1.0) * h[c];
-    }
-    g[0] = gauss * p1[0] * h[1] * h[2]; g[1] = gauss * h[0] * p1[1] * h[2]; g[2] = gauss * h[0] * h[1] * p1[2];
-    lap = gauss * (p2[0] * h[1] * h[2] + h[0] * p2[1] * h[2] + h[0] * h[1] * p2[2]);
-  }
-}
-
-FF_D double ff_gauss3d(const double* r) { return FF_PI_M34 * exp(-0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2])); }
+#include "ff_slater_rows.h"
 
 // log|det D| (D_ij = phi_j(r_i)) of ns particles; with grad: d/dr_i = sum_j grad phi_j(r_i) Dinv_ji (src/slater.py:51-61),
 // and the Laplacian sum_i [ sum_j lap phi_j(r_i) Dinv_ji - |grad_i|^2 ] (rank-one update of the determinant).
@@ -477,22 +441,6 @@ ff_backflow_f32_kernel(int64_t B, int n, int d, ff_net net, const double* __rest
 // with H0 of 2 log|det|: same-particle block sum_j hess phi_j(r_a) Dinv_ja - g_a g_a^T, cross block -T_ac (x) T_ca
 // (T_ac = sum_j grad phi_j(r_a) Dinv_jc) -- SURVEY.md A.2 / A.6 with one more coordinate.
 // Q slots per walker: [0,M) g0 | [M, M+6n) S (xx,xy,xz,yy,yz,zz per particle) | T_up (3 nup^2, component-major) | T_dn | 2 log|det| per spin
-template <bool DERIV>
-FF_D void ff_orbital3d_hess(int k, const double* r, double gauss, double& v, double* g, double* hs) {
-  int n[3];
-  ff_ho3d_decode(k, n[0], n[1], n[2]);
-  double h[3], h1[3], h2[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) ff_herm<true>(n[c], r[c], h[c], h1[c], h2[c]);
-  double p1[3], p2[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) { p1[c] = h1[c] - r[c] * h[c]; p2[c] = h2[c] - 2.0 * r[c] * h1[c] + (r[c] * r[c] - 1.0) * h[c]; }
-  v = gauss * h[0] * h[1] * h[2];
-  g[0] = gauss * p1[0] * h[1] * h[2]; g[1] = gauss * h[0] * p1[1] * h[2]; g[2] = gauss * h[0] * h[1] * p1[2];
-  hs[0] = gauss * p2[0] * h[1] * h[2]; hs[1] = gauss * p1[0] * p1[1] * h[2]; hs[2] = gauss * p1[0] * h[1] * p1[2];
-  hs[3] = gauss * h[0] * p2[1] * h[2]; hs[4] = gauss * h[0] * p1[1] * p1[2]; hs[5] = gauss * h[0] * h[1] * p2[2];
-}
-
 // Slater table of the local-energy finish, SIXTEEN LANES PER DETERMINANT (two walkers x two spin species per wave): lane r
 // of a group owns particle r of its species -- row r of D_ij = phi_j(r_i) and of the unit matrix beside it.  Gauss-Jordan
 // with partial pivoting, without moving rows: per column the unused lane with the largest entry becomes the pivot (16-lane
@@ -505,124 +453,16 @@ template <int D>
 __global__ void __launch_bounds__(FF_WAVE)
 ff_eloc_slater_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
                            const int* __restrict__ wstate, const double* __restrict__ z0, double* __restrict__ Q) {
-  constexpr int NS = FF_MAX_NS, NH2 = D * (D + 1) / 2;
-  __shared__ double s_row[4][2 * NS];           // the pivot row of the step: [A | Inv]
-  __shared__ double s_inv[4][NS][NS + 1];       // D^-1 by rows
-  __shared__ int s_orb[4][NS];
-  const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
+  __shared__ ff_slater_rows_smem<4> sm;
+  const int lane = threadIdx.x, grp = lane >> 4;
   const int64_t gid = (int64_t)blockIdx.x * 4 + grp;
   const int64_t b = gid >> 1;
   const int sp = (int)(gid & 1);
   const bool live = b < B;
   const int n = nup + ndn, M = D * n;
-  const int ns = live ? (sp ? ndn : nup) : 0, off = sp ? nup : 0;
   const int st = (live && wstate) ? wstate[b] : 0;
-  const int64_t nq = M + NH2 * n + D * (nup * nup + ndn * ndn) + 2;
-  double* q = Q + (live ? b : 0) * nq;
-  const bool mine = r < ns;
-  if (mine) s_orb[grp][r] = ((sp ? tab_dn : tab_up) + st * ns)[r];
-  __syncthreads();
-  double x[D];
-#pragma unroll
-  for (int c = 0; c < D; c++) x[c] = mine ? z0[b * M + D * (off + r) + c] : 0.25 * (c + 1 + r);
-  double gs;
-  if constexpr (D == 2) gs = ff_gauss2d(x[0], x[1]); else gs = ff_gauss3d(x);
-  double A[NS], Inv[NS];
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    double v = (j == r) ? 1.0 : 0.0;      // rows / columns beyond ns: the unit matrix (never chosen as pivots, eliminated with f = 0)
-    if (j < ns && mine) {
-      if constexpr (D == 2) ff_orbital<false>(s_orb[grp][j], x[0], x[1], gs, v, nullptr, nullptr);
-      else { double lp; ff_orbital3d<false>(s_orb[grp][j], x, gs, v, nullptr, lp); }
-    }
-    A[j] = v;
-    Inv[j] = (j == r) ? 1.0 : 0.0;
-  }
-  double acc = 0.0;
-  bool used = !mine;
-  int myrow = -1;
-  const int nsmax = nup > ndn ? nup : ndn;      // (kernel-uniform: columns beyond both determinants are skipped by a scalar branch)
-#pragma unroll
-  for (int c = 0; c < NS; c++) {
-    if (c >= nsmax) break;
-    const bool act = c < ns;      // (uniform within the group)
-    // pivot: the unused lane with the largest |A[c]| (ties: the lower lane)
-    double best = (!used && act) ? fabs(A[c]) : -1.0;
-    int who = r;
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-      const double ob = ff_lane_read(best, lane ^ m);
-      const int ow = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, who);
-      const bool take = ob > best || (ob == best && ow < who);
-      best = take ? ob : best;
-      who = take ? ow : who;
-    }
-    const bool ispiv = act && who == r && !used;
-    if (ispiv) {
-      const double ip = 1.0 / A[c];
-      acc = log(fabs(A[c]));
-#pragma unroll
-      for (int j = 0; j < NS; j++) { A[j] *= ip; Inv[j] *= ip; s_row[grp][j] = A[j]; s_row[grp][NS + j] = Inv[j]; }
-      used = true;
-      myrow = c;
-    }
-    __syncthreads();
-    if (act && !ispiv) {
-      const double f = A[c];
-#pragma unroll
-      for (int j = 0; j < NS; j++) { A[j] = fma(-f, s_row[grp][j], A[j]); Inv[j] = fma(-f, s_row[grp][NS + j], Inv[j]); }
-    }
-    __syncthreads();
-  }
-  if (myrow >= 0) {
-#pragma unroll
-    for (int j = 0; j < NS; j++) s_inv[grp][myrow][j] = Inv[j];
-  }
-  // log|det| = sum of the pivots' logs (each pivot lane holds one of them)
-  double lsum = (myrow >= 0) ? acc : 0.0;
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) lsum += ff_lane_read(lsum, lane ^ m);
-  __syncthreads();
-  if (live && ns == 0 && r == 0) q[nq - 2 + sp] = 0.0;
-  if (mine) {
-    double T[D][NS], S[NH2], gd[D];
-#pragma unroll
-    for (int c = 0; c < D; c++) {
-      gd[c] = 0.0;
-#pragma unroll
-      for (int j = 0; j < NS; j++) T[c][j] = 0.0;
-    }
-#pragma unroll
-    for (int e = 0; e < NH2; e++) S[e] = 0.0;
-    for (int j = 0; j < ns; j++) {
-      double v, g[D], hs[NH2];
-      if constexpr (D == 2) ff_orbital<true>(s_orb[grp][j], x[0], x[1], gs, v, g, hs);
-      else ff_orbital3d_hess<true>(s_orb[grp][j], x, gs, v, g, hs);
-      const double da = s_inv[grp][j][r];
-#pragma unroll
-      for (int bb = 0; bb < NS; bb++) {
-        const double di = s_inv[grp][j][bb];
-#pragma unroll
-        for (int c = 0; c < D; c++) T[c][bb] = fma(g[c], di, T[c][bb]);
-      }
-#pragma unroll
-      for (int c = 0; c < D; c++) gd[c] = fma(g[c], da, gd[c]);
-#pragma unroll
-      for (int e = 0; e < NH2; e++) S[e] = fma(hs[e], da, S[e]);
-    }
-#pragma unroll
-    for (int c = 0; c < D; c++) q[D * (off + r) + c] = 2.0 * gd[c];        // g0 = 2 grad log|det|
-#pragma unroll
-    for (int e = 0; e < NH2; e++) q[M + NH2 * (off + r) + e] = S[e];
-    double* Tq = q + M + NH2 * n + (sp ? D * nup * nup : 0);                // [comp][a][b]
-#pragma unroll
-    for (int c = 0; c < D; c++)
-#pragma unroll
-      for (int bb = 0; bb < NS; bb++) {
-        if (bb < ns) Tq[c * ns * ns + r * ns + bb] = T[c][bb];
-      }
-    if (r == 0) q[nq - 2 + sp] = 2.0 * lsum;
-  }
+  const int64_t nq = M + (D * (D + 1) / 2) * n + D * (nup * nup + ndn * ndn) + 2;
+  ff_slater_rows_body<D, 4>(sm, lane, grp, live, sp, nup, ndn, tab_up, tab_dn, st, z0 + (live ? b : 0) * M, Q + (live ? b : 0) * nq);
 }
 
 // launch for both dimensions (the d = 2 finish of ff_cnf_fwd.hip uses it beyond the register-resident 4 x 4 determinants)

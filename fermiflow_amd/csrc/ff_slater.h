@@ -123,6 +123,31 @@ FF_D void ff_herm_rec_d2(const int* n, double x, int md, double* h, double* h1, 
   }
 }
 
+// h_n(x), h_n'(x), h_n''(x) for ONE degree n <= 7, the recurrence fully unrolled over literal coefficients: no constant-memory
+// loads and no loop (a lane of the fused finish of ff_wide.hip evaluates one orbital; every table load there is an exposed
+// round trip).  Same numbers as ff_herm_rec_d2 (the same recurrence in the same order).
+FF_D void ff_herm_one_d2(int n, double x, double& h, double& h1, double& h2) {
+  constexpr double RA[7] = {1.4142135623730951, 1.0, 0.81649658092772603, 0.70710678118654752, 0.63245553203367588,
+                            0.57735026918962576, 0.53452248382484879};
+  constexpr double RB[7] = {0.0, 0.70710678118654752, 0.81649658092772603, 0.86602540378443865, 0.89442719099991588,
+                            0.91287092917527686, 0.92582009977255146};
+  constexpr double HD1[8] = {0.0, 1.4142135623730951, 2.0, 2.4494897427831779, 2.8284271247461903, 3.1622776601683795,
+                             3.4641016151377544, 3.7416573867739413};
+  constexpr double HD2[8] = {0.0, 0.0, 2.8284271247461903, 4.8989794855663558, 6.9282032302755088, 8.9442719099991592,
+                             10.954451150103322, 12.961481396815721};
+  double hm2 = 0.0, hm1 = 1.0, hc = RA[0] * x;
+  h = (n == 0) ? 1.0 : hc;
+  h1 = (n == 0) ? 0.0 : HD1[1];
+  h2 = 0.0;
+#pragma unroll
+  for (int m = 1; m < 7; m++) {
+    const double hn = fma(RA[m] * x, hc, -RB[m] * hm1);
+    hm2 = hm1; hm1 = hc; hc = hn;
+    const bool sel = n == m + 1;
+    h = sel ? hc : h; h1 = sel ? HD1[m + 1] * hm1 : h1; h2 = sel ? HD2[m + 1] * hm2 : h2;
+  }
+}
+
 // inverse (by the adjugate) and determinant of a register-resident matrix up to 3 x 3: Ainv[j][b], no pivot search, one reciprocal
 template <int NS>
 FF_D double ff_inv_small(const double (&A)[NS][NS], double (&Ai)[NS][NS]) {

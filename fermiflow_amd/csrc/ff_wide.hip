@@ -33,6 +33,7 @@
 #include "ff_dp5.h"
 #include "ff_radial.h"
 #include "ff_fwd_args.h"
+#include "ff_slater_rows.h"
 
 // FF_STAMPS: diagnostic build only (make variant NAME=stamps EXTRA=-DFF_STAMPS; tools/probes/wide_c5.py): s_memtime shares
 // of the phases of the local-energy kernel's right-hand side, added into stats[8..] as 64-bit counters by wave 0.
@@ -287,7 +288,10 @@ FF_D double ff_quad_sum(double v) {
 #ifndef FF_WIDE_T1_WAVES
 #define FF_WIDE_T1_WAVES 1
 #endif
-template <int D, int T, bool TAB, class TJ>
+// FIN: with the fused finish (ff_ode::compact_finish) as the epilogue of every walker.  A template parameter, not a run-time branch: the
+// epilogue's registers and LDS would otherwise weigh on the instantiations that run without it -- the T = 1 kernel of the heavy-walker
+// route went from 292 to 380 registers and config 2's pass from 0.809 to 0.832 ms with the branch merely compiled in.
+template <int D, int T, bool TAB, class TJ, bool FIN>
 __global__ void __launch_bounds__(FF_WAVE * T, T == 1 ? FF_WIDE_T1_WAVES : 1)
 ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   typedef ff_wide_mma<TJ> MMA;
@@ -362,6 +366,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
+  bool degrees_known = false;      // (fused finish: the orbitals' Hermite degrees are in LDS)
   for (int64_t bq = blockIdx.x;; bq += gridDim.x) {
     if (A.queue) {   // persistent grid: next walker from the launch's work counter (heavy walkers sit at the front)
       __syncthreads();
@@ -642,6 +647,146 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #pragma unroll
       for (int v = 0; v < 4; v++) s_J[MMA::row(K, v, lg) * JS + 16 * w + lc] = yJ[4 * K + v];
     __syncthreads();
+    // -------------------------------------------------------------------- fused finish (ff_eloc; workgroup-uniform branch)
+    // What ff_eloc_slater_rows_kernel + the contraction kernels did from the workspace -- 8 M^2 bytes per walker written and read
+    // back: 4.09 GB per launch at configs[4] -- on the workgroup that still holds J (src/utils.py:56-63, src/VMC.py:48-55):
+    //   grad_x logp = J^T g0 - grad Delta          lap_x logp = tr(H0 J J^T) + g0 . kbar - lap Delta
+    // The Slater table of z(t0) built by the whole workgroup (ff_slater_table_wg, ff_slater_rows.h) into LDS; S = J J^T of the final J
+    // on the matrix cores exactly as every right-hand side forms it (in the precision of the sensitivity matrices).
+    if constexpr (FIN) {
+      __shared__ ff_slater_rows_smem<2> s_sl;
+      constexpr int NH2 = D * (D + 1) / 2;
+      // scratch of ff_slater_table_wg: (species, particle, orbital) entries for the largest nup^2 + ndn^2 this instantiation can meet
+      constexpr int NSA = NCAP < FF_MAX_NS ? NCAP : FF_MAX_NS, NSQ = NSA * NSA + (NCAP - NSA) * (NCAP - NSA);
+      __shared__ double s_orbv[(1 + D + NH2) * NSQ];
+      __shared__ int s_odeg[D * NCAP];
+      const int nup = A.fin.nup, ndn = A.fin.ndn;
+      double* const qs = s_rec;                                   // the walker's Slater slots (layout: ff_slater_rows.h), records are dead
+      const int oS = M, oT = M + NH2 * n, oL = oT + D * (nup * nup + ndn * ndn);
+      const double xown = own ? A.y_in[b * M + rp] : 0.0;        // (for V(x), requested here: an exposed round trip otherwise)
+      if (own) s_z[rp] = y[IZ];
+      if (A.fin.wstate != nullptr || !degrees_known) {             // one orbital set for every walker: decoded once per kernel
+        ff_slater_wg_degrees<D>(s_odeg, tid, nup, ndn, A.fin.tab_up, A.fin.tab_dn, A.fin.wstate ? A.fin.wstate[b] : 0);
+        degrees_known = true;
+      }
+      __syncthreads();
+      ff_slater_table_wg<D, NTHR>(s_sl, s_orbv, s_odeg, tid, nup, ndn, s_z, qs);
+      // S = J J^T of the final J on the matrix cores, as every right-hand side forms it (tiles (I, w)) -> s_A (A is dead)
+      {
+        typename MMA::acc_t accF[T];
+#pragma unroll
+        for (int I = 0; I < T; I++) { const typename MMA::acc_t zero = {0, 0, 0, 0}; accF[I] = zero; }
+        const TJ* Jb = &s_J[(16 * w + lc) * JS + lg];
+        const TJ* Ja = &s_J[lc * JS + lg];
+#pragma unroll
+        for (int K = 0; K < T; K++) {
+          if (16 * K < M) {      // workgroup-uniform
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              const int ks = 4 * K + v;
+              const TJ bS = Jb[4 * ks];
+              TJ aS[T];
+#pragma unroll
+              for (int I = 0; I < T; I++) aS[I] = Ja[16 * I * JS + 4 * ks];
+#pragma unroll
+              for (int I = 0; I < T; I++) accF[I] = MMA::mma(aS[I], bS, accF[I]);
+            }
+          }
+        }
+#pragma unroll
+        for (int I = 0; I < T; I++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) s_A[MMA::row(I, v, lg) * JS + 16 * w + lc] = accF[I][v];
+      }
+      __syncthreads();
+      // tr(H0 S): thread t takes the same-spin particle pairs (a, c) = t, t + NTHR, ... of both species
+      double trp = 0.0;
+      {
+        const int npu = nup * nup, npt = npu + ndn * ndn;
+        for (int e = tid; e < npt; e += NTHR) {
+          const int sp = e >= npu ? 1 : 0, ee = sp ? e - npu : e, ns = sp ? ndn : nup, off = sp ? nup : 0;
+          const int a = ee / ns, c = ee - a * ns;
+          const double* Tq = qs + oT + (sp ? D * npu : 0);         // [comp][a][b]
+          double Sb[D][D];
+#pragma unroll
+          for (int u = 0; u < D; u++)
+#pragma unroll
+            for (int v2 = 0; v2 < D; v2++) Sb[u][v2] = (double)s_A[(D * (off + a) + u) * JS + D * (off + c) + v2];
+          double q = 0.0;
+#pragma unroll
+          for (int u = 0; u < D; u++)
+#pragma unroll
+            for (int v2 = 0; v2 < D; v2++) q = fma(Tq[u * ns * ns + a * ns + c] * Tq[v2 * ns * ns + c * ns + a], Sb[u][v2], q);
+          q = -q;
+          if (a == c) {      // the same-particle block: sum_j hess phi_j(r_a) Dinv_ja, upper triangle (xx, xy[, xz], yy[, yz, zz])
+            const double* Sa = qs + oS + NH2 * (off + a);
+            int k = 0;
+#pragma unroll
+            for (int u = 0; u < D; u++)
+#pragma unroll
+              for (int v2 = u; v2 < D; v2++) { q = fma((u == v2 ? 1.0 : 2.0) * Sa[k], Sb[u][v2], q); k++; }
+          }
+          trp += 2.0 * q;
+        }
+      }
+      // grad_x logp: direction i on thread i
+      double gradi = 0.0, gki = 0.0;
+      if (tid < M) {
+        double t = 0.0;
+        for (int k = 0; k < M; k++) t = fma(qs[k], (double)s_J[k * JS + tid], t);
+        gradi = t - (double)s_J[M * JS + tid];
+      }
+      if (own) gki = qs[rp] * y[IK];
+      const double lapv = gsum(trp + gki) - lapd;
+      const double g2 = gsum(gradi * gradi);
+      const double logp0 = qs[oL] + qs[oL + 1];
+      const double g0own = own ? qs[rp] : 0.0;
+      // V(x) on the radius lanes
+      __syncthreads();
+      if (own) s_z[rp] = xown;
+      __syncthreads();
+      double vl = 0.0;
+#pragma unroll
+      for (int qk = 0; qk < NQ; qk++) {
+        const int id = rq_id[qk];
+        if (id < 0) break;
+        const int a = id & 31, bb0 = (id >> 5) & 31;
+        const bool pair = bb0 != 31;
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; c++) {
+          const double dlt = s_z[a * D + c] - (pair ? s_z[bb0 * D + c] : 0.0);
+          r2 = fma(dlt, dlt, r2);
+        }
+        vl += pair ? A.fin.Z / sqrt(r2) : (A.fin.use_ho ? 0.5 * r2 : 0.0);
+      }
+      if (!has_mu && A.fin.use_ho && own) { const double xv = s_z[rp]; vl = fma(0.5 * xv, xv, vl); }   // (no one-body radii without mu)
+      const double Vv = gsum(vl);
+      if (tid < M) {
+        if (A.fin.grad) A.fin.grad[b * M + tid] = gradi + bad;
+      }
+      if (own) {
+        A.y_out[b * M + rp] = y[IZ] + bad;
+        if (A.fin.glogp0) A.fin.glogp0[b * M + rp] = g0own + bad;
+      }
+      if (tid == 0) {
+        A.dl_out[b] = delta + bad;
+        if (A.fin.logp) A.fin.logp[b] = logp0 - delta + bad;
+        if (A.fin.lap) A.fin.lap[b] = lapv + bad;
+        if (A.fin.V) A.fin.V[b] = Vv;
+        if (A.fin.eloc) A.fin.eloc[b] = -0.25 * lapv - 0.125 * g2 + Vv + bad;
+        if (A.h_out) A.h_out[b] = C.hmax_acc > 0.0 ? C.hmax_acc : hwarm0;
+        if (A.wcost) A.wcost[b] = S.nacc + S.nrej;
+        if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
+      }
+      // (the records are rewritten by every evaluation, the all-zero record behind the last one must be zero again -- and so must
+      // the padding of A, which S has just overwritten)
+      __syncthreads();
+      for (int e = tid; e < (RCAP + 1) * RW; e += NTHR) s_rec[e] = 0.0;
+      for (int e = tid; e < MP * JS; e += NTHR) s_A[e] = (TJ)0;
+      __syncthreads();
+      continue;
+    }
     // Jt[b][i][p] = dz_p/dx_i: wave w writes the rows i = w, w + T, ... as contiguous spans
     for (int i = w; i < M; i += T) {
       if (l < M) A.Jt[(b * M + i) * M + l] = (double)s_J[l * JS + i];
@@ -730,16 +875,25 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
   const int64_t cap = a.queue ? per_cu * wide_cus() : ((int64_t)1 << 20);
   const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
   // single-precision sensitivities (ff_set_sens_precision(32)): the table kernel with J, A, S in fp32; its fallback stays fp64
-  if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float>), grid, FF_WAVE * T, stream, a, n);
-  else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double>), grid, FF_WAVE * T, stream, a, n);
-  FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double>), grid, FF_WAVE * T, stream, a, n);
+  if (a.fin.on & 2) {      // fused finish (ff_ode::compact_finish)
+    if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float, true>), grid, FF_WAVE * T, stream, a, n);
+    else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double, true>), grid, FF_WAVE * T, stream, a, n);
+    FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double, true>), grid, FF_WAVE * T, stream, a, n);
+    return;
+  }
+  if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float, false>), grid, FF_WAVE * T, stream, a, n);
+  else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double, false>), grid, FF_WAVE * T, stream, a, n);
+  FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double, false>), grid, FF_WAVE * T, stream, a, n);
 }
 
 int ff_wide_eloc_heavy(void* stream, int n, int d, const ff_fwd_args& a, int64_t max_groups) {
   if (!ff_wide_supported(n, d) || (n * d + 4 + 15) / 16 != 1 || !a.evt || a.queue) return FF_EUNSUPPORTED;   // (table kernel, T = 1, grid-stride)
   const unsigned grid = (unsigned)(a.B < max_groups ? a.B : max_groups);
-  if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double>), grid, FF_WAVE, stream, a, n);
-  else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double>), grid, FF_WAVE, stream, a, n);
+  if (a.fin.on & 2) {
+    if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double, true>), grid, FF_WAVE, stream, a, n);
+    else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double, true>), grid, FF_WAVE, stream, a, n);
+  } else if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double, false>), grid, FF_WAVE, stream, a, n);
+  else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double, false>), grid, FF_WAVE, stream, a, n);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }

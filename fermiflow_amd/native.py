@@ -223,33 +223,46 @@ def cnf_adjoint(net, y_start, a_z, a_d, t_from, t_to, rtol, atol, need_gx=True, 
     return (gx, gp, st) if want_stats else (gx, gp)
 
 
+COMPACT_WORKSPACE_BYTES = 32 << 30     # eloc(compact=None): beyond this many bytes of full workspace, ask for the compact one
+
+
 def eloc(tab_up, tab_dn, nup, ndn, net, x, t0, t1, rtol, atol, Z, use_ho, walker_state=None, want_stats=False,
-         pass1_events=None, walker_cost=None, walker_order=None, two_pass=False, **warm):
+         pass1_events=None, walker_cost=None, walker_order=None, two_pass=False, compact=None, **warm):
     """ff_eloc.  pass1_events: optional (start, end) torch.cuda.Event pair recorded around the sensitivity pass
     (bench.py times the dominant kernel with it).  two_pass: ff_eloc_sensitivities + ff_eloc_finish as separate calls with the
-    sensitivities in the workspace between them (the path every kernel without a fused finish takes anyway)."""
+    sensitivities in the workspace between them (the path every kernel without a fused finish takes anyway).
+    compact: ff_ode::compact_finish -- the one-walker-per-workgroup kernels finish their walkers themselves and the workspace
+    beyond 24 coordinates is z(t0) | Delta only; slower by 6-8 % (include/fermiflow.h), so the default (None) asks for it only when
+    the full workspace would pass COMPACT_WORKSPACE_BYTES."""
     x = L.dev(x, name="x")
     B, n, d = x.shape[0], nup + ndn, x.shape[2]
     f = dict(dtype=torch.float64, device=x.device)
-    nbytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, d)
+    M = n * d
+    full_bytes = L.lib().ff_eloc_workspace_bytes(L.i64(B), n, d)
+    if compact is None:
+        compact = M > 24 and full_bytes > COMPACT_WORKSPACE_BYTES
+    if two_pass and compact:
+        raise ValueError("two_pass keeps the sensitivities in the workspace: not with compact=True")
+    compact_layout = bool(compact) and M > 24       # ff_eloc_nd beyond 24 coordinates: z(t0) | Delta only (include/fermiflow.h)
+    nbytes = L.lib().ff_eloc_nd_workspace_bytes(L.i64(B), n, d, int(bool(compact))) if not two_pass else full_bytes
     ws = torch.empty(max(1, nbytes // 8), **f)
     # z(t0) and Delta stay where the sensitivity pass leaves them: views of the workspace (its documented head, include/fermiflow.h)
     # instead of two device-to-device copies per sweep
-    M = n * d
+    dl0 = B * M if compact_layout else B * (M * M + 4 * M)
     out = dict(logp=torch.empty(B, **f), grad=torch.empty_like(x), lap=torch.empty(B, **f), V=torch.empty(B, **f),
-               eloc=torch.empty(B, **f), z=ws[:B * M].view(B, n, d), dlogp=ws[B * (M * M + 4 * M):B * (M * M + 4 * M) + B],
+               eloc=torch.empty(B, **f), z=ws[:B * M].view(B, n, d), dlogp=ws[dl0:dl0 + B],
                glogp0=torch.empty_like(x))
     st = _stats(x.device, want_stats)
-    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, **warm)
+    o = L.ode(t0, t1, rtol, atol, walker_cost=walker_cost, walker_order=walker_order, compact_finish=bool(compact), **warm)
     if pass1_events is not None:
         pass1_events[0].record()
-    if d == 2 and not two_pass:
+    if not two_pass:
         # one call: the library fuses the finish into the sensitivity kernel where that kernel implements it (then the second
-        # event of pass1_events closes the whole pass: nothing is left to run behind it but the few walkers of the heavy route)
-        L.check(L.lib().ff_eloc(L.stream(), L.i64(B), nup, ndn, L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)), net.ref(),
-                                C.byref(o), L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(out["logp"]), L.ptr(out["grad"]),
-                                L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None, None, L.ptr(out["glogp0"]), L.ptr(ws),
-                                L.ptr(st)), "ff_eloc")
+        # event of pass1_events closes the whole pass)
+        L.check(L.lib().ff_eloc_nd(L.stream(), L.i64(B), nup, ndn, int(d), L.ptr(tab_up), L.ptr(tab_dn), L.ptr(_state(walker_state)), net.ref(),
+                                   C.byref(o), L.f64(Z), int(bool(use_ho)), L.ptr(x), L.ptr(out["logp"]), L.ptr(out["grad"]),
+                                   L.ptr(out["lap"]), L.ptr(out["V"]), L.ptr(out["eloc"]), None, None, L.ptr(out["glogp0"]), L.ptr(ws),
+                                   L.ptr(st)), "ff_eloc_nd")
         if pass1_events is not None:
             pass1_events[1].record()
     else:

@@ -85,9 +85,17 @@ typedef struct ff_ode {
   int32_t heavy_class;
   double heavy_tol;
   double sum_weight;
+  /* ff_eloc_nd only.  Nonzero: the one-walker-per-workgroup kernels (every shape beyond 12 particles in d = 2 / 8 in d = 3, and the
+   * heavy-walker route) finish their walkers in their own epilogue, so that beyond 24 coordinates NO sensitivity goes to HBM and the
+   * workspace is the compact one of ff_eloc_nd_workspace_bytes(.., 1): 8 (M + 1) bytes per walker instead of 8 (M^2 + ...) -- 64 MB
+   * instead of 3.9 GB at configs[4].  It costs time (the epilogue runs on a workgroup that holds the compute unit alone, where the
+   * separate finish kernels fill the chip): local-energy pass + 6 % at configs[4], + 8 % at 12 particles.  0 (the
+   * default): those kernels leave the sensitivities in the workspace and the finish kernels run.  The same value must be given
+   * to ff_eloc_nd_workspace_bytes. */
+  int32_t compact_finish;
 } ff_ode;
 
-int ff_version(void);   /* 103; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 104; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
@@ -225,7 +233,8 @@ int ff_cnf_adjoint_energy(void* stream, int64_t B, int n, int d, const ff_net* n
  *   V = Coulomb + trap,  eloc = -lap/4 - |grad|^2/8 + V.
  * Any of logp, grad, lap, V, eloc may be NULL.  Optional extra outputs (may be NULL): z_out (B,n,2) = z(t0),
  * dlogp_out (B) = delta, glogp0_out (B,n,2) = grad_z logp0(z(t0)).
- * workspace: ff_eloc_workspace_bytes(B, n, 2) bytes of device memory (the sensitivities between the launches).
+ * workspace: ff_eloc_workspace_bytes(B, n, 2) bytes of device memory (the sensitivities between the launches; more than 12 particles:
+ * ff_eloc_nd_workspace_bytes, see ff_eloc_nd).
  * Its head is part of the contract, for callers that want z(t0) and delta without a copy (z_out = dlogp_out = NULL): with
  * M = n d, doubles [0, B M) hold z(t0) (B,n,d) and doubles [B (M^2 + 4 M), B (M^2 + 4 M) + B) hold delta (B) once pass 1 has
  * run; both stay valid until the workspace is reused. */
@@ -235,7 +244,19 @@ int ff_eloc(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, co
             const double* x, double* logp, double* grad, double* lap, double* V, double* eloc,
             double* z_out, double* dlogp_out, double* glogp0_out, void* workspace, int32_t* stats);
 
-/* The two launches of ff_eloc individually (same arguments; results of pass 1 stay in `workspace`). */
+/* ff_eloc for d = 2 or 3 (walkers (B, n, d); d = 3: HO3D orbital tables), and the form the sweeps call.  Where the sensitivity
+ * kernel implements it -- the matrix-core kernel for nup = ndown <= 3 in d = 2 always; the one-walker-per-workgroup kernels with
+ * ode->compact_finish -- the finish is the kernel's own epilogue: logp, grad, lap, V, eloc, glogp0_out are written by the kernel that
+ * integrated the walker and J^T never goes to HBM.  workspace: ff_eloc_nd_workspace_bytes(B, n, d, ode->compact_finish) bytes -- the
+ * layout of ff_eloc_workspace_bytes, except with compact_finish beyond 24 coordinates (only kernels with that epilogue serve those
+ * shapes): the COMPACT layout z(t0) (B, M) | Delta (B) | two counters.  ff_eloc is ff_eloc_nd with d = 2. */
+size_t ff_eloc_nd_workspace_bytes(int64_t B, int n, int d, int compact_finish);
+int ff_eloc_nd(void* stream, int64_t B, int nup, int ndn, int d, const int32_t* tab_up, const int32_t* tab_dn,
+               const int32_t* walker_state, const ff_net* net, const ff_ode* ode, double Z, int use_ho,
+               const double* x, double* logp, double* grad, double* lap, double* V, double* eloc,
+               double* z_out, double* dlogp_out, double* glogp0_out, void* workspace, int32_t* stats);
+
+/* The two launches of ff_eloc individually (same arguments; results of pass 1 stay in `workspace`; always the full layout). */
 int ff_eloc_sensitivities(void* stream, int64_t B, int n, int d, const ff_net* net, const ff_ode* ode,
                           const double* x, void* workspace, int32_t* stats);
 int ff_eloc_finish(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,

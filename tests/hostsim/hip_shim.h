@@ -115,23 +115,24 @@ inline unsigned long long wall_clock64() {      // 100 MHz, as the GPU's constan
 }
 #define __expf expf
 static int ff_sim_xlane_buf[1024];
-// v_mov_b32 with a DPP quad permutation (ctrl < 0x100: two bits per lane of the quad)
+// v_mov_b32 with a DPP quad permutation (ctrl < 0x100: two bits per lane of the quad).  Cross-lane operations are WAVE-level on the
+// hardware: the emulation synchronises the 64 threads of the caller's wave only (every lane of that wave must call).
 inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) {
   const unsigned t = threadIdx.x;
   ff_sim_xlane_buf[t] = v;
-  __syncthreads();
+  FF_WAVE_SYNC();
   const int o = (ctrl >= 0x121 && ctrl <= 0x12F) ? ff_sim_xlane_buf[(t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15)]      // row_ror:n within 16 lanes
                                                  : ff_sim_xlane_buf[(t & ~3u) | ((ctrl >> (2 * (t & 3))) & 3)];
-  __syncthreads();
+  FF_WAVE_SYNC();
   return o;
 }
 // ds_bpermute_b32: lane (addr / 4) % 64 of the caller's own wave
 inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
   const unsigned t = threadIdx.x;
   ff_sim_xlane_buf[t] = v;
-  __syncthreads();
+  FF_WAVE_SYNC();
   const int o = ff_sim_xlane_buf[(t & ~63u) | ((addr >> 2) & 63)];
-  __syncthreads();
+  FF_WAVE_SYNC();
   return o;
 }
 // wave vote (the kernels only ask whether any lane of a single-wave workgroup voted yes)

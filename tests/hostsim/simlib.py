@@ -22,7 +22,8 @@ class FFOde(C.Structure):
                 ("max_steps", C.c_int32), ("walker_cost", C.c_void_p), ("walker_order", C.c_void_p),
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
-                ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double)]
+                ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double),
+                ("compact_finish", C.c_int32)]
 
 
 def build():
@@ -173,13 +174,13 @@ def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, wclas
                  h_scale_loose=h_scale_loose, heavy_class=heavy_class, heavy_tol=heavy_tol, sum_weight=sum_weight)
 
 
-def _ode(t0, t1, rtol, atol, steps=None, order=None):
+def _ode(t0, t1, rtol, atol, steps=None, order=None, compact=False):
     q = lambda a: a.ctypes.data if a is not None else None
     qi = q
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
                  q(_WARM.get("h_out")), qi(_WARM.get("wclass")), float(_WARM.get("sens_tol", 1.0)), float(_WARM.get("h_scale_loose", 0.0)),
                  int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))), int(_WARM.get("heavy_class", 0)),
-                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)))
+                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)), int(bool(compact)))
 
 
 def walker_order(cost, hval=None):
@@ -229,6 +230,25 @@ def eloc(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8,
                       int(use_ho), _p(x), _p(o["logp"]), _p(o["grad"]), _p(o["lap"]), _p(o["V"]), _p(o["eloc"]),
                       _p(o["z"]), _p(o["dlogp"]), _p(o["glogp0"]), _p(wk), _p(stats)))
     o["stats"] = stats
+    return o
+
+
+def eloc_nd(x, nup, ndn, net, Z, use_ho=True, t0=0.0, t1=1.0, rtol=1e-6, atol=1e-8, tab_up=None, tab_dn=None, wstate=None, compact=True):
+    """ff_eloc_nd (d from x) with ff_ode.compact_finish; z / dlogp are read from the head of the workspace."""
+    x = _d(x); B, n, d = x.shape
+    tu, td = _tabs(nup, ndn, tab_up, tab_dn); ws = _i(wstate) if wstate is not None else None
+    o = dict(logp=np.empty(B), grad=np.empty_like(x), lap=np.empty(B), V=np.empty(B), eloc=np.empty(B), glogp0=np.empty_like(x))
+    stats = np.zeros(4, dtype=np.int32); ode = _ode(t0, t1, rtol, atol, compact=compact)
+    lib().ff_eloc_nd_workspace_bytes.restype = C.c_size_t
+    nb = lib().ff_eloc_nd_workspace_bytes(C.c_int64(B), n, d, int(bool(compact)))
+    wk = np.zeros(nb // 8)
+    _ck(lib().ff_eloc_nd(None, C.c_int64(B), nup, ndn, d, _p(tu), _p(td), _p(ws), C.byref(net.c), C.byref(ode), C.c_double(Z),
+                         int(use_ho), _p(x), _p(o["logp"]), _p(o["grad"]), _p(o["lap"]), _p(o["V"]), _p(o["eloc"]),
+                         None, None, _p(o["glogp0"]), _p(wk), _p(stats)))
+    M = n * d
+    o["z"] = wk[:B * M].reshape(B, n, d).copy()
+    dl0 = B * M if (compact and M > 24) else B * (M * M + 4 * M)
+    o["dlogp"] = wk[dl0:dl0 + B].copy(); o["stats"] = stats; o["workspace_bytes"] = nb
     return o
 
 

@@ -170,6 +170,17 @@ def test_config5_local_energy_vs_oracle(dev, bits, capsys):
     with capsys.disabled():
         print(f"\n[config 5, {bits}-bit sensitivity matrices] 24 walkers: max rel E_loc error vs oracle {rel.max():.2e}")
     assert rel.max() < ELOC_RTOL, rel.max()
+    # ff_ode.compact_finish: the same walkers finished in the sensitivity kernel's epilogue (compact workspace), same bar
+    prev = native.set_sens_precision(bits)
+    try:
+        tu, td = model._tables(dev)
+        rc = native.eloc(tu, td, 10, 10, model.cnf.v_wrapper.v.net(), model.x[:nb].contiguous(), 0.0, 1.0, 1e-6, 1e-8, 2.0, True, compact=True)
+    finally:
+        native.set_sens_precision(prev)
+    relc = np.abs(N(rc["eloc"]) - ref["eloc"]) / np.abs(ref["eloc"])
+    with capsys.disabled():
+        print(f"[config 5, {bits}-bit, finish fused into the sensitivity kernel] max rel E_loc error vs oracle {relc.max():.2e}")
+    assert relc.max() < ELOC_RTOL, relc.max()
     if bits == 32:
         return
     # stand-alone calls at a tight tolerance: flow, log-density and the adjoint's parameter gradient
@@ -190,6 +201,38 @@ def test_config5_local_energy_vs_oracle(dev, bits, capsys):
     gxo, gpo, _ = O.cnf_adjoint(zo, dlo, az, ad, net, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(N(gx), gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
     np.testing.assert_allclose(N(gp), gpo, atol=1e-6 * np.abs(gpo).max())
+
+
+@pytest.mark.parametrize("nup,ndn,dim", [(3, 3, 2), (2, 1, 2), (7, 6, 2), (12, 12, 2), (5, 4, 3), (10, 10, 3)])
+def test_compact_finish_equals_the_finish_kernels(dev, nup, ndn, dim):
+    """ff_ode.compact_finish: the one-walker-per-workgroup kernels finish their walkers in their epilogue (tr(H0 J J^T) on the matrix
+    cores, Slater table built by the workgroup; beyond 24 coordinates nothing but z(t0) and Delta in the workspace) -- every output
+    against the separate finish kernels on the same sensitivities."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, nup, ndn, 2.0) if dim == 2 else _model3d(dev, nup, ndn, 2.0, False)
+    v = model.cnf.v_wrapper.v
+    B = 200
+    torch.manual_seed(31 + nup)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    prev = native.set_kernel_family(1)
+    try:
+        net = v.net(refresh=True)
+        x = native.cnf_generate(net, z, 0.0, 1.0, 1e-8, 1e-10)
+        tu, td = model._tables(dev)
+        a = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-8, 1e-10, 2.0, True, compact=False)
+        b = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-8, 1e-10, 2.0, True, compact=True)
+    finally:
+        native.set_kernel_family(prev)
+    M = (nup + ndn) * dim
+    assert b["z"].untyped_storage().nbytes() < (a["z"].untyped_storage().nbytes() if M > 24 else 1 << 62)
+    if M > 24:
+        assert b["z"].untyped_storage().nbytes() == 8 * (B * (M + 1) + 2)
+    for k in ("z", "dlogp"):
+        assert torch.equal(a[k], b[k]), k      # the same integration
+    for k in ("logp", "V", "eloc", "lap", "grad", "glogp0"):
+        sc = max(1.0, a[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() < 1e-9 * sc, (k, (a[k] - b[k]).abs().max().item(), sc)
 
 
 def test_wide_direct_evaluation_equals_the_table_path(dev):

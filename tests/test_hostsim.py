@@ -2,6 +2,8 @@
 barriers) checked against the golden vectors and the oracle.  This exercises the kernels' logic -- lane
 mapping, LDS hand-offs, step control, reductions -- in the GPU-less build container; the `-m gpu` tests in
 test_gpu_parity.py are the parity tests proper (hipcc build, through the C ABI, on the MI355X)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -684,6 +686,12 @@ def test_one_walker_per_workgroup_kernels(nup, ndn, d, B, force):
             np.testing.assert_allclose(r["eloc"], ref["eloc"], rtol=1e-6)
             np.testing.assert_allclose(r["grad"], ref["grad"], atol=1e-6 * max(1.0, np.abs(ref["grad"]).max()))
             np.testing.assert_allclose(r["logp"], ref["logp"], atol=1e-7)
+            # ff_ode.compact_finish: the same kernel finishes its walkers in its epilogue -- against the separate finish kernels
+            rc = S.eloc_nd(xo, nup, ndn, net, 2.0, compact=True, **tol)
+            assert rc["stats"][3] == 0
+            assert rc["workspace_bytes"] == (8 * (B * (n * d + 1) + 2) if n * d > 24 else S.lib().ff_eloc_workspace_bytes(C.c_int64(B), n, d))
+            for k in ("logp", "grad", "lap", "V", "eloc", "glogp0", "z", "dlogp"):
+                np.testing.assert_allclose(rc[k], r[k], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(r[k]).max()), err_msg=k)
             gx, gp, st = S.cnf_adjoint(zo, az, ad, net, **tol)
             np.testing.assert_allclose(gx, gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
             np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
