@@ -122,7 +122,9 @@ class _Sweep:
     step-size warm start, the lazily converted device scalars, and the checkpointable sweep state."""
 
     def _init_sweep(self, n):
-        self.profile = None          # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats
+        # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats.  {"stages": False}: only the event pair around the
+        # local-energy pass and its statistics -- every stage marker is a hipEventRecord, ~8 us of pipeline bubble on this GPU
+        self.profile = None
         # ODE step-size warm start inside the sweep (DESIGN.md 4); FERMIFLOW_WARM_START=0 restores the cold start
         self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
         self._h_flow = None          # previous sweep's accepted flow steps: per walker (persistent walkers) or their mean
@@ -148,7 +150,7 @@ class _Sweep:
         self.sum_weight = float(os.environ.get("FERMIFLOW_SUM_WEIGHT", "0"))
 
     def _mark(self, ev, name):
-        if self.profile is not None:
+        if self.profile is not None and self.profile.get("stages", True):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             ev[name] = e
@@ -390,7 +392,8 @@ class GSVMC(_Sweep, torch.nn.Module):
         has fired plus a short delay, so that the adjoint's waves are placed first (tools/probes/overlap.py: the other order
         serialises the two kernels)."""
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            # (FERMIFLOW_PREFETCH_PRIORITY: stream priority of the sampler's stream, lower number = served first; default 0)
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
             # One short kernel in front of the sampler lets the adjoint's waves be placed first -- with nothing here the Metropolis

@@ -228,6 +228,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = ff_adjtab_geom<N, D>::G, P = Gm::P, R = Gm::RA;
   constexpr int NV = 2, NSLOT = (G * R + FF_WAVE - 1) / FF_WAVE;
+#ifdef FF_PRIO_ADJTAB
+  FF_SETPRIO();
+#endif
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
 
@@ -621,6 +624,7 @@ extern int ff_wide_supported(int n, int d);
 __global__ void __launch_bounds__(FF_DEPR_EX * FF_DEPR_TY)
 ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows, int P, const double* __restrict__ prow,
                      double* __restrict__ out, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot) {
+  FF_SETPRIO();
   const double* rtab = net.radial_table;
   const bool tab_served = rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0;
   if ((int)blockIdx.x < P) {
@@ -647,16 +651,20 @@ ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows
   const int tx = threadIdx.x % FF_DEPR_EX, ty = threadIdx.x / FF_DEPR_EX;
   const int e = bid * FF_DEPR_EX + tx;
   constexpr int NE = 2 * FF_DEP_NLDS * FF_DEP_ROW;
-  double s0 = 0.0, s1 = 0.0;
+  // eight independent partial sums: eight loads in flight per thread.  (Thirty-two were worse, 64 us against 30: the kernel runs beside
+  // the prefetched Metropolis kernel, which owns most of the issue slots -- what decides its time is how soon its waves get placed.)
+  double sp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (e < NE) {
     int b = ty;
-    for (; b + FF_DEPR_TY < nblocks; b += 2 * FF_DEPR_TY) {
-      s0 += rows[(size_t)b * NE + e];
-      s1 += rows[(size_t)(b + FF_DEPR_TY) * NE + e];
+    for (; b + 7 * FF_DEPR_TY < nblocks; b += 8 * FF_DEPR_TY) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) sp[u] += rows[(size_t)(b + u * FF_DEPR_TY) * NE + e];
     }
-    if (b < nblocks) s0 += rows[(size_t)b * NE + e];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (b + u * FF_DEPR_TY < nblocks) sp[u] += rows[(size_t)(b + u * FF_DEPR_TY) * NE + e];
   }
-  sm[ty][tx] = s0 + s1;
+  sm[ty][tx] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
   __syncthreads();
   for (int w = FF_DEPR_TY / 2; w > 0; w >>= 1) {
     if (ty < w) sm[ty][tx] += sm[ty + w][tx];
@@ -669,30 +677,50 @@ ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows
 }
 
 // grad[theta] = sum_{j,k} Wtot[t][j][k] dT[t][j][k]/dtheta,  T[j][k] = sum_h w2 w1^k sigma^(k)(w1 r_j + b1);
-// one workgroup per hidden unit, lanes over the nodes, fixed-tree reduction
+// one workgroup per hidden unit, lanes over the nodes, fixed-tree reduction.
+// Written as COMPACT LOOPS over tables staged in LDS (the net's half of Wtot: 48 KB in one coalesced pass; the 182 polynomial
+// coefficients of the sigmoid's derivatives).  The first version was 900 instructions of straight-line code per thread -- every
+// coefficient a literal or a scalar load, Wtot's rows fetched where they were used -- and took 32-45 us for 2 nodes per thread: a kernel
+// that runs once per launch pays the memory latency of every instruction line and of every dependent load it touches.
+__constant__ double FF_SIGPOLY_MEM[13][14] = FF_SIGPOLY_INIT;
 __global__ void __launch_bounds__(256)
 ff_dep_contract_kernel(ff_net net, const double* __restrict__ off_table, const double* __restrict__ wtot, double* __restrict__ grad) {
+  FF_SETPRIO();
   const double* rtab = net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0)) return;
   __shared__ double sm[3][256];
+  __shared__ double s_W[FF_DEP_NTOT * FF_DEP_ROW];
+  __shared__ double s_P[13 * 14];
   const int t = blockIdx.x < (unsigned)net.He ? 0 : 1, hu = t ? blockIdx.x - net.He : blockIdx.x;
   const int H = t ? net.Hm : net.He;
   const double w1 = (t ? net.mw1 : net.ew1)[hu], b1 = (t ? net.mb1 : net.eb1)[hu], w2 = (t ? net.mw2 : net.ew2)[hu];
+  {
+    const double* Wt = wtot + (size_t)t * FF_DEP_NTOT * FF_DEP_ROW;
+    for (int e = threadIdx.x; e < FF_DEP_NTOT * FF_DEP_ROW; e += blockDim.x) s_W[e] = Wt[e];
+    for (int e = threadIdx.x; e < 13 * 14; e += blockDim.x) s_P[e] = (&FF_SIGPOLY_MEM[0][0])[e];
+  }
+  __syncthreads();
   double gw1 = 0.0, gb1 = 0.0, gw2 = 0.0;
   for (int j = threadIdx.x; j < FF_DEP_NTOT; j += blockDim.x) {
     const double rj = (double)j * (1.0 / FF_DEP_INVH);
-    double sd[13];
-    ff_sigma_derivs<12>(ff_sigmoid(fma(w1, rj, b1)), sd);
-    const double* W = wtot + ((size_t)t * FF_DEP_NTOT + j) * FF_DEP_ROW;
-    double wk = 1.0, wkm = 0.0;   // w1^k, k w1^(k-1)
-#pragma unroll
-    for (int k = 0; k < FF_DEP_ROW; k++) {
-      const double Wk = W[k];
-      gw2 = fma(Wk, wk * sd[k], gw2);
-      gb1 = fma(Wk, w2 * wk * sd[k + 1], gb1);
-      gw1 = fma(Wk, w2 * fma(wkm, sd[k], wk * rj * sd[k + 1]), gw1);
-      wkm = (k + 1) * wk;
-      wk *= w1;
+    const double sg = ff_sigmoid(fma(w1, rj, b1));
+    const double* W = &s_W[j * FF_DEP_ROW];
+    double wk = 1.0, wkm = 0.0, prev = 0.0;   // w1^k, k w1^(k-1), sigma^(k)
+#pragma unroll 1
+    for (int n = 0; n <= FF_DEP_ROW; n++) {
+      double p = s_P[n * 14 + n + 1];
+#pragma unroll 1
+      for (int c = n; c >= 1; c--) p = fma(p, sg, s_P[n * 14 + c]);
+      const double cur = p * sg;                // sigma^(n)
+      if (n >= 1) {                             // term k = n - 1: needs sigma^(k) = prev and sigma^(k+1) = cur
+        const double Wk = W[n - 1];
+        gw2 = fma(Wk, wk * prev, gw2);
+        gb1 = fma(Wk, w2 * wk * cur, gb1);
+        gw1 = fma(Wk, w2 * fma(wkm, prev, wk * rj * cur), gw1);
+        wkm = (double)n * wk;
+        wk *= w1;
+      }
+      prev = cur;
     }
   }
   sm[0][threadIdx.x] = gw1; sm[1][threadIdx.x] = gb1; sm[2][threadIdx.x] = gw2;
@@ -706,6 +734,10 @@ ff_dep_contract_kernel(ff_net net, const double* __restrict__ off_table, const d
     double* gout = grad + (t ? 3 * net.He : 0);
     gout[hu] = sm[0][0]; gout[H + hu] = sm[1][0]; gout[2 * H + hu] = sm[2][0];
   }
+}
+
+__global__ void __launch_bounds__(256) ff_zero_kernel(double* __restrict__ p, size_t n) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) p[k] = 0.0;
 }
 
 // =================================================================================================
@@ -839,7 +871,15 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
     a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);
   }
-  if (hipMemsetAsync(workspace, 0, sizeof(double) * adj_ws_doubles(wide, B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  if (wide) {      // (those kernels accumulate in their global rows and tables)
+    if (hipMemsetAsync(workspace, 0, sizeof(double) * adj_ws_doubles(wide, B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
+  } else {
+    // The narrow kernels write their private rows and tables in full; what must start at zero is the shared overflow table (Wtot:
+    // global atomics for the nodes beyond the LDS tables) and the off-table flag behind it -- 98 KB by a kernel of our own: the
+    // 37 MB hipMemsetAsync this replaces took 8.7 us plus the 8 us of pipeline bubble every blit costs on this GPU.
+    double* wt = a.off_table - (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW;
+    FF_LAUNCH(ff_zero_kernel, 48, 256, stream, wt, (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW + 1);
+  }
   int G = 0;
   if (wide) {
     // lanes per walker: two waves up to 128 radii (pairs + one-body), four beyond; one radius per lane up to 22 particles

@@ -189,6 +189,16 @@ FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
 //     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
 //     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
 #define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// wave priority for the instruction arbiter (0..3): the kernels of the critical path raise theirs where they run beside the prefetched
+// Metropolis kernel.  Measured (tools/probes/r04_ab2.sh, config 2): with priority 3 in the two reduction kernels behind the adjoint the adjoint stage goes 0.576 -> 0.532 ms and the wait for the prefetched walkers 0.040 -> 0.070: the SIMDs are busy either way, the iteration does not change.  Default 0 (off).
+#ifndef FF_PRIO
+#define FF_PRIO 0
+#endif
+#ifdef FF_HOSTSIM
+#define FF_SETPRIO() do {} while (0)
+#else
+#define FF_SETPRIO() __builtin_amdgcn_s_setprio(FF_PRIO)
+#endif
 template <int NV, bool TAB>
 FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict__ tab) {
   const double MAGIC = 6755399441055744.0;

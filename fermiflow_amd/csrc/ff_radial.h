@@ -25,24 +25,29 @@
 #define FF_TAB_DOUBLES (FF_TAB_HDR + 2 * FF_TAB_NMAX * FF_TAB_ROW)
 
 // sigma^(n)(a) as a polynomial in s = sigma(a): P_0 = s, P_{n+1} = P_n'(s) s (1 - s)
-__constant__ double FF_SIGPOLY[13][14] = {
-    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -7, 12, -6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -15, 50, -60, 24, 0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -31, 180, -390, 360, -120, 0, 0, 0, 0, 0, 0, 0},
-    {0, 1, -63, 602, -2100, 3360, -2520, 720, 0, 0, 0, 0, 0, 0},
-    {0, 1, -127, 1932, -10206, 25200, -31920, 20160, -5040, 0, 0, 0, 0, 0},
-    {0, 1, -255, 6050, -46620, 166824, -317520, 332640, -181440, 40320, 0, 0, 0, 0},
-    {0, 1, -511, 18660, -204630, 1020600, -2739240, 4233600, -3780000, 1814400, -362880, 0, 0, 0},
-    {0, 1, -1023, 57002, -874500, 5921520, -21538440, 46070640, -59875200, 46569600, -19958400, 3628800, 0, 0},
-    {0, 1, -2047, 173052, -3669006, 33105600, -158838240, 451725120, -801496080, 898128000, -618710400, 239500800, -39916800, 0},
-    {0, 1, -4095, 523250, -15195180, 180204024, -1118557440, 4115105280, -9574044480, 14495120640, -14270256000, 8821612800, -3113510400, 479001600}};
+// (a macro, expanded into a function-local constexpr array: with the fully unrolled loops below every coefficient becomes an instruction
+// literal.  As a __constant__ array it cost the small kernels a chain of COLD scalar loads -- ff_dep_contract_kernel spent 35 of its
+// 40 us waiting for eighteen of them, one round trip to HBM each)
+#define FF_SIGPOLY_INIT { \
+    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -3, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -7, 12, -6, 0, 0, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -15, 50, -60, 24, 0, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -31, 180, -390, 360, -120, 0, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -63, 602, -2100, 3360, -2520, 720, 0, 0, 0, 0, 0, 0}, \
+    {0, 1, -127, 1932, -10206, 25200, -31920, 20160, -5040, 0, 0, 0, 0, 0}, \
+    {0, 1, -255, 6050, -46620, 166824, -317520, 332640, -181440, 40320, 0, 0, 0, 0}, \
+    {0, 1, -511, 18660, -204630, 1020600, -2739240, 4233600, -3780000, 1814400, -362880, 0, 0, 0}, \
+    {0, 1, -1023, 57002, -874500, 5921520, -21538440, 46070640, -59875200, 46569600, -19958400, 3628800, 0, 0}, \
+    {0, 1, -2047, 173052, -3669006, 33105600, -158838240, 451725120, -801496080, 898128000, -618710400, 239500800, -39916800, 0}, \
+    {0, 1, -4095, 523250, -15195180, 180204024, -1118557440, 4115105280, -9574044480, 14495120640, -14270256000, 8821612800, -3113510400, 479001600}}
+
 
 // sigma^(0..NMAXD)(a) from s = sigma(a)
 template <int NMAXD>
 FF_D void ff_sigma_derivs(double s, double* out) {
+  constexpr double FF_SIGPOLY[13][14] = FF_SIGPOLY_INIT;
 #pragma unroll
   for (int n = 0; n <= NMAXD; n++) {
     double p = FF_SIGPOLY[n][n + 1];

@@ -411,6 +411,9 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 
 #pragma unroll 1
     for (;;) {
+#ifdef FF_WIDE_XBAR      // (experiment of DESIGN.md 4 "reproducibility of the multi-wave kernels": two more barriers per evaluation)
+      __syncthreads();
+#endif
       double gy, g0, g1, g2;
       ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
@@ -633,6 +636,9 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       out[IDL] = -dsum;
       out[ILP] = -(qsum + (own ? gdi * kb_in : 0.0));
       FF_STAMP(6);
+#ifdef FF_WIDE_XBAR
+      __syncthreads();
+#endif
       s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
       if (s == 99) break;
     }

@@ -228,11 +228,13 @@ def test_compact_finish_equals_the_finish_kernels(dev, nup, ndn, dim):
     assert b["z"].untyped_storage().nbytes() < (a["z"].untyped_storage().nbytes() if M > 24 else 1 << 62)
     if M > 24:
         assert b["z"].untyped_storage().nbytes() == 8 * (B * (M + 1) + 2)
+    # the same integration -- to rounding, not bit for bit: the multi-wave fp64 kernels occasionally take an extra rejected step from
+    # one run to the next (tools/probes/det_scan.py: |dz| <= 1e-10 whenever it happens)
     for k in ("z", "dlogp"):
-        assert torch.equal(a[k], b[k]), k      # the same integration
+        assert (a[k] - b[k]).abs().max().item() < 1e-9, k
     for k in ("logp", "V", "eloc", "lap", "grad", "glogp0"):
         sc = max(1.0, a[k].abs().max().item())
-        assert (a[k] - b[k]).abs().max().item() < 1e-9 * sc, (k, (a[k] - b[k]).abs().max().item(), sc)
+        assert (a[k] - b[k]).abs().max().item() < 2e-9 * sc, (k, (a[k] - b[k]).abs().max().item(), sc)
 
 
 def test_wide_direct_evaluation_equals_the_table_path(dev):

@@ -1,0 +1,56 @@
+"""Run-to-run reproducibility of the local-energy kernels, per shape: NRUN runs of 200 walkers, count of runs that differ from the first.
+Finding (round 4): alone on the GPU every kernel repeats bit for bit except, rarely, the multi-wave fp64 matrix-core kernels
+(v_mfma_f64_16x16x4); with a SECOND PROCESS on the same GPU (waves are preempted and restored) those kernels deviate in most runs -- an
+extra rejected step here and there, results within the solver tolerance -- and no other kernel ever does.
+  python tools/probes/det_scan.py            alone
+  (python tools/probes/det_scan.py &) ; python tools/probes/det_scan.py      two processes sharing the GPU"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import __graft_entry__ as Gm
+from fermiflow_amd import native
+dev = torch.device("cuda:0")
+NRUN = int(os.environ.get("NRUN", "80"))
+import fermiflow_amd as ff
+def setup(nup, ndn, fam, dim=2, bits=64):
+    if dim == 2:
+        model = Gm._model(dev, nup, ndn, 2.0)
+    else:
+        gs = Gm._model(dev, 2, 2, 2.0)
+        model = ff.GSVMC(nup, ndn, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+    v = model.cnf.v_wrapper.v
+    torch.manual_seed(31 + nup)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (200,))
+    prev = native.set_kernel_family(fam)
+    net = v.net(refresh=True)
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-8, 1e-10)
+    native.set_kernel_family(prev)
+    tu, td = model._tables(dev)
+    def run():
+        prev = native.set_kernel_family(fam)
+        pb = native.set_sens_precision(bits)
+        try:
+            return native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-8, 1e-10, 2.0, True, want_stats=True)
+        finally:
+            native.set_kernel_family(prev)
+            native.set_sens_precision(pb)
+    return run
+if os.environ.get("ONLY_BIG"):
+    shapes = [((3, 3), 0, 2, 64), ((7, 6), 0, 2, 64), ((7, 6), 0, 2, 32), ((12, 12), 0, 2, 64), ((10, 10), 0, 3, 64), ((10, 10), 0, 3, 32)]
+else:
+  shapes = [((3, 3), 1, 2, 64), ((3, 3), 0, 2, 64), ((7, 6), 0, 2, 64), ((8, 8), 0, 2, 64), ((12, 12), 0, 2, 64), ((12, 12), 0, 2, 32),
+            ((5, 5), 0, 3, 64), ((10, 10), 0, 3, 64), ((10, 10), 0, 3, 32)]
+runs = {s: setup(s[0][0], s[0][1], s[1], s[2], s[3]) for s in shapes}
+ref = {s: runs[s]() for s in shapes}
+cnt = {s: 0 for s in shapes}
+mx = {s: [0.0, 0.0] for s in shapes}
+evs = {s: set() for s in shapes}
+for it in range(NRUN):
+    for s in shapes:
+        r = runs[s]()
+        evs[s].add(int(r["stats"][0]))
+        dz = (r["z"] - ref[s]["z"]).abs().max().item(); de = ((r["eloc"] - ref[s]["eloc"]) / ref[s]["eloc"]).abs().max().item()
+        cnt[s] += int(dz > 0 or de > 0)
+        mx[s] = [max(mx[s][0], dz), max(mx[s][1], de)]
+for s in shapes:
+    print(s[0], f"d={s[2]} family {s[1]} {s[3]}-bit matrices", ": deviating runs", cnt[s], "of", NRUN, f"max |dz| {mx[s][0]:.1e} max rel dE_loc {mx[s][1]:.1e}; evaluations per run", min(evs[s]), "...", max(evs[s]))
