@@ -117,6 +117,13 @@ def _add_generic_potentials(r, x, extra):
     return r
 
 
+# Where the sampler's side stream is released (FERMIFLOW_PREFETCH_GO): "est" -- in front of the estimator kernel, "adj" -- in front of
+# the adjoint call.  The sampler must reach the workgroup dispatcher while the adjoint's workgroups are still being placed, not
+# behind them: the adjoint launches twice as many workgroups as fit, and a kernel that arrives a microsecond after it waits for that
+# backlog -- 376 us in the trace that showed it.
+_PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "adj")
+
+
 class _Sweep:
     """What GSVMC and BetaVMC share: flow + local energy of given base walkers with the walker schedule and the
     step-size warm start, the lazily converted device scalars, and the checkpointable sweep state."""
@@ -434,6 +441,10 @@ class GSVMC(_Sweep, torch.nn.Module):
             # from E on the device (ff_cnf_adjoint_energy) -- nothing here waits for the host
             prev = self._dev.get("E")
             shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
+            go_early = None
+            if prefetch and _PREFETCH_GO == "est":
+                go_early = torch.cuda.Event()
+                go_early.record()
             if not D._active():
                 _, est = native.energy_estimate(Eloc, r["logp"], shift, batch)       # one launch: sums and finish (nothing to all-reduce)
             else:
@@ -442,8 +453,8 @@ class GSVMC(_Sweep, torch.nn.Module):
                 est = native.energy_finish(sums, shift, batch)    # [E, sum (e - E)^2, mean(logp (e - E))]
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
-            go = None
-            if prefetch:
+            go = go_early
+            if prefetch and go is None:
                 go = torch.cuda.Event()
                 go.record()
             _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
