@@ -124,14 +124,15 @@ FF_D double ff3_add_rn(double a, double b) { double r = a + b; FF_OPAQUE(r); ret
 // 12 x 12 matrices in scratch: 85 ms per 131 072 walkers x 100 steps at 20 particles.)
 // NOISE: explicit g0 (B,n,D), g (S,B,n,D), u (S,B); otherwise Philox counters (seed, woff + b) with the quad / uniform slots of
 // the respective one-lane kernel.  g0 without NOISE: the walkers to continue from (ff_mcmc_continue).
-template <int D, bool NOISE>
+// NS: compile-time capacity of a species' determinant (8, 10 or 12: the matrix row of a lane and every elimination loop have that many
+// entries -- at configs[4], 10 x 10, a sixth less than with FF_MAX_NS)
+template <int D, bool NOISE, int NS>
 __global__ void __launch_bounds__(FF_WAVE)
 ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
                     const int* __restrict__ wstate, int steps, double tau, const double* __restrict__ g0,
                     const double* __restrict__ g, const double* __restrict__ u, uint64_t seed, int64_t woff,
                     double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
-  constexpr int NS = FF_MAX_NS;
-  __shared__ double s_row[4][NS];
+  __shared__ double s_row[2][4][NS];            // the pivot row of a column, double-buffered by column parity: ONE barrier per column
   __shared__ int s_deg[4][NS][D];               // Hermite degrees of the group's orbitals
   __shared__ double s_h[FF_WAVE][D][8];         // per lane: h_0..h_7 of each coordinate of its particle
   __shared__ int s_md;
@@ -215,17 +216,19 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
       const bool ispiv = act && who == r && !used;
       if (ispiv) {
 #pragma unroll
-        for (int j = 0; j < NS; j++) s_row[grp][j] = A[j];
+        for (int j = 0; j < NS; j++) s_row[c & 1][grp][j] = A[j];
         used = true;
       }
       __syncthreads();
       if (act && !used) {
         const double f = A[c] * ff_rcp(piv);
 #pragma unroll
-        for (int j = 0; j < NS; j++) { if (j > c) A[j] = fma(-f, s_row[grp][j], A[j]); }
+        for (int j = 0; j < NS; j++) { if (j > c) A[j] = fma(-f, s_row[c & 1][grp][j], A[j]); }
       }
-      __syncthreads();
+      // (no second barrier: column c + 1 publishes into the other buffer, and whoever writes this one again at column c + 2 has passed
+      // the barrier of column c + 1, which every reader of column c reaches only after its reads)
     }
+    __syncthreads();      // (the next call's first column writes buffer 0 again)
     return prod;
   };
   auto logabsdet = [&](const double* xx) -> double { return log(fabs(detprod(xx, true))); };
@@ -380,8 +383,12 @@ int ff_mcmc_rows_launch(void* stream, int d, bool noise, int64_t B, int nup, int
                         double tau, const double* g0, const double* g, const double* u, uint64_t seed, int64_t woff, double* x_out,
                         double* logp_out, uint8_t* accept, int* acc_count) {
   const unsigned grid = (unsigned)((2 * B + 3) / 4);
-#define FF_MR(D_, N_) FF_LAUNCH((ff_mcmc_rows_kernel<D_, N_>), grid, FF_WAVE, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, \
-                                x_out, logp_out, accept, acc_count)
+  const int nsm = nup > ndn ? nup : ndn;
+#define FF_MR(D_, N_) do { \
+    if (nsm <= 8) FF_LAUNCH((ff_mcmc_rows_kernel<D_, N_, 8>), grid, FF_WAVE, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count); \
+    else if (nsm <= 10) FF_LAUNCH((ff_mcmc_rows_kernel<D_, N_, 10>), grid, FF_WAVE, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count); \
+    else FF_LAUNCH((ff_mcmc_rows_kernel<D_, N_, FF_MAX_NS>), grid, FF_WAVE, stream, B, nup, ndn, tu, td, ws, steps, tau, g0, g, u, seed, woff, x_out, logp_out, accept, acc_count); \
+  } while (0)
   if (d == 2) { if (noise) FF_MR(2, true); else FF_MR(2, false); }
   else { if (noise) FF_MR(3, true); else FF_MR(3, false); }
 #undef FF_MR
