@@ -881,12 +881,14 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
   const int64_t cap = a.queue ? per_cu * wide_cus() : ((int64_t)1 << 20);
   const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
   // single-precision sensitivities (ff_set_sens_precision(32)): the table kernel with J, A, S in fp32; its fallback stays fp64
+#ifndef FF_WIDE_NO_FIN
   if (a.fin.on & 2) {      // fused finish (ff_ode::compact_finish)
     if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float, true>), grid, FF_WAVE * T, stream, a, n);
     else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double, true>), grid, FF_WAVE * T, stream, a, n);
     FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double, true>), grid, FF_WAVE * T, stream, a, n);
     return;
   }
+#endif
   if (a.evt && ff_wide_sens_fp32() && T >= 2) FF_LAUNCH((ff_wide_eloc_kernel<D, (T >= 2 ? T : 2), true, float, false>), grid, FF_WAVE * T, stream, a, n);
   else if (a.evt) FF_LAUNCH((ff_wide_eloc_kernel<D, T, true, double, false>), grid, FF_WAVE * T, stream, a, n);
   FF_LAUNCH((ff_wide_eloc_kernel<D, T, false, double, false>), grid, FF_WAVE * T, stream, a, n);
@@ -895,10 +897,13 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
 int ff_wide_eloc_heavy(void* stream, int n, int d, const ff_fwd_args& a, int64_t max_groups) {
   if (!ff_wide_supported(n, d) || (n * d + 4 + 15) / 16 != 1 || !a.evt || a.queue) return FF_EUNSUPPORTED;   // (table kernel, T = 1, grid-stride)
   const unsigned grid = (unsigned)(a.B < max_groups ? a.B : max_groups);
+#ifndef FF_WIDE_NO_FIN
   if (a.fin.on & 2) {
     if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double, true>), grid, FF_WAVE, stream, a, n);
     else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double, true>), grid, FF_WAVE, stream, a, n);
-  } else if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double, false>), grid, FF_WAVE, stream, a, n);
+  } else
+#endif
+  if (d == 2) FF_LAUNCH((ff_wide_eloc_kernel<2, 1, true, double, false>), grid, FF_WAVE, stream, a, n);
   else FF_LAUNCH((ff_wide_eloc_kernel<3, 1, true, double, false>), grid, FF_WAVE, stream, a, n);
   FF_LAUNCH_CHECK();
   return FF_OK;
