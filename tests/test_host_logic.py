@@ -257,3 +257,25 @@ def test_adjoint_workspace_serves_either_kernel_family():
     finally:
         lib.ff_set_kernel_family(prev)
     assert a == b and a > 0
+
+
+def test_compact_finish_workspace_sizes():
+    """ff_ode.compact_finish (ABI 104): beyond 24 coordinates the workspace of ff_eloc_nd is z(t0) | Delta | two counters and nothing of
+    size (n d)^2; up to 24 coordinates -- where kernels without a fused finish may serve a walker -- the full layout either way; the
+    binding asks for it by itself only past COMPACT_WORKSPACE_BYTES of full workspace."""
+    import ctypes as C
+    from fermiflow_amd import _lib, native
+    lib = _lib.lib()
+    assert lib.ff_version() == 104
+    assert C.sizeof(_lib.FFOde) % 8 == 0 and _lib.FFOde._fields_[-1][0] == "compact_finish"
+    full = lambda B, n, d: lib.ff_eloc_workspace_bytes(C.c_int64(B), n, d)
+    nd = lambda B, n, d, c: lib.ff_eloc_nd_workspace_bytes(C.c_int64(B), n, d, c)
+    for (n, d) in ((6, 2), (12, 2), (8, 3)):                 # M <= 24
+        assert nd(1000, n, d, 0) == full(1000, n, d) == nd(1000, n, d, 1)
+    for (n, d) in ((13, 2), (24, 2), (20, 3)):               # M > 24
+        M = n * d
+        assert nd(1000, n, d, 0) == full(1000, n, d)
+        assert nd(1000, n, d, 1) == 8 * (1000 * (M + 1) + 2)
+    # configs[4]: 131 072 walkers of 20 particles in d = 3 -- 4.09 GB of J^T alone in the full layout, 64 MB compact
+    assert full(131072, 20, 3) > 4.0e9 and nd(131072, 20, 3, 1) == 8 * (131072 * 61 + 2) < 64.1e6
+    assert native.COMPACT_WORKSPACE_BYTES == 32 << 30 and full(1 << 20, 20, 3) > native.COMPACT_WORKSPACE_BYTES > full(1 << 19, 20, 3)
