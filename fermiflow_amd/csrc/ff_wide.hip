@@ -360,7 +360,12 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     const int bpart = rs + 4 * k;
     const bool valid = rowlane && bpart < n && (bpart != ra || has_mu);
     prec[k] = ((valid ? ff_wide_partner(n, P, ra, bpart) : RCAP) * RW) << 1 | ((valid && bpart < ra) ? 1 : 0);
-    pdst[k] = rp * JS + ((valid && bpart != ra) ? bpart : ra) * D;
+    // (lanes that own no row -- rp >= M -- park their -0.0 in the LAST padding row of A, which nobody reads as anything but zero.  They
+    // used to write at rp * JS: for rp = M that is A[M][0..D-1], the (grad Delta)' entries of particle 0 which lanes 3, 7 (, 11) store
+    // in the same phase -- in program order within one wave, hence harmless in the one-wave kernel this code grew from, but a RACE across
+    // waves: now and then the zero won, that evaluation's grad Delta source lost a component and the step was rejected.  Found in
+    // round 4 by evaluating every right-hand side three times and comparing (-DFF_WIDE_SELFCHECK).)
+    pdst[k] = rowlane ? rp * JS + ((valid && bpart != ra) ? bpart : ra) * D : (MP - 1) * JS;
   }
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
@@ -413,6 +418,14 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     for (;;) {
 #ifdef FF_WIDE_XBAR      // (experiment of DESIGN.md 4 "reproducibility of the multi-wave kernels": two more barriers per evaluation)
       __syncthreads();
+#endif
+      TJ outJ[NVJ];
+      double out[NVS];
+#ifdef FF_WIDE_SELFCHECK   // (experiment of DESIGN.md 4: every right-hand side is evaluated twice from the same registers and compared)
+      TJ outJ_first[NVJ], outJ_second[NVJ];
+      double out_first[NVS], out_second[NVS];
+      for (int rep = 0; rep < 3; rep++) {
+      if (rep >= 1) __syncthreads();
 #endif
       double gy, g0, g1, g2;
       ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
@@ -621,8 +634,6 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       __syncthreads();
       FF_STAMP(5);
       // ---------------------------------------------------------------- second-order sums, right-hand side
-      TJ outJ[NVJ];
-      double out[NVS];
       double qs = 0.0;
 #pragma unroll
       for (int k = 0; k < NPK; k++) qs = fma((prec[k] & 1) ? -1.0 : 1.0, s_rec[(prec[k] >> 1) + QPW + rc], qs);
@@ -636,6 +647,40 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       out[IDL] = -dsum;
       out[ILP] = -(qsum + (own ? gdi * kb_in : 0.0));
       FF_STAMP(6);
+#ifdef FF_WIDE_SELFCHECK
+      if (rep == 0) {
+#pragma unroll
+        for (int v = 0; v < NVJ; v++) outJ_first[v] = outJ[v];
+#pragma unroll
+        for (int v = 0; v < NVS; v++) out_first[v] = out[v];
+        nev--;
+      } else if (rep == 1) {
+#pragma unroll
+        for (int v = 0; v < NVJ; v++) outJ_second[v] = outJ[v];
+#pragma unroll
+        for (int v = 0; v < NVS; v++) out_second[v] = out[v];
+        nev--;
+      } else {
+        int bad_idx = -1;
+        double va = 0.0, vb = 0.0, vc = 0.0;
+#pragma unroll
+        for (int v = 0; v < NVJ; v++)
+          if (!(outJ_first[v] == outJ[v] && outJ_second[v] == outJ[v]) && bad_idx < 0) { bad_idx = 100 + v; va = (double)outJ_first[v]; vb = (double)outJ_second[v]; vc = (double)outJ[v]; }
+#pragma unroll
+        for (int v = 0; v < NVS; v++)
+          if (!(out_first[v] == out[v] && out_second[v] == out[v]) && bad_idx < 0) { bad_idx = v; va = out_first[v]; vb = out_second[v]; vc = out[v]; }
+        if (bad_idx >= 0 && A.stats) {      // stats[8]: count; two records (lane, component, stage, walker, agreement code, three values as floats) behind it
+          const int slot = atomicAdd(&A.stats[8], 1);
+          if (slot < 2) {
+            int* q = A.stats + 9 + 9 * slot;
+            q[0] = tid; q[1] = bad_idx; q[2] = s; q[3] = (int)b; q[4] = (va == vb ? 1 : 0) | (vb == vc ? 2 : 0) | (va == vc ? 4 : 0);
+            q[5] = __float_as_int((float)va); q[6] = __float_as_int((float)vb); q[7] = __float_as_int((float)vc);
+            q[8] = __float_as_int((float)((va - vc) / (fabs(vc) + 1e-300)));
+          }
+        }
+      }
+      }      // rep
+#endif
 #ifdef FF_WIDE_XBAR
       __syncthreads();
 #endif
