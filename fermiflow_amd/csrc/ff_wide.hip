@@ -416,9 +416,6 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 
 #pragma unroll 1
     for (;;) {
-#ifdef FF_WIDE_XBAR      // (experiment of DESIGN.md 4 "reproducibility of the multi-wave kernels": two more barriers per evaluation)
-      __syncthreads();
-#endif
       TJ outJ[NVJ];
       double out[NVS];
 #ifdef FF_WIDE_SELFCHECK   // (experiment of DESIGN.md 4: every right-hand side is evaluated twice from the same registers and compared)
@@ -680,9 +677,6 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
         }
       }
       }      // rep
-#endif
-#ifdef FF_WIDE_XBAR
-      __syncthreads();
 #endif
       s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
       if (s == 99) break;
