@@ -360,12 +360,14 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     const int bpart = rs + 4 * k;
     const bool valid = rowlane && bpart < n && (bpart != ra || has_mu);
     prec[k] = ((valid ? ff_wide_partner(n, P, ra, bpart) : RCAP) * RW) << 1 | ((valid && bpart < ra) ? 1 : 0);
-    // (lanes that own no row -- rp >= M -- park their -0.0 in the LAST padding row of A, which nobody reads as anything but zero.  They
+    // (lanes that own no row -- rp >= M -- park their -0.0 in the padding rows of A, which nobody reads as anything but zero.  They
     // used to write at rp * JS: for rp = M that is A[M][0..D-1], the (grad Delta)' entries of particle 0 which lanes 3, 7 (, 11) store
     // in the same phase -- in program order within one wave, hence harmless in the one-wave kernel this code grew from, but a RACE across
     // waves: now and then the zero won, that evaluation's grad Delta source lost a component and the step was rejected.  Found in
     // round 4 by evaluating every right-hand side three times and comparing (-DFF_WIDE_SELFCHECK).)
-    pdst[k] = rowlane ? rp * JS + ((valid && bpart != ra) ? bpart : ra) * D : (MP - 1) * JS;
+    // (each such lane its own D entries of the padding rows M + 1 ..: 4 (MP - M) D <= (MP - M - 1) JS for every shape served, so that
+    // not even equal values meet at one address and a ThreadSanitizer run of the host simulator stays silent)
+    pdst[k] = rowlane ? rp * JS + ((valid && bpart != ra) ? bpart : ra) * D : (M + 1) * JS + (tid - 4 * M) * D;
   }
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
