@@ -739,6 +739,18 @@ def test_heavy_walker_route_vs_oracle(dev, capsys):
     with capsys.disabled():
         for name, (cnt, mx, med, gerr, lerr) in out.items():
             print(f"\n[heavy route vs oracle] {name}: {cnt} walkers, E_loc rel. error max {mx:.2e} median {med:.2e}; grad logp {gerr:.2e}; logp {lerr:.2e}")
+    # ff_ode.compact_finish on the routed pass: the heavy route's one-wave kernel finishes its walkers in its own epilogue instead of
+    # leaving their sensitivities to the two filtered finish kernels -- same integration, every output to rounding
+    rc = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_order=native.walker_order(cost),
+                     walker_h_init=hg, walker_h_scale=model._h_scale_eloc, walker_class=cost, sens_tol=model.sens_tol,
+                     sens_tol_class=model.sens_tol_class, walker_h_scale_loose=model._h_scale_loose, compact=True)
+    assert int(rc["stats"][3]) == 0 and int(rc["stats"][0]) == int(r["stats"][0])
+    assert torch.equal(rc["z"], r["z"]) and torch.equal(rc["dlogp"], r["dlogp"])
+    light = (cost < 12).nonzero().squeeze(1)
+    for k in ("eloc", "logp", "lap", "V", "grad", "glogp0"):
+        assert torch.equal(rc[k][light], r[k][light]), k                      # the throughput kernel's walkers: the same kernel
+        sc = max(1.0, r[k][heavy].abs().max().item())
+        assert (rc[k][heavy] - r[k][heavy]).abs().max().item() < 1e-9 * sc, k
 
 
 @pytest.mark.parametrize("nup,ndn,B", [(3, 3, 65536), (6, 6, 8192)])
