@@ -1413,7 +1413,10 @@ static int launch_fwd(void* stream, const ff_fwd_args& a) {
   if constexpr (MODE == 2 && N <= 3) routed = launch_routed(stream, N, D, a, table, false);
   if (routed == FF_ROUTE_FAILED) return FF_ELAUNCH;
   if (routed == FF_ROUTE_NONE && a.evt) table(stream, a);
-  FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid, FF_WAVE, stream, a);
+  // behind a table kernel the direct kernel is a fallback that almost always finds nothing to do: a grid-stride launch of two waves per
+  // SIMD instead of one workgroup per walker group (13 108 workgroups at config 2: 6 us just to start and retire them)
+  const unsigned grid_fb = a.evt && grid > 2048u ? 2048u : grid;
+  FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, false>), grid_fb, FF_WAVE, stream, a);
   return FF_OK;
 }
 
