@@ -1676,7 +1676,10 @@ static int eloc_finish_impl(void* stream, int64_t B, int nup, int ndn, const int
   {
     const int Gf = FF_WAVE / (2 * n);
     const int64_t ng = (B + Gf - 1) / Gf;
-    FF_LAUNCH_LDS(ff_eloc_contract_kernel, (unsigned)(ng < 32768 ? ng : 32768), FF_WAVE, ff_contract_lds_bytes(nup, ndn), stream, B, nup, ndn, Z, use_ho, x,
+    // (the filtered launch of the heavy route skips 99.6 % of the walker groups: a small grid striding over them instead of one
+    // workgroup per group, whose starting and retiring alone took 26 us beside the throughput kernel)
+    const int64_t gcap = flt.wclass ? 1024 : 32768;
+    FF_LAUNCH_LDS(ff_eloc_contract_kernel, (unsigned)(ng < gcap ? ng : gcap), FF_WAVE, ff_contract_lds_bytes(nup, ndn), stream, B, nup, ndn, Z, use_ho, x,
               (const double*)w.Q, (const double*)w.Jt, (const double*)w.kbar, (const double*)w.dD, (const double*)w.dl,
               (const double*)w.Lp, logp, grad, lap, V, eloc, glogp0_out, flt);
   }
