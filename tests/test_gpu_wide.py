@@ -243,7 +243,7 @@ def test_multi_wave_kernels_repeat_bit_for_bit(dev):
     import __graft_entry__ as Gm
     import fermiflow_amd as ff
     from fermiflow_amd import native
-    def setup(nup, ndn, dim, bits):
+    def setup(nup, ndn, dim, bits, compact=False):
         if dim == 2:
             model = Gm._model(dev, nup, ndn, 2.0)
         else:
@@ -256,11 +256,12 @@ def test_multi_wave_kernels_repeat_bit_for_bit(dev):
         def run():
             prev = native.set_sens_precision(bits)
             try:
-                return native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-8, 1e-10, 2.0, True, want_stats=True)
+                return native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-8, 1e-10, 2.0, True, want_stats=True, compact=compact)
             finally:
                 native.set_sens_precision(prev)
         return run
-    shapes = [(7, 6, 2, 64), (7, 6, 2, 32), (12, 12, 2, 64), (10, 10, 3, 64), (10, 10, 3, 32)]
+    # (the last two: the same kernels with the finish in their epilogue, ff_ode.compact_finish)
+    shapes = [(7, 6, 2, 64), (7, 6, 2, 32), (12, 12, 2, 64), (10, 10, 3, 64), (10, 10, 3, 32), (12, 12, 2, 64, True), (10, 10, 3, 32, True)]
     runs = {s: setup(*s) for s in shapes}
     ref = {s: runs[s]() for s in shapes}
     for it in range(25):
