@@ -192,6 +192,7 @@ class _Sweep:
                 hprev, uniform = self._h_flow, True
         x = native.cnf_generate(net, z, t0, t1, self.cnf.rtol, self.cnf.atol, walker_cost=cost,
                                 walker_h_init=hprev, walker_h_scale=0.75, walker_h_out=hg, walker_h_uniform=uniform)
+        self.walker_cost = cost          # the flow pass's cost class per walker (diagnostics and tests; ff_ode.walker_cost)
         if warm and not per_walker_h:
             order, self._h_flow = native.walker_order(cost, hval=hg)      # the schedule and the mean accepted step from the same launches
         else:

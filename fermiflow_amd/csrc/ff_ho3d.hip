@@ -263,7 +263,10 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
     //    lane and step, six times the walker's sixteen);
     //  * the decision u < |psi(x')|^2 / |psi(x)|^2 is taken as u e^{R' - R} (P_up P_dn)^2 < (P'_up P'_dn)^2 on the determinants of the
     //    polynomial parts of the orbitals, R = sum r_i^2 (ff_mcmc_spin_philox_kernel): no exp per particle, no log per determinant.
-    __shared__ double s_nrm[2][64], s_uu[2];
+    // (capacity: the largest walker the entry points admit -- D * 2 FF_MAX_NS coordinates, rounded up to whole quads; 64 was too small
+    //  for more than 21 particles in d = 3: ADVICE r04)
+    constexpr int NRM = 4 * ((D * 2 * FF_MAX_NS + 3) / 4);
+    __shared__ double s_nrm[2][NRM], s_uu[2];
     const int wk = lane >> 5, L = lane & 31, nq = (M + 3) >> 2;
     auto draw = [&](uint32_t step) {
       if (L < nq) {
@@ -656,6 +659,26 @@ ff_wide_contract3d_kernel(int64_t B, int nup, int ndn, double Zc, int use_ho, co
   }
 }
 
+// The very noise ff_mcmc_sample3d consumes, materialised (tests: feed it to ff_mcmc_sample_noise3d) -- quads 0 .. ceil(3n / 4) - 1 of
+// (walker, step) are the normals of the walker's coordinates in order, block 0xffff its uniform (ff_mcmc_rows_kernel<3, false>).
+__global__ void __launch_bounds__(128)
+ff_rng_fill3d_kernel(int64_t B, int n, int steps, uint64_t seed, int64_t woff, double* __restrict__ g0, double* __restrict__ g,
+                     double* __restrict__ u) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int M = 3 * n, nq = (M + 3) >> 2;
+  const uint64_t wid = (uint64_t)(woff + b);
+  for (int s = 0; s <= steps; s++) {
+    double* gs = s == 0 ? g0 + b * M : g + ((int64_t)(s - 1) * B + b) * M;
+    for (int q = 0; q < nq; q++) {
+      double z4[4];
+      ff_normal_quad(seed, wid, (uint32_t)s, (uint32_t)q, z4);
+      for (int k = 0; k < 4; k++) if (4 * q + k < M) gs[4 * q + k] = z4[k];
+    }
+    if (s > 0) u[(int64_t)(s - 1) * B + b] = ff_uniform(seed, wid, (uint32_t)s, 0xffffu);
+  }
+}
+
 // =================================================================================================
 extern void ff_set_error(const char* msg);
 #define FF_CHECK(cond, code, msg) do { if (!(cond)) { ff_set_error(msg); return code; } } while (0)
@@ -696,6 +719,14 @@ int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* t
   if (B == 0) return FF_OK;
   return ff_mcmc_rows_launch(stream, 3, false, B, nup, ndn, tab_up, tab_dn, walker_state, steps, tau, (const double*)nullptr,
                              (const double*)nullptr, (const double*)nullptr, seed, walker_offset, x_out, logp_out, (uint8_t*)nullptr, accept_count);
+}
+
+int ff_rng_fill3d(void* stream, int64_t B, int n, int steps, uint64_t seed, int64_t walker_offset, double* g0, double* g, double* u) {
+  FF_CHECK(B >= 0 && n > 0 && n <= 2 * FF_MAX_NS && steps >= 0 && g0 && (steps == 0 || (g && u)), FF_EINVAL, "ff_rng_fill3d: bad argument");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_rng_fill3d_kernel, ff3_grid(B, 128), 128, stream, B, n, steps, seed, walker_offset, g0, g, u);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
 }
 
 int ff_backflow_v_div_f32(void* stream, int64_t B, int n, int d, const ff_net* net, const double* x, double* v, double* div) {

@@ -27,7 +27,8 @@ FF_D uint64_t ff_bits53(uint32_t hi, uint32_t lo) { return (((uint64_t)hi << 32)
 // Two N(0,1) from two 32-bit words (Box-Muller) on the hardware fp32 transcendentals -- v_log_f32 (log2), v_sqrt_f32,
 // v_sin_f32 / v_cos_f32 (argument in revolutions) -- promoted to fp64.  A Metropolis chain only needs its proposal to be
 // SYMMETRIC to be exact, and this one is by construction: the radius uniform (a + 1/2) 2^-32 lies in (0, 1] (no infinite
-// proposal), the angle covers the first quadrant only (30 bits of b) and each normal takes its sign from a bit of b of its
+// proposal; the largest a round to u1 = 1.0f exactly: rad = sqrt(-0.0) = -0.0 and both normals are signed zeros -- harmless),
+// the angle covers the first quadrant only (30 bits of b) and each normal takes its sign from a bit of b of its
 // own, so g and -g (indeed any sign pattern) are equally likely bit for bit whatever the rounding of the transcendentals.
 // 24-bit normals with the tail to 6.7 sigma; the fp64 chain (log, sqrt, sincospi: ~90 fp64 instructions per pair) was a
 // third of the Metropolis kernel.  ff_rng_fill materialises exactly these values.

@@ -107,12 +107,14 @@ def mcmc_sample_noise(tab_up, tab_dn, nup, ndn, g0, g, u, tau=0.1, walker_state=
     return x, logp, acc
 
 
-def rng_fill(B, n, steps, seed, device, walker_offset=0):
-    g0 = torch.empty(B, n, 2, dtype=torch.float64, device=device)
-    g = torch.empty(steps, B, n, 2, dtype=torch.float64, device=device)
+def rng_fill(B, n, steps, seed, device, walker_offset=0, dim=2):
+    """the noise ff_mcmc_sample (dim = 2) / ff_mcmc_sample3d (dim = 3) consume for these walkers, materialised"""
+    g0 = torch.empty(B, n, dim, dtype=torch.float64, device=device)
+    g = torch.empty(steps, B, n, dim, dtype=torch.float64, device=device)
     u = torch.empty(steps, B, dtype=torch.float64, device=device)
-    L.check(L.lib().ff_rng_fill(L.stream(), L.i64(B), n, int(steps), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
-                                L.ptr(g0), L.ptr(g), L.ptr(u)), "ff_rng_fill")
+    fn, name = (L.lib().ff_rng_fill, "ff_rng_fill") if dim == 2 else (L.lib().ff_rng_fill3d, "ff_rng_fill3d")
+    L.check(fn(L.stream(), L.i64(B), n, int(steps), C.c_uint64(int(seed) & (2**64 - 1)), L.i64(walker_offset),
+               L.ptr(g0), L.ptr(g), L.ptr(u)), name)
     return g0, g, u
 
 

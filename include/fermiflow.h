@@ -307,6 +307,9 @@ int ff_mcmc_sample_noise3d(void* stream, int64_t B, int nup, int ndn, const int3
 int ff_mcmc_sample3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,
                      const int32_t* walker_state, int steps, double tau, uint64_t seed, int64_t walker_offset,
                      double* x_out, double* logp_out, int32_t* accept_count);
+/* The very noise ff_mcmc_sample3d consumes, materialised (for tests: feed it to ff_mcmc_sample_noise3d); g0 (B,n,3), g (S,B,n,3), u (S,B). */
+int ff_rng_fill3d(void* stream, int64_t B, int n, int steps, uint64_t seed, int64_t walker_offset,
+                  double* g0, double* g, double* u);
 /* Local-energy finish for d = 3 (pass 1: ff_eloc_sensitivities with d = 3, n = 2..4; workspace: ff_eloc_workspace_bytes(B, n, 3));
  * arguments as ff_eloc_finish, walkers (B, n, 3), HO3D orbital tables. */
 int ff_eloc_finish3d(void* stream, int64_t B, int nup, int ndn, const int32_t* tab_up, const int32_t* tab_dn,

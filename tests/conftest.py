@@ -45,4 +45,4 @@ def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
     return {k: np.load(os.path.join(d, f"{k}.npz")) for k in
-            ("g1_mcmc", "g2_slater", "g3_backflow", "g4_cnf", "g5_gsvmc", "g6_betavmc")}
+            ("g1_mcmc", "g2_slater", "g3_backflow", "g4_cnf", "g5_gsvmc", "g6_betavmc", "g7_3d")}

@@ -3,7 +3,7 @@
 /root/reference through ref_shim.py) on seeded inputs.
 
 Run in the build container only:   python tests/golden/make_golden.py [group ...]
-Groups: mcmc slater backflow cnf gsvmc betavmc   (default: all)
+Groups: mcmc slater backflow cnf gsvmc betavmc d3   (default: all)
 
 Every fixture stores inputs and the reference's outputs; no reference source text is stored.
 Reference call sites are cited next to each group.
@@ -364,8 +364,149 @@ def g_betavmc(R_unused):
         out[f"{nm}_w1"], out[f"{nm}_b1"], out[f"{nm}_w2"] = w1, b1, w2
     np.savez_compressed(os.path.join(HERE, "g6_betavmc.npz"), **out)
 
+# ---------------------------------------------------------------------------------------------
+def ho3d_closures(R):
+    """3-D oscillator orbitals as Python closures, built HERE from the reference's own HO2D closures (src/orbitals.py:65-82):
+    phi3D_{nx,ny,nz}(x, y, z) = phi2D_{nx,ny}(x, y) * [pi^(1/4) * phi2D_{nz,0}(z, 0)]  -- the bracket is the normalised 1-D
+    oscillator function pi^(-1/4) e^(-z^2/2) h_nz(z), because phi2D_{n,0}(z, 0) = pi^(-1/2) e^(-z^2/2) h_n(z) h_0(0) and h_0 = 1.
+    Every factor is evaluated by reference code; only the product is formed here.  List order = fermiflow_amd.orbitals.HO3D:
+    for shell: for nx in 0..shell: for ny in 0..shell-nx: (nx, ny, shell-nx-ny); E = shell + 3/2."""
+    torch = R.torch
+    ho = R.orbitals.HO2D()
+    k2 = lambda nx, ny: (nx + ny) * (nx + ny + 1) // 2 + nx          # index of (nx, ny) in HO2D().orbitals (src/orbitals.py:81)
+    c = float(np.pi) ** 0.25
 
-GROUPS = dict(mcmc=g_mcmc, slater=g_slater, backflow=g_backflow, cnf=g_cnf, gsvmc=g_gsvmc, betavmc=g_betavmc)
+    def make(nx, ny, nz):
+        fxy, fz = ho.orbitals[k2(nx, ny)], ho.orbitals[k2(nz, 0)]
+        def phi(x):
+            z = x[..., 2]
+            return fxy(x[..., :2]) * (c * fz(torch.stack((z, torch.zeros_like(z)), dim=-1)))
+        return phi
+    orbs, Es, nxyz = [], [], []
+    for shell in range(8):
+        for nx in range(shell + 1):
+            for ny in range(shell + 1 - nx):
+                orbs.append(make(nx, ny, shell - nx - ny)); Es.append(shell + 1.5); nxyz.append((nx, ny, shell - nx - ny))
+    return orbs, Es, nxyz
+
+
+def replay_sample(R, bd, up, dn, B, dim, seed, steps, tau=0.1):
+    """The body of FreeFermion.sample (src/base_dist.py:62-70) statement by statement with randn(B, n, dim) in place of the
+    hard-coded randn(B, n, 2) of :62; log_prob is the reference's.  Returns noise, accept masks, walkers."""
+    torch = R.torch
+    torch.manual_seed(seed)
+    n = len(up) + len(dn)
+    g0 = torch.randn(B, n, dim)
+    x = g0.clone()
+    logp = bd.log_prob(up, dn, x)
+    logp0 = logp.clone()
+    gs, us, acc = [], [], []
+    for _ in range(steps):
+        g = torch.randn_like(x)
+        new_x = x + tau * g
+        new_logp = bd.log_prob(up, dn, new_x)
+        p = torch.exp(new_logp - logp)
+        u = torch.rand_like(p)
+        a = u < p
+        x[a] = new_x[a]; logp[a] = new_logp[a]
+        gs.append(g.numpy().copy()); us.append(u.numpy().copy()); acc.append(a.numpy().copy())
+    return g0.numpy(), np.stack(gs), np.stack(us), np.stack(acc), logp0.numpy(), x, logp
+
+
+def g_3d(R_unused):
+    """d = 3 (BASELINE.json configs[4]).  The reference has no 3-D orbital LIST (src/orbitals.py:56) and one
+    hard-coded randn shape (src/base_dist.py:62) -- everything else on the path is dimension-generic and is run here AS IS on
+    (B, n, 3) walkers: LogAbsSlaterDet.apply (src/slater.py:13-62), FreeFermion.log_prob (src/base_dist.py:49-56),
+    y_grad_laplacian (src/utils.py:40-65), the Metropolis loop body (src/base_dist.py:63-70), Backflow, CNF.generate /
+    delta_logp, GSVMC.logp (src/VMC.py:35-38) and the estimator lines of GSVMC.forward (src/VMC.py:46-58)."""
+    out = {}
+    R = ref_shim.load(1e-10, 1e-12)
+    torch = R.torch
+    orbs, Es, nxyz = ho3d_closures(R)
+    out["nxyz"] = np.array(nxyz, dtype=np.int32); out["Es"] = np.array(Es)
+    bd = R.base_dist.FreeFermion()
+    rng = np.random.RandomState(321)
+    # orbital values at random points (first 35 = shells 0..4)
+    torch.manual_seed(6)
+    pts = torch.randn(40, 3) * 1.3
+    out["orb_pts"] = pts.numpy(); out["orb_vals"] = np.stack([o(pts).numpy() for o in orbs[:35]])
+    # (i) one determinant: value, gradient, Laplacian
+    for n in (1, 4, 10):
+        idx = np.arange(10, dtype=np.int32) if n == 10 else np.sort(rng.choice(20, size=n, replace=False)).astype(np.int32)
+        sel = tuple(orbs[i] for i in idx)
+        torch.manual_seed(200 + n)
+        x = torch.randn(16, n, 3, requires_grad=True)
+        y, g, lap = R.utils.y_grad_laplacian(lambda x: R.slater.LogAbsSlaterDet.apply(sel, x), x)
+        out[f"n{n}_orb"] = idx; out[f"n{n}_x"] = x.detach().numpy().copy()
+        out[f"n{n}_logabsdet"] = y.detach().numpy(); out[f"n{n}_grad"] = g.detach().numpy(); out[f"n{n}_lap"] = lap.detach().numpy()
+        E = sum(Es[i] for i in idx)
+        eloc = -0.5 * lap - 0.5 * (g ** 2).sum(dim=(-2, -1)) + 0.5 * (x ** 2).sum(dim=(-2, -1))
+        print("3d det n", n, "max |Eloc - E|", (eloc - E).abs().max().item())
+        assert torch.allclose(eloc, E * torch.ones(16), rtol=1e-6), (n, eloc)
+    # two spin species through FreeFermion.log_prob: random subsets (3, 6) and configs[4]'s closed shells (10, 10)
+    for tag, iu, idn, B in (("lp36", np.sort(rng.choice(20, 3, replace=False)), np.sort(rng.choice(20, 6, replace=False)), 12),
+                            ("lp1010", np.arange(10), np.arange(10), 8)):
+        up, dn = tuple(orbs[i] for i in iu), tuple(orbs[i] for i in idn)
+        torch.manual_seed(88 + len(iu))
+        x = torch.randn(B, len(iu) + len(idn), 3, requires_grad=True)
+        y, g, lap = R.utils.y_grad_laplacian(lambda x: bd.log_prob(up, dn, x), x)
+        out[tag + "_up"], out[tag + "_dn"] = iu.astype(np.int32), idn.astype(np.int32)
+        out[tag + "_x"] = x.detach().numpy().copy(); out[tag + "_logp"] = y.detach().numpy()
+        out[tag + "_grad"] = g.detach().numpy(); out[tag + "_lap"] = lap.detach().numpy()
+    # (ii) Metropolis replay
+    for name, (nup, ndown, B, seed, steps) in {"m2d2": (2, 2, 64, 17, 100), "m10d10": (10, 10, 16, 19, 60), "m4d3": (4, 3, 32, 23, 100)}.items():
+        up, dn = tuple(orbs[:nup]), tuple(orbs[:ndown])
+        g0, gs, us, acc, logp0, x, logp = replay_sample(R, bd, up, dn, B, 3, seed, steps)
+        out[name + "_cfg"] = np.array([nup, ndown, B, seed, steps], dtype=np.int64)
+        out[name + "_noise_sha"] = np.array(sha(g0) + sha(gs) + sha(us))
+        out[name + "_logp0"] = logp0
+        out[name + "_accept"] = np.packbits(acc.astype(np.uint8), axis=None)
+        out[name + "_x"] = x.numpy().copy(); out[name + "_logp"] = logp.numpy().copy()
+        print("3d mcmc", name, "acc-rate", acc.mean(), "x sha", sha(x.numpy())[:16])
+    # (iii) local energy, estimator and the six parameter gradients of a GSVMC iteration on 3-D walkers
+    only = os.environ.get("FF_3D_CASES")
+    for name, (nup, ndown, Z, B, seed) in {"e2d2": (2, 2, 2.0, 12, 31), "e5d4": (5, 4, 2.0, 4, 33), "e1d1": (1, 1, 0.5, 8, 35)}.items():
+        if only and name not in only.split(","):
+            continue
+        t = time.time()
+        eta, mu = nontrivial_weights(R)
+        v = R.equivariant_funs.Backflow(eta, mu=mu)
+        cnf = R.flow.CNF(v, (0.0, 1.0))
+        import types
+        model = R.VMC.GSVMC(nup, ndown, types.SimpleNamespace(orbitals=orbs), bd, cnf, R.potentials.CoulombPairPotential(Z),
+                            sp_potential=R.potentials.HO())
+        _, _, _, _, _, z, _ = replay_sample(R, bd, model.orbitals_up, model.orbitals_down, B, 3, seed, 100)
+        x = cnf.generate(z)                                             # src/VMC.py:32
+        x = x.detach().clone().requires_grad_(True)                     # :44
+        logp_full = model.logp(x, params_require_grad=True)             # :46
+        logp, grad_logp, lap_logp = R.utils.y_grad_laplacian(model.logp, x)   # :48
+        kinetic = -1 / 4 * lap_logp - 1 / 8 * (grad_logp ** 2).sum(dim=(-2, -1))
+        potential = model.pair_potential.V(x) + model.sp_potential.V(x)
+        Eloc = (kinetic + potential).detach()
+        E, E_std = Eloc.mean().item(), Eloc.std().item()
+        gradE = (logp_full * (Eloc - E)).mean()
+        model.zero_grad()
+        gradE.backward()
+        zb, dl = cnf.delta_logp(x.detach())
+        o = dict(cfg=np.array([nup, ndown, B, seed], dtype=np.int64), Z=np.array(Z), z=z.detach().numpy(), x=x.detach().numpy(),
+                 zback=zb.detach().numpy(), dlogp=dl.detach().numpy(),
+                 logp=logp.detach().numpy(), grad=grad_logp.detach().numpy(), lap=lap_logp.detach().numpy(),
+                 V=potential.detach().numpy(), Eloc=Eloc.numpy(), E=np.array(E), E_std=np.array(E_std), gradE=np.array(gradE.item()))
+        for nme, p in model.named_parameters():
+            o["pg_" + nme] = p.grad.numpy().reshape(-1).copy()
+        for k_, v_ in o.items():
+            out[f"{name}_{k_}"] = v_
+        print("3d gsvmc", name, "E", E, "E_std", E_std, "%.1fs" % (time.time() - t), flush=True)
+    for nm, m in (("eta", eta), ("mu", mu)):
+        w1, b1, w2 = mlp_np(m)
+        out[f"{nm}_w1"], out[f"{nm}_b1"], out[f"{nm}_w2"] = w1, b1, w2
+    path = os.path.join(HERE, "g7_3d.npz")
+    if only and os.path.exists(path):
+        old = dict(np.load(path)); old.update(out); out = old
+    np.savez_compressed(path, **out)
+
+
+GROUPS = dict(mcmc=g_mcmc, slater=g_slater, backflow=g_backflow, cnf=g_cnf, gsvmc=g_gsvmc, betavmc=g_betavmc, d3=g_3d)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

@@ -137,9 +137,10 @@ def mcmc_continue(x_init, nup, ndn, steps, seed, offset=0, tau=0.1):
     return x, lp, cnt
 
 
-def rng_fill(B, n, steps, seed, offset=0):
-    g0 = np.empty((B, n, 2)); g = np.empty((steps, B, n, 2)); u = np.empty((steps, B))
-    _ck(lib().ff_rng_fill(None, C.c_int64(B), n, steps, C.c_uint64(seed), C.c_int64(offset), _p(g0), _p(g), _p(u)))
+def rng_fill(B, n, steps, seed, offset=0, dim=2):
+    g0 = np.empty((B, n, dim)); g = np.empty((steps, B, n, dim)); u = np.empty((steps, B))
+    fn = lib().ff_rng_fill if dim == 2 else lib().ff_rng_fill3d
+    _ck(fn(None, C.c_int64(B), n, steps, C.c_uint64(seed), C.c_int64(offset), _p(g0), _p(g), _p(u)))
     return g0, g, u
 
 

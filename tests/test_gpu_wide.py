@@ -2,18 +2,23 @@
 (nup = ndown = 10 in a 3-D trap, n d = 60) and every 2-D system beyond 12 particles -- shapes the reference serves through
 its shape-generic PyTorch code (src/equivariant_funs.py:17-102, --nup/--ndown of src/FermionHO2D.py:18-19).
 
-The oracle (oracle/ff_oracle.c) is the checker; the north-star bar for E_loc is 1e-5 relative (fp64).  d = 3 has no upstream
-code: its oracle is pinned by the eigenfunction known-answer test only (tests/test_oracle_golden.py), which is repeated here
-through the production path at BASELINE size."""
+The oracle (oracle/ff_oracle.c) is the checker; the north-star bar for E_loc is 1e-5 relative (fp64).  d = 3: the reference has no
+3-D orbital list, but everything else on its path is dimension-generic -- tests/golden/g7_3d.npz holds what the REFERENCE computes on
+(B, n, 3) walkers with 3-D closures made of its own HO2D closures (make_golden.py group d3); the oracle is pinned to it
+(tests/test_oracle_golden.py::test_3d_*) and the HIP path is compared with it directly below (test_3d_*_vs_reference)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import oracle as O
-from tests.common import net_arrays
+from tests.common import net_arrays, mcmc_noise_from_seed, gsvmc_param_grads, make_flow, T
 
 pytestmark = pytest.mark.gpu
 ELOC_RTOL = 1e-5     # BASELINE.json north_star: "E_loc within 1e-5 relative fp64"
+# bounds of the configs[4] known-answer test (measured: tools/probes/c5_cond.py)
+# measured (tools/probes/c5_cond.py, 131 072 Metropolis walkers): max |E_loc - 60| = 4.4e-12 -- walkers drawn from |psi|^2 stay away from
+# its nodes, the largest condition number of a Slater matrix in the batch is 6e4 (random points, test_ho3d_base_distribution, do not)
+C5_KAT_MAX, C5_KAT_MEAN = 1e-9, 1e-11
 
 
 def N(t):
@@ -133,18 +138,51 @@ def _model3d(dev, nup, ndn, Z, zero):
 def test_config5_known_answer_at_full_size(dev):
     """BASELINE.json configs[4] at its per-GPU size: nup = ndown = 10 in the 3-D trap (closed shells 0..2), 131 072 walkers.
     Zero flow and Z = 0: every walker's E_loc is the sum of the occupied orbital energies, 2 (1.5 + 3 * 2.5 + 6 * 3.5) = 60
-    (tests/test_basedist.py:5-60 one dimension up).  The 10 x 10 determinants of Metropolis walkers are occasionally
-    ill-conditioned, hence quantile criteria as in test_ho3d_base_distribution."""
+    (tests/test_basedist.py:5-60 one dimension up).  The assertion is a MAXIMUM over all 131 072 walkers plus the batch mean and E_std
+    (the quantile criteria of rounds 3-4 left the worst walkers unbounded and the mean unchecked; they were
+    inherited from the random-point test, where 10 x 10 determinants can be ill-conditioned -- Metropolis walkers are not)."""
     model = _model3d(dev, 10, 10, 0.0, True)
     torch.manual_seed(4)
     g = model(131072)
     g.backward()
     assert model.x.shape == (131072, 20, 3)
     err = (model.Eloc - 60.0).abs()
-    q = torch.quantile(err, torch.tensor([0.5, 0.99, 0.9999], dtype=torch.float64, device=dev))
-    assert q[0].item() < 1e-9 and q[1].item() < 1e-6 and q[2].item() < 1e-3, q
-    assert np.isfinite(model.E) and abs(model.Eloc.median().item() - 60.0) < 1e-9
+    assert err.max().item() < C5_KAT_MAX, err.max().item()          # EVERY walker
+    assert abs(model.E - 60.0) < C5_KAT_MEAN, model.E
+    assert model.E_std < C5_KAT_MAX
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("bits", [64, 32])
+def test_config5_heaviest_walkers_vs_oracle(dev, bits, capsys):
+    """configs[4] with the benchmark's flow and Z = 2, a production sweep of 8 192 walkers: EVERY walker of the top cost classes (the 192
+    most expensive by the flow pass's cost class -- close approaches to a vanishing radius, where the sensitivities take the most
+    steps and carry the largest error) plus the first 64 walkers of the batch, 256 in all, against the oracle's generic jet
+    arithmetic (O.eloc3d) at the north-star bar, for both precisions of the sensitivity matrices (config 2 had
+    this test, configs 4 / 5 did not)."""
+    from fermiflow_amd import native
+    model = _model3d(dev, 10, 10, 2.0, False)
+    prev = native.set_sens_precision(bits)
+    try:
+        torch.manual_seed(5)
+        g = model(8192)
+        g.backward()
+    finally:
+        native.set_sens_precision(prev)
+    cost = model.walker_cost.to(torch.int64)
+    order = torch.argsort(cost, descending=True, stable=True)
+    heavy = order[:192]
+    light = torch.arange(64, device=dev)
+    light = light[~torch.isin(light, heavy)]
+    idx = torch.cat([heavy, light])
+    ref = O.eloc3d(N(model.x[idx]), 10, 10, _onet(model), 2.0, rtol=1e-9, atol=1e-11)
+    rel = np.abs(N(model.Eloc[idx]) - ref["eloc"]) / np.abs(ref["eloc"])
+    nh = len(heavy)
+    with capsys.disabled():
+        print(f"\n[config 5, {bits}-bit sensitivity matrices] cost classes of the batch {int(cost.min())}..{int(cost.max())}; the {nh} heaviest "
+              f"(class >= {int(cost[heavy].min())}): max rel E_loc error vs oracle {rel[:nh].max():.2e}; {len(light)} ordinary walkers: {rel[nh:].max():.2e}")
+    assert rel.max() < ELOC_RTOL, rel.max()
+    np.testing.assert_allclose(N(model.Eloc[idx]).mean(), ref["eloc"].mean(), rtol=1e-6)
 
 
 @pytest.mark.parametrize("bits", [64, 32])
@@ -341,3 +379,110 @@ def test_driver_runs_the_three_dimensional_trap(dev, capsys):
     assert len(lines) == 2
     E = [float(ln.split("E:")[1].split()[0]) for ln in lines]
     assert all(np.isfinite(E)) and 60.0 < E[0] < 120.0 and E[0] != E[1]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# d = 3 against the REFERENCE (tests/golden/g7_3d.npz): log-density with gradient and Laplacian, bit-exact
+# Metropolis, the local energy and a whole GSVMC iteration with its six parameter gradients.
+
+def test_3d_log_density_vs_reference(golden, dev):
+    """FreeFermion.log_prob / y_grad_laplacian on (B, n, 3) walkers: LogAbsSlaterDet.apply (src/slater.py:13-62) of 1, 4 and 10 3-D
+    orbitals and the two-species log-density (src/base_dist.py:49-56) incl. configs[4]'s closed shells (10, 10)."""
+    import fermiflow_amd as ff
+    G = golden["g7_3d"]
+    h = ff.HO3D()
+    assert [(o.nx, o.ny, o.nz) for o in h.orbitals] == [tuple(r) for r in G["nxyz"].tolist()]
+    bd = ff.FreeFermion(device=dev)
+    for n in (1, 4, 10):
+        up = tuple(h.orbitals[k] for k in G[f"n{n}_orb"])
+        x = T(G[f"n{n}_x"], dev)
+        np.testing.assert_allclose(N(bd.log_prob(up, (), x)) / 2, G[f"n{n}_logabsdet"], atol=1e-12)
+        lp, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, up, ()), x)
+        np.testing.assert_allclose(N(lp) / 2, G[f"n{n}_logabsdet"], atol=1e-12)
+        np.testing.assert_allclose(N(g) / 2, G[f"n{n}_grad"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(N(lap) / 2, G[f"n{n}_lap"], rtol=1e-9, atol=1e-6)
+    for tag in ("lp36", "lp1010"):
+        up, dn = tuple(h.orbitals[k] for k in G[tag + "_up"]), tuple(h.orbitals[k] for k in G[tag + "_dn"])
+        lp, g, lap = ff.y_grad_laplacian(ff.utils.freefermion_logp(bd, up, dn), T(G[tag + "_x"], dev))
+        np.testing.assert_allclose(N(lp), G[tag + "_logp"], atol=1e-11)
+        np.testing.assert_allclose(N(g), G[tag + "_grad"], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(N(lap), G[tag + "_lap"], rtol=1e-8, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["m2d2", "m10d10", "m4d3"])
+def test_3d_mcmc_bit_exact_vs_reference(golden, dev, name):
+    """The Metropolis loop body of the reference (src/base_dist.py:63-70) on (B, n, 3) walkers from the torch-CPU noise stream:
+    acceptance indices and final walkers bit-identical -- the sixteen-lane sampler (m10d10: configs[4]'s determinants) and the
+    one-lane-per-walker kernels alike."""
+    import fermiflow_amd as ff
+    G = golden["g7_3d"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name, dim=3)
+    h = ff.HO3D()
+    bd = ff.FreeFermion(device=dev)
+    x, logp, acc = bd.sample_with_noise(h.orbitals[:nup], h.orbitals[:ndn], T(g0, dev), T(g, dev), T(u, dev))
+    assert (N(acc) == accept).all(), "acceptance indices differ from the reference"
+    assert (N(x) == G[name + "_x"]).all(), "final walkers are not bit-identical"
+    np.testing.assert_allclose(N(logp), G[name + "_logp"], atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["e2d2", "e5d4", "e1d1"])
+def test_3d_local_energy_vs_reference(golden, dev, name):
+    """logp, grad, Laplacian, V, E_loc per walker of y_grad_laplacian(GSVMC.logp, x) on 3-D walkers (src/utils.py:40-65 through the
+    nested adjoints; src/VMC.py:46-55) at the reference's default tolerance -- e2d2 on the wave-per-walker-group kernels (M = 12),
+    e5d4 on the one-walker-per-workgroup family (M = 27), e1d1 the column sweep."""
+    import fermiflow_amd as ff
+    G = golden["g7_3d"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    cnf = make_flow(*net_arrays(G, ""), dev)
+    model = ff.GSVMC(nup, ndn, ff.HO3D(), ff.FreeFermion(device=dev), cnf, ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
+    x = T(G[name + "_x"], dev)
+    np.testing.assert_allclose(N(cnf.generate(T(G[name + "_z"], dev))), G[name + "_x"], atol=2e-6)
+    zb, dl = cnf.delta_logp(x)
+    np.testing.assert_allclose(N(zb), G[name + "_zback"], atol=2e-6)
+    np.testing.assert_allclose(N(dl), G[name + "_dlogp"], atol=2e-6)
+    r = model.local_energy(x, want_stats=True)
+    assert int(r["stats"][3]) == 0
+    el = G[name + "_Eloc"]
+    assert (np.abs(N(r["eloc"]) - el) / np.abs(el)).max() < ELOC_RTOL
+    np.testing.assert_allclose(N(r["eloc"]), el, rtol=2e-7)         # what is actually achieved
+    np.testing.assert_allclose(N(r["logp"]), G[name + "_logp"], atol=1e-6)
+    np.testing.assert_allclose(N(r["grad"]), G[name + "_grad"], atol=1e-6)
+    np.testing.assert_allclose(N(r["lap"]), G[name + "_lap"], rtol=1e-7, atol=1e-5)
+    np.testing.assert_allclose(N(r["V"]), G[name + "_V"], rtol=1e-12)
+    if nup + ndn > 4:       # the same walkers with the sensitivity matrices in fp32 (configs[4]'s "fp32 MFMA path"), same bar
+        from fermiflow_amd import native
+        prev = native.set_sens_precision(32)
+        try:
+            r32 = model.local_energy(x)
+        finally:
+            native.set_sens_precision(prev)
+        assert (np.abs(N(r32["eloc"]) - el) / np.abs(el)).max() < ELOC_RTOL
+
+
+@pytest.mark.parametrize("name,rt,at,vtol,gtol", [("e2d2", 1e-10, 1e-12, 1e-7, 1e-6), ("e2d2", 1e-6, 1e-8, 1e-5, 1e-5),
+                                                  ("e5d4", 1e-10, 1e-12, 1e-7, 1e-6), ("e5d4", 1e-6, 1e-8, 1e-5, 3e-5),
+                                                  ("e1d1", 1e-10, 1e-12, 1e-7, 1e-6)])
+def test_3d_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gtol, capsys):
+    """GSVMC.forward -> .backward() end to end (src/VMC.py:40-59, src/FermionHO2D.py:69-72) on the reference's 3-D base walkers through
+    the production sweep: x, E, E_std, gradE and every parameter's .grad against the reference's own numbers.  (e5d4 at the default
+    tolerance: the gradient of FOUR walkers, nothing averages -- 1.4e-5 of its largest entry measured, E and E_loc inside 1e-5.)"""
+    import fermiflow_amd as ff
+    G = golden["g7_3d"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    cnf = make_flow(*net_arrays(G, ""), dev)
+    cnf.rtol, cnf.atol = rt, at
+    model = ff.GSVMC(nup, ndn, ff.HO3D(), ff.FreeFermion(device=dev), cnf, ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
+    for sweep in range(2):
+        gradE = model.forward_from(T(G[name + "_z"], dev))
+        model.zero_grad()
+        gradE.backward()
+        np.testing.assert_allclose(N(model.x), G[name + "_x"], atol=100 * rt)
+        np.testing.assert_allclose(model.E, float(G[name + "_E"]), rtol=vtol)
+        np.testing.assert_allclose(model.E_std, float(G[name + "_E_std"]), rtol=10 * vtol)
+        np.testing.assert_allclose(gradE.item(), float(G[name + "_gradE"]), rtol=100 * vtol, atol=1e-9)
+        ref = gsvmc_param_grads(G, name)
+        got = np.concatenate([N(p.grad).reshape(-1) for p in model.parameters()])
+        with capsys.disabled():
+            print(f"\n[3-D sweep vs reference, {name}, rtol {rt:g}, sweep {sweep}] E rel. error {abs(model.E / float(G[name + '_E']) - 1):.1e}, "
+                  f"gradient error {np.abs(got - ref).max() / np.abs(ref).max():.1e} of its largest entry")
+        np.testing.assert_allclose(got, ref, atol=gtol * np.abs(ref).max())

@@ -48,7 +48,7 @@ def test_philox_mcmc_equals_noise_path():
     # the stream itself (Box-Muller on 32-bit words in single precision, explicit sign bits; csrc/ff_rng.h): moments and a
     # Kolmogorov-Smirnov test of 123 000 normals, exact symmetry of the sign pattern aside (the GPU test repeats this on the
     # hardware transcendentals)
-    from scipy import stats
+    stats = pytest.importorskip("scipy.stats")          # (the only use of scipy in the host suite)
     h0, h, hu = S.rng_fill(512, 6, 20, 77, offset=0)
     z = h.ravel()
     assert abs(z.mean()) < 0.012 and abs(z.std() - 1) < 0.01 and abs(hu.mean() - 0.5) < 0.012
@@ -496,6 +496,14 @@ def test_ho3d_logprob_and_sampler(golden):
     xs, lps, cnt = S.mcmc3d(6, 4, 4, 8, 99)          # Philox sampler: closed shells 0..1 for both spins
     assert np.isfinite(xs).all() and 0 < cnt.sum() <= 6 * 8
     np.testing.assert_allclose(lps, O.logprob3d(xs, 4, 4, derivs=False), atol=1e-11)
+    # ... and it is the noise-fed chain on its own stream (ff_rng_fill3d), walkers and accept counts bit for bit -- also at the
+    # largest walker the entry point admits: 11 + 11 and 12 + 12 particles in d = 3 are 66 / 72 coordinates, more than the 64 normals
+    # the kernel's LDS staging held until round 5 (walker 0's normals overwrote walker 1's)
+    for nup, ndn, B, steps in ((4, 4, 6, 8), (11, 11, 3, 3), (12, 12, 2, 2)):
+        h0, h, hu = S.rng_fill(B, nup + ndn, steps, 99, dim=3)
+        x1, lp1, a1 = S.mcmc_noise3d(h0, h, hu, nup, ndn)
+        x2, lp2, c2 = S.mcmc3d(B, nup, ndn, steps, 99)
+        assert (x1 == x2).all() and (a1.sum(0) == c2).all(), (nup, ndn)
 
 
 def test_fp32_backflow_error_against_fp64(golden):

@@ -199,9 +199,9 @@ def test_gsvmc_estimator(golden):
 
 
 def test_ho3d_known_answer_eigenfunctions():
-    """The oracle's HO3D orbitals (no upstream code): orthonormal on a quadrature grid, and Slater determinants
-    of them are eigenfunctions -- E_loc == sum of orbital energies (shell + 3/2) at random points, the reference's
-    tests/test_basedist.py:5-60 one dimension up.  This is what pins the d = 3 oracle (there is no reference to import)."""
+    """The oracle's HO3D orbitals: orthonormal on a quadrature grid, and Slater determinants of them are eigenfunctions --
+    E_loc == sum of orbital energies (shell + 3/2) at random points, the reference's tests/test_basedist.py:5-60 one dimension
+    up.  (Since round 5 the d = 3 oracle is ALSO pinned to reference-derived goldens: the g7 tests below.)"""
     E3 = np.array([s + 1.5 for s in range(8) for nx in range(s + 1) for ny in range(s + 1 - nx)])
     ax = np.linspace(-6, 6, 41)
     pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
@@ -214,3 +214,68 @@ def test_ho3d_known_answer_eigenfunctions():
         lp, g, lap = O.logprob3d(x, nup, ndn, tab_up=iu, tab_dn=idn)
         eloc = -0.25 * lap - 0.125 * (g ** 2).sum(axis=(1, 2)) + 0.5 * (x ** 2).sum(axis=(1, 2))
         np.testing.assert_allclose(eloc, E3[iu].sum() + (E3[idn].sum() if ndn else 0.0), rtol=1e-10)
+
+
+# ---- d = 3 pinned to the REFERENCE (tests/golden/g7_3d.npz; make_golden.py group d3): the reference's dimension-generic code
+# ---- (LogAbsSlaterDet, FreeFermion.log_prob, y_grad_laplacian, the Metropolis loop body, Backflow, CNF, GSVMC.logp) run on
+# ---- (B, n, 3) walkers with 3-D orbital closures that are products of the reference's own HO2D closures.
+
+def test_3d_orbitals_and_slater_vs_reference(golden):
+    G = golden["g7_3d"]
+    nxyz = np.array([(nx, ny, s - nx - ny) for s in range(8) for nx in range(s + 1) for ny in range(s + 1 - nx)])
+    assert (G["nxyz"] == nxyz).all()                       # same list order as fermiflow_amd.orbitals.HO3D / the oracle
+    np.testing.assert_allclose(O.orbitals3d(np.arange(35), G["orb_pts"]), G["orb_vals"], rtol=1e-13, atol=1e-16)
+    for n in (1, 4, 10):
+        lp, g, lap = O.logprob3d(G[f"n{n}_x"], n, 0, tab_up=G[f"n{n}_orb"])
+        np.testing.assert_allclose(lp / 2, G[f"n{n}_logabsdet"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(g / 2, G[f"n{n}_grad"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(lap / 2, G[f"n{n}_lap"], rtol=1e-9, atol=1e-6)
+    for tag in ("lp36", "lp1010"):
+        iu, idn = G[tag + "_up"], G[tag + "_dn"]
+        lp, g, lap = O.logprob3d(G[tag + "_x"], len(iu), len(idn), tab_up=iu, tab_dn=idn)
+        np.testing.assert_allclose(lp, G[tag + "_logp"], atol=1e-11)
+        np.testing.assert_allclose(g, G[tag + "_grad"], rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(lap, G[tag + "_lap"], rtol=1e-9, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["m2d2", "m10d10", "m4d3"])
+def test_3d_mcmc_bit_exact_vs_reference(golden, name):
+    """The loop body of FreeFermion.sample (src/base_dist.py:63-70) on (B, n, 3) walkers: accept masks and final walkers
+    bit-identical to the reference's."""
+    G = golden["g7_3d"]
+    nup, ndn, g0, g, u, accept = mcmc_noise_from_seed(G, name, dim=3)
+    x, logp, acc = O.mcmc_noise3d(g0, g, u, nup, ndn)
+    assert (acc == accept).all()
+    assert (x == G[name + "_x"]).all()
+    np.testing.assert_allclose(logp, G[name + "_logp"], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["e2d2", "e5d4", "e1d1"])
+def test_3d_local_energy_and_gradient_vs_reference(golden, name):
+    """E_loc, logp, grad, Laplacian per walker, E, E_std, gradE and the six parameter gradients of a GSVMC iteration on 3-D
+    walkers (src/VMC.py:46-58 through y_grad_laplacian's nested adjoints) -- O.eloc3d and the d-generic flow / adjoint."""
+    G = golden["g7_3d"]
+    nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])
+    Z = float(G[name + "_Z"])
+    net = O.Net(*net_arrays(G, ""))
+    x = G[name + "_x"]
+    xg, _ = O.cnf_generate(G[name + "_z"], net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(xg, x, atol=1e-12)
+    r = O.eloc3d(x, nup, ndn, net, Z, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r["eloc"], G[name + "_Eloc"], rtol=1e-9)
+    np.testing.assert_allclose(r["logp"], G[name + "_logp"], atol=1e-9)
+    np.testing.assert_allclose(r["grad"], G[name + "_grad"], atol=1e-8)
+    np.testing.assert_allclose(r["lap"], G[name + "_lap"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(r["V"], G[name + "_V"], rtol=1e-13)
+    np.testing.assert_allclose(r["eloc"].mean(), float(G[name + "_E"]), rtol=1e-10)
+    np.testing.assert_allclose(r["eloc"].std(ddof=1), float(G[name + "_E_std"]), rtol=1e-8)
+    z, dl, _ = O.cnf_delta_logp(x, net, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(z, G[name + "_zback"], atol=1e-12)
+    np.testing.assert_allclose(dl, G[name + "_dlogp"], atol=1e-12)
+    lp0, g0, _ = O.logprob3d(z, nup, ndn)
+    el = G[name + "_Eloc"]
+    w = (el - el.mean()) / B
+    np.testing.assert_allclose(((lp0 - dl) * w).sum(), float(G[name + "_gradE"]), rtol=1e-8, atol=1e-12)
+    _, gp, _ = O.cnf_adjoint(z, dl, w[:, None, None] * g0, -w, net, rtol=1e-10, atol=1e-12)
+    ref = gsvmc_param_grads(G, name)
+    np.testing.assert_allclose(gp, ref, atol=1e-8 * np.abs(ref).max())
