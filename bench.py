@@ -153,8 +153,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the GPU reaches its steady clocks only after some ten iterations (tools/probes/warmup_sweep.sh: 1.93 ms per iteration
     # at --steps 5 --warmup 2, 1.89 at 10/2, 1.84 at 20/2, 1.81 at 20/5 and 20/10: every stage shrinks by the same factor)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
+    # (a 20-step window is 31 ms, two scheduler hiccups wide -- a bare run now times 200 steps; when the caller asks
+    # for fewer, a `long_window_leg` of 200 steps rides on the same line)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["gsvmc", "beta", "n12", "c5"], default="gsvmc")
     ap.add_argument("--walkers-per-gpu", type=int, default=0, help="default: 65536 (gsvmc, beta), 32768 (n12), 131072 (c5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -287,6 +289,26 @@ def main():
     w_head = (tuple(t.detach().cpu().numpy().copy() for t in (_v.eta.fc1.weight, _v.eta.fc1.bias, _v.eta.fc2.weight)),
               tuple(t.detach().cpu().numpy().copy() for t in (_v.mu.fc1.weight, _v.mu.fc1.bias, _v.mu.fc2.weight)))
     beta_head = (model.F, model.F_std, model.S) if wl == "beta" else None
+    # ---- the same loop over >= 200 steps (only when the caller's K is shorter): the headline's window at K = 20 is 31 ms
+    long_leg = None
+    if args.steps < 200 and wl != "c5" and not args.no_extras:
+        kl = 200
+        model.profile = {"stages": False}
+        fence()
+        t0l = time.perf_counter()
+        for _ in range(kl):
+            step()
+        fence()
+        dtl = time.perf_counter() - t0l
+        if world > 1:
+            tt = torch.tensor([dtl], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtl = tt.item()
+        pl, model.profile = model.profile, None
+        long_leg = {"steps": kl, "ms_per_step": dtl / kl * 1e3, "value": B_glob * 100 * kl / dtl,
+                    "rhs_evals_per_walker": sum(int(st_[0].item()) for st_ in pl["eloc_stats"]) / kl / wpg,
+                    "eloc_pass_ms": sum(a.elapsed_time(b) for a, b in pl["pass1"]) / kl,
+                    "note": "the headline loop continued for 200 more steps, same weights (lr as the headline), same instrumentation"}
     model.profile = {}
     fence()
     t0s = time.perf_counter()
@@ -299,15 +321,18 @@ def main():
     # ---- reference-semantics leg (VERDICT r03 next #3c): one tolerance for every component of every walker (sens_tol = 1), no
     #      routing by cost class (heavy_class < 0), Hairer's cold start for all three integrations -- what the policy in
     #      config.workload buys, and what it costs in accuracy: max E_loc error of both against a 1e-11 solve on the same base walkers
+    def eloc_error(z, mdl=None):
+        """max over the batch of |E_loc - E_loc(1e-11 solve)| / |E_loc| of the production sweep (mdl's policy) on base walkers z"""
+        mdl = mdl or model
+        g_ = mdl.forward_from(z, batch=B_glob)
+        x_, e_ = mdl.x, mdl.Eloc.clone()
+        tu_, td_ = mdl._tables(dev)
+        tight = native.eloc(tu_, td_, nup, ndown, mdl.cnf.v_wrapper.v.net(), x_, 0.0, 1.0, 1e-11, 1e-13, args.Z, True)["eloc"]
+        del g_
+        return ((e_ - tight).abs() / tight.abs()).max().item()
+
     ref_leg = None
     if wl == "gsvmc" and not args.no_extras:
-        def eloc_error(z):
-            g_ = model.forward_from(z, batch=B_glob)
-            x_, e_ = model.x, model.Eloc.clone()
-            tu_, td_ = model._tables(dev)
-            tight = native.eloc(tu_, td_, nup, ndown, gs.cnf.v_wrapper.v.net(), x_, 0.0, 1.0, 1e-11, 1e-13, args.Z, True)["eloc"]
-            del g_
-            return ((e_ - tight).abs() / tight.abs()).max().item()
         with torch.no_grad():
             zr = model.basedist.sample(model.orbitals_up, model.orbitals_down, (wpg,))
         err_policy = eloc_error(zr)
@@ -364,6 +389,61 @@ def main():
                    "steps": k2, "ms_per_step": dt2 / k2 * 1e3, "value": B_glob * 100 * k2 / dt2,
                    "rhs_evals_per_walker": ev2 / wpg, "eloc_kernel_ms": sum(a.elapsed_time(b) for a, b in p2["pass1"]) / k2,
                    "E": model.E, "E_std": model.E_std}
+        if wl == "gsvmc":      # the tolerance policy's error on THESE weights (VERDICT r04 next #1a), three fresh batches
+            errs = []
+            for sd in (11, 12, 13):
+                torch.manual_seed(sd)
+                with torch.no_grad():
+                    zt = model.basedist.sample(model.orbitals_up, model.orbitals_down, (wpg,))
+                errs.append(eloc_error(zt))
+            trained["headline_policy_eloc_max_rel_err"] = max(errs)
+            trained["headline_policy_eloc_max_rel_err_by_batch"] = errs
+            trained["bar"] = 1e-5
+
+    # ---- driver leg (VERDICT r04 next #1a; SURVEY 8(d) weights (i)): what a user of the drop-in driver runs -- init_zeros() flow
+    #      (src/FermionHO2D.py:40-43), Adam lr = 1e-2 (:61), the training loop of :66-72 for 300 iterations on this workload's walkers
+    driver = None
+    if wl == "gsvmc" and not args.no_extras:
+        dm = G._model(dev, nup, ndown, args.Z)
+        dv = dm.cnf.v_wrapper.v
+        dv.eta.init_zeros(); dv.mu.init_zeros()
+        dm.to(dev)
+        dopt = make_adam(dm.parameters(), lr=1e-2)
+        torch.manual_seed(4321)
+
+        def dstep():
+            g_ = dm(B_glob); dopt.zero_grad(); g_.backward(); dopt.step()
+        windows = {}
+        it = 0
+        for label, upto, width in (("iter_1", 10, 10), ("iter_100", 105, 10), ("iter_300", 300, 10)):
+            while it < upto - width:
+                dstep(); it += 1
+            dm.profile = {"stages": False}
+            fence()
+            t0d = time.perf_counter()
+            for _ in range(width):
+                dstep(); it += 1
+            fence()
+            dtd = time.perf_counter() - t0d
+            if world > 1:
+                tt = torch.tensor([dtd], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtd = tt.item()
+            pd, dm.profile = dm.profile, None
+            windows[label] = {"iterations": f"{it - width + 1}-{it}", "ms_per_step": dtd / width * 1e3, "value": B_glob * 100 * width / dtd,
+                              "rhs_evals_per_walker": sum(int(st_[0].item()) for st_ in pd["eloc_stats"]) / width / wpg,
+                              "eloc_pass_ms": sum(a.elapsed_time(b) for a, b in pd["pass1"]) / width, "E": dm.E, "E_std": dm.E_std}
+        errs = []
+        for sd in (21, 22, 23):
+            torch.manual_seed(sd)
+            with torch.no_grad():
+                zt = dm.basedist.sample(dm.orbitals_up, dm.orbitals_down, (wpg,))
+            errs.append(eloc_error(zt, dm))
+        driver = {"what": "init_zeros() flow, Adam lr=1e-2, 300 iterations of the reference's training loop (src/FermionHO2D.py:40-43,61-72) at "
+                          f"{wpg} walkers/GPU, Z={args.Z}; windows of 10 iterations",
+                  **windows, "max_abs_fc1_weight": max(dv.eta.fc1.weight.abs().max().item(), dv.mu.fc1.weight.abs().max().item()),
+                  "headline_policy_eloc_max_rel_err": max(errs), "headline_policy_eloc_max_rel_err_by_batch": errs, "bar": 1e-5}
+        del dm, dopt
 
     # ---- per-stage times and the dominant kernel's roofline (HIP events recorded on the launch stream)
     names = ["mcmc", "generate", "eloc", "estimator", "adjoint"]
@@ -401,7 +481,10 @@ def main():
                 "traffic": None, "avg_launch_ms": k_ms, "rhs_evals_per_walker": evals / wpg,
                 "flop_per_walker_eval": flop_per_eval, "radial_functions": radial,
                 # with the fused finish (matrix-core kernel, nup = ndown) J^T stays on chip: x in; z, grad, grad_z logp0 and five scalars out
-                "algorithmic_bytes": wpg * 8 * ((4 * M + 5) if (kind == "mfma" and nup == ndown) else (M + M * M + 4 * M + 1))}
+                # x in; z, grad logp, grad_z logp0 and five scalars out -- for EVERY kernel (the M^2 workspace the kernels
+                # without a fused finish write and re-read is traffic, not algorithm; `workspace_bytes` states it)
+                "algorithmic_bytes": wpg * 8 * (4 * M + 5),
+                "workspace_bytes": 0 if (kind == "mfma" and nup == ndown) else wpg * 8 * (M * M + 4 * M + 1)}
     # every kernel of the pass between the two events (routing: the heavy walkers' kernel and their two finish kernels run beside /
     # in the shadow of the throughput kernel): their counters are added up
     pass_kernels = [kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0]]
@@ -426,8 +509,37 @@ def main():
            "stages_note": "stage markers (hipEventRecord, ~8 us of pipeline bubble each) are not in the timed region: stages_ms is a second loop "
                           f"of {args.steps} steps right behind it, which ran at {dt_marked / args.steps * 1e3:.4f} ms per step with its markers",
            "roofline": roofline}
+    if long_leg is not None:
+        out["long_window_leg"] = long_leg
     if trained is not None:
         out["trained_leg"] = trained
+    if driver is not None:
+        out["driver_leg"] = driver
+    if world > 1:
+        # ---- the communicator the N > 1 numbers were measured on: backend, ranks, devices, and the two all-reduces
+        #      a sweep adds (four estimator sums; the 300-double gradient) timed alone, 100 repetitions each
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collectives_per_iteration": 2,
+                "rccl": (backend == "nccl")}
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev), "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "gcn_arch": getattr(props, "gcnArchName", "")}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        comm["ranks"] = gathered
+        from fermiflow_amd import dist as Dm
+        for label, nel in (("allreduce_4_doubles_us", 4), ("allreduce_300_doubles_us", 300)):
+            buf = torch.ones(nel, dtype=torch.float64, device=dev)
+            for _ in range(10):
+                Dm.all_reduce_sum_(buf)
+            fence()
+            t0c = time.perf_counter()
+            for _ in range(100):
+                Dm.all_reduce_sum_(buf)
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t0c) / 100 * 1e6], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            comm[label] = tt.item()
+        out["comm"] = comm
     if ref_leg is not None:
         out["reference_semantics_leg"] = ref_leg
     if wl == "beta":

@@ -144,9 +144,18 @@ class _Sweep:
         # class is <= sens_tol_class integrate J, the Laplacian of z and the Delta derivatives at sens_tol x rtol/atol and
         # open with _h_scale_loose x the flow's step; the others (close approaches) keep rtol/atol.  FERMIFLOW_SENS_TOL=1
         # restores one tolerance for everything.
-        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "10"))
-        self.sens_tol_class = 8
-        self._h_scale_loose = 1.0
+        # Round 5: 5 x for class <= 6 (rounds 2-4: 10 x for class <= 8).  Measured on 65 536 walkers x 5 seeds against a 1e-11 solve
+        # (tools/probes/policy_sweep.py; tests/golden/trained_weights.npz), max relative E_loc error, bar 1e-5:
+        #                      synthetic weights   +300 it. lr 1e-4   init_zeros +300 it. lr 1e-2   +1000 it.
+        #   10 x, class <= 8        4.3e-7             1.0e-5               4.0e-6                  1.3e-5     <- the walkers of class 7-8
+        #   10 x, class <= 6        5.7e-7             1.6e-6               6.7e-7                  3.1e-6
+        #    5 x, class <= 6        5.7e-7             1.6e-6               4.4e-7                  1.6e-6     (one tolerance: 1.6e-6 ... 5.5e-6)
+        # i.e. the old policy passed the bar only on the weights it was tuned on; as the flow strengthens the sensitivities grow and
+        # a 10 x looser control of them is a 1e-5 error.  Cost: none on the synthetic weights (13.3 -> 13.6 evaluations per walker),
+        # 5-15 % more evaluations on trained flows.
+        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "5"))
+        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6"))
+        self._h_scale_loose = 0.9
         # routing of the local-energy pass (ff_ode.heavy_class / heavy_tol / sum_weight; 0 = the library's defaults 12, 0.3, 4;
         # heavy_class < 0: no routing).  Reference semantics -- one tolerance, one kernel for every walker -- are
         # sens_tol = 1, heavy_class = -1 (FERMIFLOW_SENS_TOL=1 FERMIFLOW_HEAVY_CLASS=-1).

@@ -67,8 +67,9 @@ typedef struct ff_ode {
    * passes a point at which the field is merely C^1 (a vanishing radius).  walker_class (in, B): a cost class per walker --
    * walker_cost of the flow pass along the same trajectory.  Walkers with class <= sens_tol_class control those components at
    * sens_tol x (rtol, atol) -- their own coordinates keep rtol/atol -- and open with walker_h_init x walker_h_scale_loose
-   * (0: walker_h_scale); the others keep one tolerance for everything.  The sweeps pass sens_tol = 10, class 8, scale 1.0:
-   * 19.5 -> 13.6 evaluations per walker at 6 particles, 25.1 -> 14.1 at 12; E_loc error of the loose walkers <= 2e-7. */
+   * (0: walker_h_scale); the others keep one tolerance for everything.  The sweeps pass sens_tol = 5, class 6, scale 0.9
+   * (rounds 2-4: 10, 8, 1.0 -- 1.3e-5 relative E_loc error on trained flows, past the 1e-5 bar): 19.5 -> 13.6 evaluations per
+   * walker at 6 particles on the benchmark's weights; max E_loc error 1.6e-6 on those and on trained ones. */
   const int32_t* walker_class;
   double sens_tol;
   double walker_h_scale_loose;

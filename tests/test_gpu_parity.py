@@ -361,7 +361,7 @@ def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gt
     cnf.rtol, cnf.atol = rt, at
     model = ff.GSVMC(nup, ndn, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
                      ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
-    assert model.warm_start and model.sens_tol == 10.0      # the production settings: warm start + sensitivity-tolerance policy
+    assert model.warm_start and model.sens_tol == 5.0 and model.sens_tol_class == 6      # the production settings: warm start + sensitivity-tolerance policy
     for sweep in range(2):      # the second sweep opens its flow pass with the first one's mean step (warm start across sweeps)
         gradE = model.forward_from(T(G[name + "_z"], dev))
         model.zero_grad()
@@ -771,7 +771,7 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     hg, cost = torch.zeros(B, **f), torch.zeros(B, dtype=torch.int32, device=dev)
     x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
     loose = cost <= model.sens_tol_class
-    assert model.sens_tol == 10.0 and 0.85 < loose.double().mean().item() < 1.0
+    assert model.sens_tol == 5.0 and model.sens_tol_class == 6 and 0.8 < loose.double().mean().item() < 1.0
     tight = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
     a = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
                     walker_h_scale=model._h_scale_eloc)
@@ -795,6 +795,52 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
         m(4096); m(4096)
         Es.append(m.E)
     assert abs(Es[0] / Es[1] - 1) < 1e-7
+
+
+def _load_weight_set(model, W, tag):
+    v = model.cnf.v_wrapper.v
+    with torch.no_grad():
+        for nm, m in (("eta", v.eta), ("mu", v.mu)):
+            m.fc1.weight.copy_(torch.as_tensor(W[f"{tag}_{nm}_w1"]).reshape(-1, 1))
+            m.fc1.bias.copy_(torch.as_tensor(W[f"{tag}_{nm}_b1"]))
+            m.fc2.weight.copy_(torch.as_tensor(W[f"{tag}_{nm}_w2"]).reshape(1, -1))
+
+
+@pytest.mark.parametrize("tag", ["head", "trained", "driver", "driver1000"])
+def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
+    """VERDICT r04 next #1c.  The production sweep at BASELINE.json configs[1] -- tolerance policy by cost class, routing of the heavy
+    walkers, warm starts; GSVMC.forward_from, second (warm) sweep -- against a 1e-11 solve of the same walkers: the MAXIMUM relative
+    E_loc error over 5 seeds x 65 536 walkers, on the benchmark's synthetic weights ("head") and on three TRAINED weight sets
+    (tests/golden/trained_weights.npz, written by tools/probes/policy_error.py on the GPU: head + 300 iterations at lr 1e-4;
+    init_zeros() + 300 and + 1000 iterations of the reference's loop at lr 1e-2, src/FermionHO2D.py:40-43,61-72).
+    Bar of the north star: 1e-5.  Asserted: 3e-6 (measured 5.7e-7 / 1.6e-6 / 4.4e-7 / 1.6e-6).  The policy of rounds 2-4 (10 x for
+    class <= 8) measures 4.3e-7 / 1.0e-5 / 4.0e-6 / 1.3e-5 here -- it passed on the weights it was tuned on only."""
+    import os
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    if tag != "head":
+        _load_weight_set(model, np.load(os.path.join(os.path.dirname(__file__), "golden", "trained_weights.npz")), tag)
+    assert model.sens_tol == 5.0 and model.sens_tol_class == 6 and model.heavy_class == 0 and model.warm_start
+    tu, td = model._tables(dev)
+    worst, evals = [], []
+    for seed in range(500, 505):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (65536,))
+        model.forward_from(z)
+        model.profile = {"stages": False}
+        model.forward_from(z)
+        pr, model.profile = model.profile, None
+        tight = native.eloc(tu, td, 3, 3, model.cnf.v_wrapper.v.net(), model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+        rel = (model.Eloc - tight).abs() / tight.abs()
+        worst.append(rel.max().item())
+        evals.append(int(pr["eloc_stats"][0][0].item()) / 65536)
+        assert abs(model.Eloc.mean().item() / tight.mean().item() - 1) < 1e-8
+    with capsys.disabled():
+        print(f"\n[policy error, {tag} weights] max rel. E_loc error vs a 1e-11 solve by seed: " + " ".join(f"{w:.1e}" for w in worst) +
+              f"; RHS evaluations per walker {np.mean(evals):.1f}")
+    assert max(worst) < 3e-6, worst
 
 
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
