@@ -1274,15 +1274,37 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
 #define FF_ORD_SEG 2048
 FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
 
+// First-step scale of a cost class (ff_walker_schedule).  The local-energy pass opens every walker with scale x (the largest step the
+// flow pass accepted along the same trajectory); a first step that fails its error test costs a whole step -- six evaluations, for
+// the walker's wave -- a scale that is too small costs an extra step at the end.  On the benchmark's synthetic weights 0.9 is accepted
+// by 99 % of the walkers; after a few hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations
+// per walker where 23 do).  So the scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first
+// step -- more than 4 %: scale x 0.93; fewer than 1 %: x 1.02; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.
+// Error control is untouched: every step passes the same test whatever it opened with.
+FF_D double ff_scale_update(double cur, unsigned n, unsigned nr) {
+  if (!(cur > 0.0)) cur = 0.6;
+  if (n >= 64u) {
+    const double f = (double)nr / (double)n;
+    if (f > 0.04) cur *= 0.93;
+    else if (f < 0.01) cur *= 1.02;
+  }
+  return fmin(1.0, fmax(0.25, cur));
+}
+
 // pass 1: per-segment histogram (+ optionally the segment's sum of hval, fixed tree: the sweeps want the mean accepted step of
 // the flow pass, and a torch mean() was two more launches)
+// (ff_walker_schedule: + per-segment counts, by cost class, of the walkers of the PREVIOUS local-energy pass and of those whose first
+// step was rejected there -- the largest step that pass accepted for the walker, prev_he, is smaller than the step it opened with,
+// prev_hs; integer counts, so their sum over segments does not depend on any order)
 __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t B, const int32_t* __restrict__ cost,
                                                                         unsigned* __restrict__ hist, const double* __restrict__ hval,
-                                                                        double* __restrict__ hsum) {
-  __shared__ unsigned h[FF_ORD_BINS];
+                                                                        double* __restrict__ hsum, int64_t Bprev,
+                                                                        const int32_t* __restrict__ prev_cost, const double* __restrict__ prev_hs,
+                                                                        const double* __restrict__ prev_he, unsigned* __restrict__ pstat) {
+  __shared__ unsigned h[FF_ORD_BINS], pn[FF_ORD_BINS], pr[FF_ORD_BINS];
   __shared__ double sh[FF_ORD_THREADS];
   const int t = threadIdx.x;
-  if (t < FF_ORD_BINS) h[t] = 0;
+  if (t < FF_ORD_BINS) { h[t] = 0; pn[t] = 0; pr[t] = 0; }
   __syncthreads();
   const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
   double acc = 0.0;
@@ -1290,9 +1312,23 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
     atomicAdd(&h[ff_ord_row(cost[j0 + k])], 1u);
     if (hval) acc += hval[j0 + k];
   }
+  if (pstat) {
+    for (int k = t; k < FF_ORD_SEG && j0 + k < Bprev; k += FF_ORD_THREADS) {
+      const double hs0 = prev_hs[j0 + k], he0 = prev_he[j0 + k];
+      if (hs0 > 0.0 && he0 > 0.0) {       // (a failed or cold-started walker says nothing about the scale)
+        const int row = ff_ord_row(prev_cost[j0 + k]);
+        atomicAdd(&pn[row], 1u);
+        if (he0 < 0.999 * hs0) atomicAdd(&pr[row], 1u);
+      }
+    }
+  }
   sh[t] = acc;
   __syncthreads();
   if (t < FF_ORD_BINS) hist[(int64_t)blockIdx.x * FF_ORD_BINS + t] = h[t];
+  if (pstat && t < FF_ORD_BINS) {
+    pstat[((int64_t)blockIdx.x * FF_ORD_BINS + t) * 2] = pn[t];
+    pstat[((int64_t)blockIdx.x * FF_ORD_BINS + t) * 2 + 1] = pr[t];
+  }
   if (hval) {
     for (int q = FF_ORD_THREADS / 2; q > 0; q >>= 1) {
       if (t < q) sh[t] += sh[t + q];
@@ -1307,8 +1343,23 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
 __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t B, const int32_t* __restrict__ cost,
                                                                         const unsigned* __restrict__ hist, int nseg,
                                                                         int32_t* __restrict__ order, const double* __restrict__ hsum,
-                                                                        double* __restrict__ hmean) {
+                                                                        double* __restrict__ hmean, const unsigned* __restrict__ pstat,
+                                                                        int nseg_prev, const double* __restrict__ tab_in,
+                                                                        double* __restrict__ tab_out, const double* __restrict__ hval,
+                                                                        double* __restrict__ hs_out, double interval) {
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
+  // ff_walker_schedule: the first-step scale of every cost class, learned from the previous pass (ff_scale_update) -- every workgroup
+  // forms the same table from the same integer counts; workgroup 0 stores it for the next call
+  __shared__ double s_tab[FF_ORD_BINS];
+  if (tab_in && threadIdx.x < FF_ORD_BINS) {
+    const int row = threadIdx.x;                 // row 0 = class 31
+    unsigned n = 0, nr = 0;
+    if (pstat)
+      for (int k = 0; k < nseg_prev; k++) { n += pstat[((int64_t)k * FF_ORD_BINS + row) * 2]; nr += pstat[((int64_t)k * FF_ORD_BINS + row) * 2 + 1]; }
+    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr);
+    s_tab[row] = v;
+    if (blockIdx.x == 0 && tab_out) tab_out[FF_ORD_BINS - 1 - row] = v;
+  }
   if (hmean && blockIdx.x == 0 && threadIdx.x == 0) {      // the segments' sums in segment order: one fixed summation order
     double a = 0.0;
     for (int k = 0; k < nseg; k++) a += hsum[k];
@@ -1357,7 +1408,17 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
     for (int k = 0; k < PER; k++) { const unsigned c = cnt[row][part * PER + k]; cnt[row][part * PER + k] = off; off += c; }
   }
   __syncthreads();
-  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) order[cnt[ff_ord_row(cost[j0 + k])][t]++] = (int32_t)(j0 + k);
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
+    const int row = ff_ord_row(cost[j0 + k]);
+    order[cnt[row][t]++] = (int32_t)(j0 + k);
+    if (hs_out) {
+      // the largest step this class is trusted with -- and of the steps of that size the interval takes, the EQUAL ones: two steps of
+      // 0.5 are accepted where 0.57 + 0.43 risks a rejection for the same number of evaluations
+      double hq = hval[j0 + k] * s_tab[row];
+      if (interval > 0.0 && hq > 0.0 && hq < interval) hq = interval / ceil(interval / hq - 1e-9);
+      hs_out[j0 + k] = hq;
+    }
+  }
 }
 
 extern "C" {
@@ -1495,25 +1556,39 @@ int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, co
   return FF_OK;
 }
 
-// [nseg][BINS] histogram | nseg segment sums of hval
+// [nseg][BINS] histogram | nseg segment sums of hval | [nseg][BINS][2] statistics of the previous pass (ff_walker_schedule)
 size_t ff_walker_order_workspace_bytes(int64_t B) {
   const size_t nseg = (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
-  return sizeof(unsigned) * FF_ORD_BINS * nseg + sizeof(double) * nseg;
+  return sizeof(unsigned) * FF_ORD_BINS * nseg + sizeof(double) * nseg + sizeof(unsigned) * 2 * FF_ORD_BINS * nseg;
 }
 
-int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean) {
+int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
+                       const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
+                       double interval, double* hs_out) {
   FF_CHECK(B >= 0 && (B == 0 || (cost && order && workspace)), FF_EINVAL, "ff_walker_order: bad argument");
   FF_CHECK((hval == nullptr) == (hmean == nullptr), FF_EINVAL, "ff_walker_order_mean: hval and hmean go together");
   FF_CHECK(B < ((int64_t)1 << 31), FF_EUNSUPPORTED, "ff_walker_order: B >= 2^31");
+  FF_CHECK(scale_in == nullptr || (hval && hs_out && scale_out && scale_out != scale_in), FF_EINVAL,
+           "ff_walker_schedule: the scale table needs hval, hs_out and a second table to write");
+  FF_CHECK((prev_cost == nullptr) == (prev_hs == nullptr) && (prev_cost == nullptr) == (prev_he == nullptr) && (prev_cost == nullptr || scale_in),
+           FF_EINVAL, "ff_walker_schedule: prev_cost, prev_hs, prev_he go together (and with the scale table)");
   if (B == 0) return FF_OK;
   const int nseg = (int)((B + FF_ORD_SEG - 1) / FF_ORD_SEG);
   double* hsum = (double*)((unsigned*)workspace + (size_t)FF_ORD_BINS * nseg);
-  FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace, hval, hsum);
+  unsigned* pstat = prev_cost ? (unsigned*)(hsum + nseg) : nullptr;
+  // (the previous pass is this rank's shard of the same batch: the statistics cover min(B, B_prev) = B walkers of it)
+  FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace, hval, hsum, B, prev_cost, prev_hs,
+            prev_he, pstat);
   FF_LAUNCH_CHECK();
   FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order,
-            (const double*)hsum, hmean);
+            (const double*)hsum, hmean, (const unsigned*)pstat, nseg, scale_in, scale_out, hval, scale_in ? hs_out : (double*)nullptr,
+            interval);
   FF_LAUNCH_CHECK();
   return FF_OK;
+}
+
+int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean) {
+  return ff_walker_schedule(stream, B, cost, order, workspace, hval, hmean, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr);
 }
 
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {

@@ -300,6 +300,25 @@ def walker_order(cost, hval=None):
     return order, hmean
 
 
+def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0):
+    """ff_walker_schedule: (order, mean(hval) as a 1-element tensor, hs) with hs[b] = hval[b] * scale_in[cost[b]] -- the step every walker's
+    local-energy pass opens with; scale_out receives the table updated from the previous pass prev = (cost, hs, he) (None: copied)."""
+    cost = cost.contiguous()
+    if cost.dtype != torch.int32 or not cost.is_cuda:
+        raise ValueError("cost must be an int32 device tensor")
+    hval = L.dev(hval, name="hval")
+    order = torch.empty_like(cost)
+    hs = torch.empty_like(hval)
+    hmean = torch.empty(1, dtype=torch.float64, device=cost.device)
+    ws = torch.empty(max(1, (L.lib().ff_walker_order_workspace_bytes(L.i64(cost.numel())) + 7) // 8), dtype=torch.float64, device=cost.device)
+    pc, ph, pe = prev if prev is not None else (None, None, None)
+    if prev is not None and not (pc.numel() == ph.numel() == pe.numel() == cost.numel()):
+        raise ValueError("walker_schedule: the previous pass must have this call's batch size")
+    L.check(L.lib().ff_walker_schedule(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean),
+                                       L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.f64(abs(float(interval))), L.ptr(hs)), "ff_walker_schedule")
+    return order, hmean, hs
+
+
 def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0, out=None):
     """tensor [sum(e - shift), sum((e - shift)^2)] on the device; shift_dev: optional 1-element device tensor, then
     shift = shift_dev[0] * shift_dev_scale (no host round trip for the mean); out: where to write the two sums."""

@@ -96,7 +96,7 @@ typedef struct ff_ode {
   int32_t compact_finish;
 } ff_ode;
 
-int ff_version(void);   /* 104; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 105; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
@@ -112,6 +112,19 @@ int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order
 /* ff_walker_order that also returns hmean[0] = mean of hval (B) -- the sweeps open the next flow pass with the mean step size this
  * one accepted (ff_ode.walker_h_uniform), and the two launches of the schedule read the per-walker arrays anyway.  Fixed tree. */
 int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean);
+/* ff_walker_order_mean that also chooses the step every walker's local-energy pass opens with (ABI 105; no upstream counterpart -- the
+ * reference's solvers start cold, src/NeuralODE/nnModule.py:59-67): hs_out[b] = hval[b] * scale_out[cost[b]], scale a table of 32 factors
+ * by cost class (scale_in; entries <= 0 read as 0.6) that FOLLOWS the passes: given the previous pass of the same batch size --
+ * prev_cost (its classes), prev_hs (the steps it opened with, i.e. the previous call's hs_out), prev_he (its ff_ode.walker_h_out) --
+ * a class of which more than 4 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor, fewer than 1 %
+ * 1.02 x, within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  The updated table -- the one this call applies -- goes to
+ * scale_out (a second buffer: workgroups read scale_in while it is written); pass it as scale_in of the next call.  prev_* may be NULL
+ * (first call: scale_out = scale_in).  interval > 0 (= |t1 - t0| of the pass): the step is rounded DOWN to interval / k, the equal steps
+ * that cover the interval in as many steps as the scaled one would.  Integer counts and a fixed rule: the table is a deterministic function of the passes before it.  Pass hs_out
+ * as ff_ode.walker_h_init with walker_h_scale = walker_h_scale_loose = 1.  The error test of every step is untouched. */
+int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
+                       const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
+                       double interval, double* hs_out);
 const char* ff_last_error(void);
 /* Kernel family of the fused CNF kernels (ff_cnf_generate, ff_cnf_delta_logp, ff_eloc_sensitivities, ff_cnf_adjoint*):
  * 0 (default) = by particle number -- one wave per walker group up to 12 particles in d = 2 / 4 in d = 3, one walker per

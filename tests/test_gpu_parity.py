@@ -361,7 +361,7 @@ def test_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gt
     cnf.rtol, cnf.atol = rt, at
     model = ff.GSVMC(nup, ndn, ff.HO2D(), ff.FreeFermion(device=dev), cnf,
                      ff.CoulombPairPotential(float(G[name + "_Z"])), sp_potential=ff.HO())
-    assert model.warm_start and model.sens_tol == 5.0 and model.sens_tol_class == 6      # the production settings: warm start + sensitivity-tolerance policy
+    assert model.warm_start and model.sens_tol == 1.0 and model.adaptive_h      # the production settings: warm start, one tolerance, learned first steps
     for sweep in range(2):      # the second sweep opens its flow pass with the first one's mean step (warm start across sweeps)
         gradE = model.forward_from(T(G[name + "_z"], dev))
         model.zero_grad()
@@ -754,15 +754,16 @@ def test_heavy_walker_route_vs_oracle(dev, capsys):
 
 
 @pytest.mark.parametrize("nup,ndn,B", [(3, 3, 65536), (6, 6, 8192)])
-def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
-    """ff_ode.walker_class / sens_tol as GSVMC/BetaVMC sweeps use it: walkers whose flow-pass cost class is <= 8
-    integrate the sensitivity components at 10x rtol/atol, the others (a particle passing a C^1 point) at rtol/atol.  On a
-    full batch: a third fewer RHS evaluations, and the per-walker E_loc error against a 1e-11 solve stays where the uniform
-    tolerance has it -- the LOOSE walkers alone stay below 1e-6 (bar: 1e-5), the maximum over all walkers is set by the
-    strict ones and does not move.  Switching the policy off (sens_tol = 1) changes the sweep's E at the 1e-8 level."""
+def test_sensitivity_tolerance_mechanism(dev, nup, ndn, B):
+    """ff_ode.walker_class / sens_tol / sens_tol_class: walkers whose flow-pass cost class is <= sens_tol_class integrate
+    the sensitivity components at sens_tol x rtol/atol, the others at rtol/atol.  The sweeps of rounds 2-4 ran it at 10 x / class <= 8;
+    since round 5 they pass sens_tol = 1 (one tolerance: on trained flows the factor shows one for one in the worst walkers' E_loc,
+    test_headline_policy_error_over_seeds_and_weight_sets) -- the mechanism stays in the ABI and is checked here at 10 x / class <= 8 on
+    the synthetic weights: a third fewer RHS evaluations, the strict walkers untouched, the loose ones below 1e-6."""
     import __graft_entry__ as Gm
     from fermiflow_amd import native
     model = Gm._model(dev, nup, ndn, 2.0)
+    assert model.sens_tol == 1.0
     net = model.cnf.v_wrapper.v.net()
     tu, td = model._tables(dev)
     torch.manual_seed(13)
@@ -770,27 +771,23 @@ def test_sensitivity_tolerance_policy_of_the_sweep(dev, nup, ndn, B):
     f = dict(dtype=torch.float64, device=dev)
     hg, cost = torch.zeros(B, **f), torch.zeros(B, dtype=torch.int32, device=dev)
     x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8, walker_cost=cost, walker_h_out=hg)
-    loose = cost <= model.sens_tol_class
-    assert model.sens_tol == 5.0 and model.sens_tol_class == 6 and 0.8 < loose.double().mean().item() < 1.0
+    loose = cost <= 8
+    assert 0.85 < loose.double().mean().item() < 1.0
     tight = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
     a = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
                     walker_h_scale=model._h_scale_eloc)
     b = native.eloc(tu, td, nup, ndn, net, x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hg,
-                    walker_h_scale=model._h_scale_eloc, walker_class=cost, sens_tol=model.sens_tol,
-                    sens_tol_class=model.sens_tol_class, walker_h_scale_loose=model._h_scale_loose)
+                    walker_h_scale=model._h_scale_eloc, walker_class=cost, sens_tol=10.0, sens_tol_class=8, walker_h_scale_loose=1.0)
     assert int(a["stats"][3]) == 0 and int(b["stats"][3]) == 0
     assert int(b["stats"][0]) < 0.8 * int(a["stats"][0]), (a["stats"][:3], b["stats"][:3])
     ra, rb = (a["eloc"] / tight - 1).abs(), (b["eloc"] / tight - 1).abs()
-    # maximum over ALL walkers (set by the strict ones, i.e. by the walkers with a particle passing the origin): 4.9e-7 at 6
-    # particles (those walkers, class >= 12, are routed to the one-walker-per-wave kernel at 0.3 x the tolerances: csrc/ff_cnf_fwd.hip,
-    # launch_mfma; 2.1e-7 with the column kernel of rounds 1-2), 1.3e-6 at 12 -- bar 1e-5
     assert rb[loose].max().item() < 1e-6 and rb.max().item() < (1e-6 if nup + ndn <= 6 else 3e-6), (rb[loose].max(), rb.max())
     assert torch.equal(a["eloc"][~loose], b["eloc"][~loose]) or (rb[~loose].max() <= 2 * ra[~loose].max() + 1e-9)
     assert abs(b["eloc"].mean().item() / a["eloc"].mean().item() - 1) < 1e-7
     Es = []
     for tol in (10.0, 1.0):
         m = Gm._model(dev, nup, ndn, 2.0)
-        m.sens_tol = tol
+        m.sens_tol, m.sens_tol_class = tol, 8
         torch.manual_seed(21)
         m(4096); m(4096)
         Es.append(m.E)
@@ -808,39 +805,48 @@ def _load_weight_set(model, W, tag):
 
 @pytest.mark.parametrize("tag", ["head", "trained", "driver", "driver1000"])
 def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
-    """VERDICT r04 next #1c.  The production sweep at BASELINE.json configs[1] -- tolerance policy by cost class, routing of the heavy
-    walkers, warm starts; GSVMC.forward_from, second (warm) sweep -- against a 1e-11 solve of the same walkers: the MAXIMUM relative
-    E_loc error over 5 seeds x 65 536 walkers, on the benchmark's synthetic weights ("head") and on three TRAINED weight sets
-    (tests/golden/trained_weights.npz, written by tools/probes/policy_error.py on the GPU: head + 300 iterations at lr 1e-4;
-    init_zeros() + 300 and + 1000 iterations of the reference's loop at lr 1e-2, src/FermionHO2D.py:40-43,61-72).
-    Bar of the north star: 1e-5.  Asserted: 3e-6 (measured 5.7e-7 / 1.6e-6 / 4.4e-7 / 1.6e-6).  The policy of rounds 2-4 (10 x for
-    class <= 8) measures 4.3e-7 / 1.0e-5 / 4.0e-6 / 1.3e-5 here -- it passed on the weights it was tuned on only."""
+    """VERDICT r04 next #1c.  The production sweep at BASELINE.json configs[1] -- one tolerance for every component, first steps by cost
+    class from the learned table, routing of the heavy walkers; GSVMC.forward_from, several sweeps so that the table has settled --
+    against a 1e-11 solve of the same walkers: the MAXIMUM relative E_loc error over 5 seeds x 65 536 walkers, on the benchmark's
+    synthetic weights ("head") and on three TRAINED weight sets (tests/golden/trained_weights.npz, written by
+    tools/probes/policy_error.py on the GPU: head + 300 iterations at lr 1e-4; init_zeros() + 300 and + 1000 iterations of the
+    reference's loop at lr 1e-2, src/FermionHO2D.py:40-43,61-72).  Bar of the north star: 1e-5.
+    Measured (tools/probes/policy_sweep.py): 8.1e-7 / 1.7e-6 / 4.4e-7 / 6.7e-6 -- and that is the error of a plain rtol = 1e-6 solve
+    with a per-walker norm, which is what the sweep now is (the 10 x / class <= 8 policy of rounds 2-4: 4.3e-7 / 1.0e-5 / 4.0e-6 /
+    1.3e-5; 5 x / class <= 6: 8.1e-7 / 1.0e-5 / 4.4e-7 / 2.7e-5).  Asserted: 3e-6 (driver1000: 1e-5, where the plain solve itself is at
+    6.7e-6), and never worse than the stand-alone one-tolerance call on the same walkers."""
     import os
     import __graft_entry__ as Gm
     from fermiflow_amd import native
     model = Gm._model(dev, 3, 3, 2.0)
     if tag != "head":
         _load_weight_set(model, np.load(os.path.join(os.path.dirname(__file__), "golden", "trained_weights.npz")), tag)
-    assert model.sens_tol == 5.0 and model.sens_tol_class == 6 and model.heavy_class == 0 and model.warm_start
+    assert model.sens_tol == 1.0 and model.heavy_class == 0 and model.warm_start and model.adaptive_h
     tu, td = model._tables(dev)
-    worst, evals = [], []
+    worst, plain, evals = [], [], []
     for seed in range(500, 505):
         torch.manual_seed(seed)
         with torch.no_grad():
             z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (65536,))
-        model.forward_from(z)
+        for _ in range(3 if seed == 500 else 1):
+            model.forward_from(z)
         model.profile = {"stages": False}
         model.forward_from(z)
         pr, model.profile = model.profile, None
-        tight = native.eloc(tu, td, 3, 3, model.cnf.v_wrapper.v.net(), model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+        net = model.cnf.v_wrapper.v.net()
+        tight = native.eloc(tu, td, 3, 3, net, model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
         rel = (model.Eloc - tight).abs() / tight.abs()
         worst.append(rel.max().item())
+        one = native.eloc(tu, td, 3, 3, net, model.x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True)["eloc"]      # stand-alone: cold start, no classes
+        plain.append(((one - tight).abs() / tight.abs()).max().item())
         evals.append(int(pr["eloc_stats"][0][0].item()) / 65536)
         assert abs(model.Eloc.mean().item() / tight.mean().item() - 1) < 1e-8
     with capsys.disabled():
         print(f"\n[policy error, {tag} weights] max rel. E_loc error vs a 1e-11 solve by seed: " + " ".join(f"{w:.1e}" for w in worst) +
-              f"; RHS evaluations per walker {np.mean(evals):.1f}")
-    assert max(worst) < 3e-6, worst
+              " | plain one-tolerance call: " + " ".join(f"{w:.1e}" for w in plain) + f"; RHS evaluations per walker {np.mean(evals):.1f}; " +
+              "first-step factors by class 2..12: " + " ".join(f"{v:.2f}" for v in model._h_tab[model._h_tab_cur][2:13].tolist()))
+    assert max(worst) < (1e-5 if tag == "driver1000" else 3e-6), worst
+    assert max(worst) <= max(1.5 * max(plain), 3e-6), (worst, plain)
 
 
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):

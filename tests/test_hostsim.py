@@ -752,3 +752,30 @@ def test_one_launch_estimator_and_schedule_with_mean():
         cost = rng.integers(0, 40, size=B).astype(np.int32); h = rng.random(B)
         order, hm = S.walker_order(cost, hval=h)
         assert (order == S.walker_order(cost)).all() and abs(hm - h.mean()) < 1e-14
+        # ff_walker_schedule: the same order and mean, plus the first step of every walker from the factor table of its cost class --
+        # and the table follows the previous pass: classes of which > 4 % rejected their first step (he < hs) shrink by 0.93, < 1 % grow
+        # by 1.02 within [0.25, 1], classes with fewer than 64 walkers and walkers without a step keep theirs
+        tab = np.where(np.arange(32) <= 6, 0.9, 0.6)
+        o2, hm2, hs, tab1 = S.walker_schedule(cost, h, tab)
+        assert (o2 == order).all() and hm2 == hm and (tab1 == tab).all()
+        np.testing.assert_array_equal(hs, h * tab[np.minimum(cost, 31)])
+        he = hs.copy()
+        cls = np.minimum(cost, 31)
+        rej = (cls == 3) | ((cls == 5) & (rng.random(B) < 0.025)) | (cls == 31)
+        he[rej] *= 0.5
+        he[cls == 7] = 0.0                                   # a class whose walkers report no accepted step: no evidence
+        _, _, hs2, tab2 = S.walker_schedule(cost, h, tab1, prev=(cost, hs, he))
+        want = tab.copy()
+        for c in range(32):
+            n_c = int(((cls == c) & (he > 0)).sum()); r_c = int(((cls == c) & (he > 0) & (he < 0.999 * hs)).sum())
+            if n_c >= 64:
+                want[c] = min(1.0, max(0.25, tab[c] * (0.93 if r_c / n_c > 0.04 else (1.02 if r_c / n_c < 0.01 else 1.0))))
+        np.testing.assert_allclose(tab2, want, rtol=1e-15)
+        np.testing.assert_array_equal(hs2, h * tab2[cls])    # the update is applied at once: this pass opens with what the last one taught
+        # interval > 0: steps rounded down to interval / k
+        _, _, hs3, _ = S.walker_schedule(cost, h, tab, interval=1.0)
+        hq = h * tab[cls]
+        np.testing.assert_allclose(hs3, np.where(hq < 1.0, 1.0 / np.ceil(1.0 / hq - 1e-9), hq), rtol=1e-15)
+        assert (hs3 <= hq * (1 + 1e-12)).all()
+        if B >= 4100:      # (~100 walkers per class)
+            assert tab2[3] == tab[3] * 0.93 and tab2[0] == min(1.0, tab[0] * 1.02) and tab2[7] == tab[7]

@@ -24,9 +24,16 @@ def load(model, tag):
 configs = [(10, 8, 4), (1, 8, 4), (5, 8, 4), (3, 8, 4), (10, 7, 4), (10, 6, 4), (5, 7, 4), (10, 8, 16), (10, 8, 40), (5, 8, 16), (3, 8, 16), (30, 8, 40)]
 if os.environ.get("FF_POLICY_CONFIGS"):
     configs = [tuple(float(t) for t in c.split(",")) for c in os.environ["FF_POLICY_CONFIGS"].split(";")]
-for tag in ("head", "trained", "driver", "driver1000"):
+tags = os.environ.get("FF_POLICY_SETS", "head,trained,driver,driver1000").split(",")
+for tag in tags:
     model = G._model(dev, 3, 3, 2.0)
-    if tag != "head":
+    if tag == "bench_trained":      # what bench.py's trained leg measures: 300 iterations at lr 1e-4 from the synthetic weights
+        from fermiflow_amd.utils import make_adam
+        opt = make_adam(model.parameters(), lr=1e-4)
+        torch.manual_seed(1234)
+        for i in range(300):
+            g = model(B); opt.zero_grad(); g.backward(); opt.step()
+    elif tag != "head":
         load(model, tag)
     tu, td = model._tables(dev)
     zs, tights = [], []
@@ -42,7 +49,7 @@ for tag in ("head", "trained", "driver", "driver1000"):
         bmax = {b[0]: 0.0 for b in buckets}; bcnt = {b[0]: 0 for b in buckets}
         for k in range(nseeds):
             if len(zs) <= k:
-                torch.manual_seed(500 + k)
+                torch.manual_seed(int(os.environ.get('FF_POLICY_SEED0', '500')) + k)
                 with torch.no_grad():
                     zs.append(model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,)))
             model.forward_from(zs[k])
