@@ -165,6 +165,8 @@ class _Sweep:
         self._h_tab = None           # [2, 32] device table (double-buffered), row _h_tab_cur is current
         self._h_tab_cur = 0
         self._h_prev = None          # (cost, hs, he) of the previous local-energy pass
+        self._h_counts = None        # data-parallel runs: its first-step statistics, summed over the ranks, instead
+        self._h_counts_local = None
         # routing of the local-energy pass (ff_ode.heavy_class / heavy_tol / sum_weight; 0 = the library's defaults 12, 0.3, 4;
         # heavy_class < 0: no routing).  Reference semantics -- one tolerance, one kernel for every walker -- are
         # sens_tol = 1, heavy_class = -1 (FERMIFLOW_SENS_TOL=1 FERMIFLOW_HEAVY_CLASS=-1).
@@ -217,9 +219,16 @@ class _Sweep:
                 tab = torch.full((2, 32), float(self._h_scale_eloc), dtype=torch.float64, device=z.device)
                 tab[:, :self.sens_tol_class + 1] = self._h_scale_loose
                 self._h_tab, self._h_tab_cur, self._h_prev = tab, 0, None
-            prev = self._h_prev if (self._h_prev is not None and self._h_prev[0].shape[0] == nloc and self._h_prev[0].device == z.device) else None
             cur = self._h_tab_cur
-            order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], prev, interval=t1 - t0)
+            if D._active():
+                # data-parallel: the table follows the statistics of the GLOBAL batch (counted per shard behind the pass, summed in the
+                # estimator's all-reduce: _reduce_with_counts) -- every rank holds the same factors whatever the sharding
+                order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], None, interval=t1 - t0,
+                                                                 counts=self._h_counts)
+                self._h_counts = None
+            else:
+                prev = self._h_prev if (self._h_prev is not None and self._h_prev[0].shape[0] == nloc and self._h_prev[0].device == z.device) else None
+                order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], prev, interval=t1 - t0)
             self._h_tab_cur = 1 - cur
         elif warm and not per_walker_h:
             order, self._h_flow = native.walker_order(cost, hval=hg)      # the schedule and the mean accepted step from the same launches
@@ -239,14 +248,30 @@ class _Sweep:
                         sens_tol_class=self.sens_tol_class, walker_h_scale_loose=1.0 if hs is not None else self._h_scale_loose,
                         heavy_class=self.heavy_class, heavy_tol=self.heavy_tol, sum_weight=self.sum_weight,
                         compact=self.compact_finish)
+        self._h_counts_local = None
         if hs is not None:
-            self._h_prev = (cost, hs, he)
+            if D._active():
+                self._h_counts_local = native.scale_counts(cost, hs, he)
+            else:
+                self._h_prev = (cost, hs, he)
         _add_generic_potentials(r, x, extra)
         self._mark(ev, "eloc")
         if prof is not None:
             prof.setdefault("pass1", []).append(p1)
             prof.setdefault("eloc_stats", []).append(r["stats"])
         return x, r, he
+
+    def _reduce_with_counts(self, buf):
+        """all-reduce of the estimator's sums with the first-step statistics of this pass riding along (one collective, not two)"""
+        cl = getattr(self, "_h_counts_local", None)
+        if cl is None or not D._active():
+            return D.all_reduce_sum_(buf)
+        n = buf.numel()
+        both = torch.cat([buf.reshape(-1), cl])
+        D.all_reduce_sum_(both)
+        self._h_counts, self._h_counts_local = both[n:], None
+        buf.copy_(both[:n].view_as(buf))
+        return buf
 
     def _scalar(self, key):
         return self._dev[key].item()
@@ -263,6 +288,8 @@ class _Sweep:
             st["h_tab"] = self._h_tab[self._h_tab_cur].clone()
             if self._h_prev is not None:
                 st["h_prev"] = tuple(self._h_prev)
+            if self._h_counts is not None:
+                st["h_counts"] = self._h_counts.clone()
         if getattr(self, "_z_prev", None) is not None:
             st["z_prev"] = self._z_prev
         if getattr(self, "_z_next", None) is not None:      # prefetched walkers of the next iteration (GSVMC)
@@ -284,10 +311,11 @@ class _Sweep:
         self._resume_seed = None          # (a later load without prefetched walkers must not inherit an earlier load's key)
         self._resume_rng = None
         self._h_flow = st.get("h_flow")
-        self._h_tab, self._h_tab_cur, self._h_prev = None, 0, None
+        self._h_tab, self._h_tab_cur, self._h_prev, self._h_counts = None, 0, None, None
         if st.get("h_tab") is not None:
             self._h_tab = torch.stack([st["h_tab"], st["h_tab"]]).contiguous()
             self._h_prev = tuple(st["h_prev"]) if st.get("h_prev") is not None else None
+            self._h_counts = st.get("h_counts")
         self._dev = dict(st.get("dev", {}))
         self._n_global = st.get("n_global", 0)
         if "z_prev" in st:
@@ -488,7 +516,7 @@ class GSVMC(_Sweep, torch.nn.Module):
                 _, est = native.energy_estimate(Eloc, r["logp"], shift, batch)       # one launch: sums and finish (nothing to all-reduce)
             else:
                 sums, _ = native.energy_estimate(Eloc, r["logp"], shift, 0)
-                D.all_reduce_sum_(sums)
+                self._reduce_with_counts(sums)
                 est = native.energy_finish(sums, shift, batch)    # [E, sum (e - E)^2, mean(logp (e - E))]
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
@@ -657,7 +685,7 @@ class BetaVMC(_Sweep, torch.nn.Module):
             buf1 = native.beta_buffer(Ns, device)
             native.reduce_moments(Eloc, shift_dev=shE, out=buf1[:2])
             native.beta_state_partials(Eloc, r["logp"], ws, Ns, buf1)
-            D.all_reduce_sum_(buf1)
+            self._reduce_with_counts(buf1)
             logits = self.log_state_weights.detach().to(device)
             est, g_phi, mean_e, logp_all = native.beta_finish(buf1, shE, logits, self.beta, nglob)
             for k, key in enumerate(("E", "E_ss", "F", "F_ss", "S", "S_analytical")):

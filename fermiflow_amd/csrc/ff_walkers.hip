@@ -1346,7 +1346,8 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
                                                                         double* __restrict__ hmean, const unsigned* __restrict__ pstat,
                                                                         int nseg_prev, const double* __restrict__ tab_in,
                                                                         double* __restrict__ tab_out, const double* __restrict__ hval,
-                                                                        double* __restrict__ hs_out, double interval) {
+                                                                        double* __restrict__ hs_out, double interval,
+                                                                        const double* __restrict__ counts) {
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
   // ff_walker_schedule: the first-step scale of every cost class, learned from the previous pass (ff_scale_update) -- every workgroup
   // forms the same table from the same integer counts; workgroup 0 stores it for the next call
@@ -1354,7 +1355,9 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   if (tab_in && threadIdx.x < FF_ORD_BINS) {
     const int row = threadIdx.x;                 // row 0 = class 31
     unsigned n = 0, nr = 0;
-    if (pstat)
+    if (counts) {      // the previous pass' statistics summed over every rank's shard (ff_scale_counts + the caller's all-reduce)
+      n = (unsigned)counts[FF_ORD_BINS - 1 - row]; nr = (unsigned)counts[2 * FF_ORD_BINS - 1 - row];
+    } else if (pstat)
       for (int k = 0; k < nseg_prev; k++) { n += pstat[((int64_t)k * FF_ORD_BINS + row) * 2]; nr += pstat[((int64_t)k * FF_ORD_BINS + row) * 2 + 1]; }
     const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr);
     s_tab[row] = v;
@@ -1556,6 +1559,38 @@ int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, co
   return FF_OK;
 }
 
+// counts[c] += walkers of class c of this pass that opened with a step, counts[32 + c] += those of them whose first step was rejected
+// (integers in doubles: exact whatever the order of the atomics, and what an all-reduce over ranks adds up)
+__global__ void __launch_bounds__(FF_ORD_THREADS) ff_scale_counts_kernel(int64_t B, const int32_t* __restrict__ cost, const double* __restrict__ hs,
+                                                                         const double* __restrict__ he, double* __restrict__ counts) {
+  __shared__ unsigned pn[FF_ORD_BINS], pr[FF_ORD_BINS];
+  const int t = threadIdx.x;
+  if (t < FF_ORD_BINS) { pn[t] = 0; pr[t] = 0; }
+  __syncthreads();
+  const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
+    const double hs0 = hs[j0 + k], he0 = he[j0 + k];
+    if (hs0 > 0.0 && he0 > 0.0) {
+      const int c = FF_ORD_BINS - 1 - ff_ord_row(cost[j0 + k]);
+      atomicAdd(&pn[c], 1u);
+      if (he0 < 0.999 * hs0) atomicAdd(&pr[c], 1u);
+    }
+  }
+  __syncthreads();
+  if (t < FF_ORD_BINS) {
+    if (pn[t]) atomicAdd(&counts[t], (double)pn[t]);
+    if (pr[t]) atomicAdd(&counts[FF_ORD_BINS + t], (double)pr[t]);
+  }
+}
+
+int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double* counts64) {
+  FF_CHECK(B >= 0 && counts64 && (B == 0 || (cost && hs && he)), FF_EINVAL, "ff_scale_counts: bad argument");
+  if (B == 0) return FF_OK;
+  FF_LAUNCH(ff_scale_counts_kernel, (unsigned)((B + FF_ORD_SEG - 1) / FF_ORD_SEG), FF_ORD_THREADS, stream, B, cost, hs, he, counts64);
+  FF_LAUNCH_CHECK();
+  return FF_OK;
+}
+
 // [nseg][BINS] histogram | nseg segment sums of hval | [nseg][BINS][2] statistics of the previous pass (ff_walker_schedule)
 size_t ff_walker_order_workspace_bytes(int64_t B) {
   const size_t nseg = (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
@@ -1564,7 +1599,7 @@ size_t ff_walker_order_workspace_bytes(int64_t B) {
 
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
                        const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
-                       double interval, double* hs_out) {
+                       const double* prev_counts, double interval, double* hs_out) {
   FF_CHECK(B >= 0 && (B == 0 || (cost && order && workspace)), FF_EINVAL, "ff_walker_order: bad argument");
   FF_CHECK((hval == nullptr) == (hmean == nullptr), FF_EINVAL, "ff_walker_order_mean: hval and hmean go together");
   FF_CHECK(B < ((int64_t)1 << 31), FF_EUNSUPPORTED, "ff_walker_order: B >= 2^31");
@@ -1572,6 +1607,7 @@ int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* or
            "ff_walker_schedule: the scale table needs hval, hs_out and a second table to write");
   FF_CHECK((prev_cost == nullptr) == (prev_hs == nullptr) && (prev_cost == nullptr) == (prev_he == nullptr) && (prev_cost == nullptr || scale_in),
            FF_EINVAL, "ff_walker_schedule: prev_cost, prev_hs, prev_he go together (and with the scale table)");
+  FF_CHECK(prev_counts == nullptr || (scale_in && prev_cost == nullptr), FF_EINVAL, "ff_walker_schedule: prev_counts OR the previous pass' arrays");
   if (B == 0) return FF_OK;
   const int nseg = (int)((B + FF_ORD_SEG - 1) / FF_ORD_SEG);
   double* hsum = (double*)((unsigned*)workspace + (size_t)FF_ORD_BINS * nseg);
@@ -1582,13 +1618,13 @@ int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* or
   FF_LAUNCH_CHECK();
   FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order,
             (const double*)hsum, hmean, (const unsigned*)pstat, nseg, scale_in, scale_out, hval, scale_in ? hs_out : (double*)nullptr,
-            interval);
+            interval, prev_counts);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }
 
 int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean) {
-  return ff_walker_schedule(stream, B, cost, order, workspace, hval, hmean, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr);
+  return ff_walker_schedule(stream, B, cost, order, workspace, hval, hmean, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr);
 }
 
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {

@@ -300,7 +300,7 @@ def walker_order(cost, hval=None):
     return order, hmean
 
 
-def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0):
+def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, counts=None):
     """ff_walker_schedule: (order, mean(hval) as a 1-element tensor, hs) with hs[b] = hval[b] * scale_in[cost[b]] -- the step every walker's
     local-energy pass opens with; scale_out receives the table updated from the previous pass prev = (cost, hs, he) (None: copied)."""
     cost = cost.contiguous()
@@ -315,8 +315,16 @@ def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0):
     if prev is not None and not (pc.numel() == ph.numel() == pe.numel() == cost.numel()):
         raise ValueError("walker_schedule: the previous pass must have this call's batch size")
     L.check(L.lib().ff_walker_schedule(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean),
-                                       L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.f64(abs(float(interval))), L.ptr(hs)), "ff_walker_schedule")
+                                       L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.ptr(counts), L.f64(abs(float(interval))), L.ptr(hs)),
+            "ff_walker_schedule")
     return order, hmean, hs
+
+
+def scale_counts(cost, hs, he):
+    """ff_scale_counts: 64 doubles [walkers by cost class | of them, first step rejected] of a local-energy pass (this rank's shard)"""
+    counts = torch.zeros(64, dtype=torch.float64, device=cost.device)
+    L.check(L.lib().ff_scale_counts(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(hs), L.ptr(he), L.ptr(counts)), "ff_scale_counts")
+    return counts
 
 
 def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0, out=None):

@@ -119,12 +119,17 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * a class of which more than 4 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor, fewer than 1 %
  * 1.02 x, within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  The updated table -- the one this call applies -- goes to
  * scale_out (a second buffer: workgroups read scale_in while it is written); pass it as scale_in of the next call.  prev_* may be NULL
- * (first call: scale_out = scale_in).  interval > 0 (= |t1 - t0| of the pass): the step is rounded DOWN to interval / k, the equal steps
+ * (first call: scale_out = scale_in).  prev_counts (64 doubles, instead of prev_cost / prev_hs / prev_he): the same statistics already
+ * counted -- ff_scale_counts of the previous pass, summed over the ranks by the caller (fermiflow_amd adds them to the estimator's
+ * all-reduce), so that every rank of a data-parallel run holds the same table.  interval > 0 (= |t1 - t0| of the pass): the step is rounded DOWN to interval / k, the equal steps
  * that cover the interval in as many steps as the scaled one would.  Integer counts and a fixed rule: the table is a deterministic function of the passes before it.  Pass hs_out
  * as ff_ode.walker_h_init with walker_h_scale = walker_h_scale_loose = 1.  The error test of every step is untouched. */
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
                        const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
-                       double interval, double* hs_out);
+                       const double* prev_counts, double interval, double* hs_out);
+/* counts64[c] += walkers of cost class c that opened a local-energy pass with a step (hs > 0) and finished it (he > 0), counts64[32 + c] +=
+ * those whose first step was rejected (he < hs); the caller zeroes counts64.  Integers held in doubles: exact in any order. */
+int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double* counts64);
 const char* ff_last_error(void);
 /* Kernel family of the fused CNF kernels (ff_cnf_generate, ff_cnf_delta_logp, ff_eloc_sensitivities, ff_cnf_adjoint*):
  * 0 (default) = by particle number -- one wave per walker group up to 12 particles in d = 2 / 4 in d = 3, one walker per

@@ -460,12 +460,12 @@ def test_3d_local_energy_vs_reference(golden, dev, name):
 
 
 @pytest.mark.parametrize("name,rt,at,vtol,gtol", [("e2d2", 1e-10, 1e-12, 1e-7, 1e-6), ("e2d2", 1e-6, 1e-8, 1e-5, 1e-5),
-                                                  ("e5d4", 1e-10, 1e-12, 1e-7, 1e-6), ("e5d4", 1e-6, 1e-8, 1e-5, 3e-5),
+                                                  ("e5d4", 1e-10, 1e-12, 1e-7, 1e-6), ("e5d4", 1e-6, 1e-8, 1e-5, 1e-5),
                                                   ("e1d1", 1e-10, 1e-12, 1e-7, 1e-6)])
 def test_3d_gsvmc_forward_backward_vs_reference(golden, dev, name, rt, at, vtol, gtol, capsys):
     """GSVMC.forward -> .backward() end to end (src/VMC.py:40-59, src/FermionHO2D.py:69-72) on the reference's 3-D base walkers through
     the production sweep: x, E, E_std, gradE and every parameter's .grad against the reference's own numbers.  (e5d4 at the default
-    tolerance: the gradient of FOUR walkers, nothing averages -- 1.4e-5 of its largest entry measured, E and E_loc inside 1e-5.)"""
+    tolerance: the gradient of FOUR walkers, nothing averages -- 4e-6 of its largest entry measured.)"""
     import fermiflow_amd as ff
     G = golden["g7_3d"]
     nup, ndn, B, seed = (int(v) for v in G[name + "_cfg"])

@@ -772,6 +772,11 @@ def test_one_launch_estimator_and_schedule_with_mean():
                 want[c] = min(1.0, max(0.25, tab[c] * (0.93 if r_c / n_c > 0.04 else (1.02 if r_c / n_c < 0.01 else 1.0))))
         np.testing.assert_allclose(tab2, want, rtol=1e-15)
         np.testing.assert_array_equal(hs2, h * tab2[cls])    # the update is applied at once: this pass opens with what the last one taught
+        # the same update from the statistics counted separately (ff_scale_counts: what a data-parallel run all-reduces)
+        cnts = S.scale_counts(cost, hs, he)
+        assert cnts[:32].sum() == ((he > 0) & (hs > 0)).sum() and cnts[32:].sum() == ((he > 0) & (he < 0.999 * hs)).sum()
+        _, _, hs2c, tab2c = S.walker_schedule(cost, h, tab1, counts=cnts)
+        assert (tab2c == tab2).all() and (hs2c == hs2).all()
         # interval > 0: steps rounded down to interval / k
         _, _, hs3, _ = S.walker_schedule(cost, h, tab, interval=1.0)
         hq = h * tab[cls]
