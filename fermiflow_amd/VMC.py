@@ -58,6 +58,11 @@ class _SweepScalar(torch.Tensor):
         if fast is None or gradient is not None or inputs is not None or create_graph:
             return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
         params, flat = fast
+        # The short cut never runs the autograd graph, so tensor hooks on the parameters (register_hook,
+        # register_post_accumulate_grad_hook: DDP / FSDP reducers, hook-based clipping) would not fire: with any hook present take the
+        # ordinary path.  Note that on the short cut the parameters' .grad are VIEWS of one flat buffer.
+        if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
+            return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
         off = 0
         for p in params:
             n = p.numel()

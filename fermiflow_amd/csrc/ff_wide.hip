@@ -937,6 +937,9 @@ static void launch_wide_eloc(void* stream, const ff_fwd_args& a, int n) {
 
 int ff_wide_eloc_heavy(void* stream, int n, int d, const ff_fwd_args& a, int64_t max_groups) {
   if (!ff_wide_supported(n, d) || (n * d + 4 + 15) / 16 != 1 || !a.evt || a.queue) return FF_EUNSUPPORTED;   // (table kernel, T = 1, grid-stride)
+#ifdef FF_WIDE_NO_FIN      // (diagnostic build without the fused-finish instantiations: a caller that counts on them must hear it -- ADVICE r04)
+  if (a.fin.on & 2) { ff_set_error("this build (FF_WIDE_NO_FIN) has no fused finish: ff_ode.compact_finish is not available"); return FF_EUNSUPPORTED; }
+#endif
   const unsigned grid = (unsigned)(a.B < max_groups ? a.B : max_groups);
 #ifndef FF_WIDE_NO_FIN
   if (a.fin.on & 2) {
@@ -955,6 +958,9 @@ int ff_wide_dispatch_fwd(int mode, void* stream, int n, int d, const ff_fwd_args
     ff_set_error("fused CNF kernels serve n <= 24 particles with n*d <= 60 in d = 2, 3");
     return FF_EUNSUPPORTED;
   }
+#ifdef FF_WIDE_NO_FIN
+  if (mode >= 2 && (a.fin.on & 2)) { ff_set_error("this build (FF_WIDE_NO_FIN) has no fused finish: ff_ode.compact_finish is not available"); return FF_EUNSUPPORTED; }
+#endif
   if (mode == 0) { if (d == 2) launch_wide_flow<2, 0>(stream, a, n); else launch_wide_flow<3, 0>(stream, a, n); }
   else if (mode == 1) { if (d == 2) launch_wide_flow<2, 1>(stream, a, n); else launch_wide_flow<3, 1>(stream, a, n); }
   else {

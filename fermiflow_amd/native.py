@@ -352,14 +352,16 @@ def reduce_energy(e, logp, shift_dev):
     return out
 
 
-_EST_WS = {}      # (device, B) -> zero-initialised workspace of ff_energy_estimate (its counter is left at zero by every call)
+_EST_WS = {}      # (device, stream, B) -> zero-initialised workspace of ff_energy_estimate (its counter is left at zero by every call)
 
 
 def energy_estimate(e, logp, shift_dev, n_global):
     """ff_energy_estimate: (sums4, est3) in one launch; n_global = 0: sums4 only (est3 is None) -- all-reduce it, then energy_finish."""
     e = L.dev(e, name="e"); logp = L.dev(logp, name="logp"); shift_dev = L.dev(shift_dev.reshape(1), name="shift_dev")
     B = e.numel()
-    key = (str(e.device), B)
+    # the workspace (last-workgroup counter + per-segment partials) is the caller's per call STREAM (include/fermiflow.h): two sweeps on
+    # different streams of one device must not share it (ADVICE r04)
+    key = (str(e.device), int(torch.cuda.current_stream(e.device).cuda_stream), B)
     ws = _EST_WS.get(key)
     if ws is None:
         if len(_EST_WS) > 64:
@@ -367,8 +369,12 @@ def energy_estimate(e, logp, shift_dev, n_global):
         ws = _EST_WS[key] = torch.zeros(L.lib().ff_energy_estimate_workspace_bytes(L.i64(B)) // 8, dtype=torch.float64, device=e.device)
     sums = torch.empty(4, dtype=torch.float64, device=e.device)
     est = torch.empty(3, dtype=torch.float64, device=e.device) if n_global else None
-    L.check(L.lib().ff_energy_estimate(L.stream(), L.i64(B), L.ptr(e), L.ptr(logp), L.ptr(shift_dev), L.i64(n_global), L.ptr(sums), L.ptr(est),
-                                       L.ptr(ws)), "ff_energy_estimate")
+    try:
+        L.check(L.lib().ff_energy_estimate(L.stream(), L.i64(B), L.ptr(e), L.ptr(logp), L.ptr(shift_dev), L.i64(n_global), L.ptr(sums), L.ptr(est),
+                                           L.ptr(ws)), "ff_energy_estimate")
+    except Exception:
+        _EST_WS.pop(key, None)      # a launch that did not run to its end may have left the counter non-zero: never reuse this workspace
+        raise
     return sums, est
 
 

@@ -101,11 +101,20 @@ int ff_version(void);   /* 105; changes whenever a struct of this header changes
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
 int ff_shutdown(void);
-/* There is no ff_comm_init / _allreduce / _destroy (SURVEY 8b's minimum set names them): the multi-GPU estimator needs two
- * all-reduces of <= 2.4 KB per iteration and the host side (fermiflow_amd/dist.py) issues them through torch.distributed's
- * "nccl" backend (= RCCL) on the device buffers ff_reduce_energy / ff_beta_state_partials / ff_cnf_adjoint* fill.  A caller
- * that drives this ABI without torch sums those buffers over its ranks with its own communicator between the same calls;
- * the library itself never communicates. */
+/* The estimator's collectives for a caller that drives this ABI WITHOUT torch: per sweep ONE all-reduce of the
+ * buffer ff_energy_estimate (n_global = 0) / ff_beta_state_partials fills, then ONE of the 3(He+Hm)-double gradient of
+ * ff_cnf_adjoint* -- thin wrappers of RCCL (ncclCommInitRank / ncclAllReduce(ncclFloat64, ncclSum) / ncclCommDestroy), which is bound at
+ * run time (dlopen of the RCCL the process already holds, else librccl.so.1; FF_RCCL_LIB overrides) so that libfermiflow_hip.so itself
+ * has no RCCL dependency.  The Python package does not use them: torch.distributed's "nccl" backend is RCCL and owns the communicator
+ * there (fermiflow_amd/dist.py); everything else in this library never communicates.
+ *   ff_comm_unique_id: rank 0 obtains the 128-byte id and hands it to the other ranks by whatever launched them;
+ *   ff_comm_init: collective over the world_size ranks, each on its own current device (one process per GPU);
+ *   ff_comm_allreduce: in-place sum of `count` doubles on `stream`;   ff_comm_destroy: NULL is a no-op. */
+typedef struct ff_comm ff_comm;
+int ff_comm_unique_id(void* id128);
+int ff_comm_init(ff_comm** comm, int world_size, int rank, const void* id128);
+int ff_comm_allreduce(ff_comm* comm, void* stream, double* buf, int64_t count);
+int ff_comm_destroy(ff_comm* comm);
 /* order (B) = walker indices sorted by descending cost (ties in a fixed order; classes above 31 count as 31); cost (B) >= 0, e.g. ff_ode.walker_cost. */
 size_t ff_walker_order_workspace_bytes(int64_t B);
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace);

@@ -176,3 +176,31 @@ def test_eight_ranks_strong_scaling_dry_run():
     assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_walkers"] == 65536
     assert abs(eight["E"] - one["E"]) < 1e-12 * abs(one["E"]), (eight["E"], one["E"])
     assert abs(eight["E_std"] - one["E_std"]) < 1e-10 * one["E_std"]
+
+
+def test_ff_comm_single_rank_all_reduce():
+    """ff_comm_* (SURVEY 8(b)'s minimum symbol set; include/fermiflow.h): the RCCL wrappers a torch-free caller sums the estimator's
+    buffers with.  One rank on the one GPU of the test box: id, init, an in-place all-reduce of the 4-double and the 300-double
+    buffer of a sweep on torch's current stream (a one-rank sum is the identity), destroy.  More ranks need more devices (RCCL refuses
+    two ranks on one GPU); the driver's 8-GPU bench goes through torch.distributed, whose "nccl" backend is the same RCCL."""
+    import ctypes as C
+    from fermiflow_amd import _lib as L
+    lib = L.lib()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    uid = (C.c_char * 128)()
+    L.check(lib.ff_comm_unique_id(uid), "ff_comm_unique_id")
+    comm = C.c_void_p()
+    L.check(lib.ff_comm_init(C.byref(comm), 1, 0, uid), "ff_comm_init")
+    try:
+        for n in (4, 300):
+            buf = torch.arange(1, n + 1, dtype=torch.float64, device=dev) / 7
+            want = buf.clone()
+            L.check(lib.ff_comm_allreduce(comm, L.stream(), L.ptr(buf), L.i64(n)), "ff_comm_allreduce")
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want)
+        assert lib.ff_comm_allreduce(comm, L.stream(), None, L.i64(3)) != 0            # null buffer: FF_EINVAL, no crash
+    finally:
+        L.check(lib.ff_comm_destroy(comm), "ff_comm_destroy")
+    assert lib.ff_comm_destroy(None) == 0
+    assert lib.ff_comm_init(C.byref(comm), 2, 5, uid) != 0                            # rank outside the world

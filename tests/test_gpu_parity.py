@@ -849,6 +849,75 @@ def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
     assert max(worst) <= max(1.5 * max(plain), 3e-6), (worst, plain)
 
 
+@pytest.mark.parametrize("shape", ["c2", "c5"])
+def test_throughput_sampler_distribution_vs_parity_sampler(dev, shape, capsys):
+    """VERDICT r04 next #8.  The production Metropolis kernels (FreeFermion.sample: Philox, Box-Muller on the fp32 transcendentals,
+    determinant-ratio accept test -- no longer the reference's arithmetic) against the parity-mode kernels
+    (sample_with_noise: the reference's arithmetic operation for operation, src/base_dist.py:62-70) fed fp64 torch noise: the
+    DISTRIBUTION they sample must be the same.  Five independent batches each; E and E_std of one flow and <sum r^2> of the base
+    walkers agree within 4 standard errors of the difference (walkers are independent chains: the standard error of a batch mean is
+    sigma / sqrt(B) exactly).  c2: BASELINE.json configs[1], 65 536 walkers of 3 + 3 particles (ff_mcmc_spin_philox_kernel<3>);
+    c5: configs[4]'s sixteen-lane sampler, 16 384 walkers of 10 + 10 particles in d = 3."""
+    import __graft_entry__ as Gm
+    import fermiflow_amd as ff
+    if shape == "c2":
+        B, n, d = 65536, 6, 2
+        model = Gm._model(dev, 3, 3, 2.0)
+    else:
+        B, n, d = 16384, 20, 3
+        gs = Gm._model(dev, 2, 2, 2.0)
+        model = ff.GSVMC(10, 10, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+    bd, up, dn = model.basedist, model.orbitals_up, model.orbitals_down
+    stats = {"philox": [], "noise": []}
+    for seed in range(5):
+        torch.manual_seed(900 + seed)
+        z1 = bd.sample(up, dn, (B,))
+        gen = torch.Generator(device=dev); gen.manual_seed(7000 + seed)
+        g0 = torch.randn(B, n, d, dtype=torch.float64, device=dev, generator=gen)
+        g = torch.randn(100, B, n, d, dtype=torch.float64, device=dev, generator=gen)
+        u = torch.rand(100, B, dtype=torch.float64, device=dev, generator=gen)
+        z2, _, acc = bd.sample_with_noise(up, dn, g0, g, u)
+        del g0, g, u
+        for key, z in (("philox", z1), ("noise", z2)):
+            model.forward_from(z)
+            r2 = (z ** 2).sum(dim=(1, 2))
+            stats[key].append((model.E, model.E_std, r2.mean().item(), r2.std().item()))
+    a, b = np.array(stats["philox"]), np.array(stats["noise"])
+    nE = 5 * B
+    sig_E = np.sqrt((a[:, 1] ** 2).mean() + (b[:, 1] ** 2).mean()) / np.sqrt(nE)          # s.e. of the difference of the two 5-batch means
+    sig_r = np.sqrt((a[:, 3] ** 2).mean() + (b[:, 3] ** 2).mean()) / np.sqrt(nE)
+    dE, dr = a[:, 0].mean() - b[:, 0].mean(), a[:, 2].mean() - b[:, 2].mean()
+    with capsys.disabled():
+        print(f"\n[sampler distribution, {shape}] E philox {a[:, 0].mean():.5f} vs noise-fed {b[:, 0].mean():.5f}: difference {dE:+.2e} = {dE / sig_E:+.2f} s.e.; "
+              f"E_std {a[:, 1].mean():.4f} vs {b[:, 1].mean():.4f}; <sum r^2> {a[:, 2].mean():.5f} vs {b[:, 2].mean():.5f}: {dr / sig_r:+.2f} s.e.")
+    assert abs(dE) < 4 * sig_E and abs(dr) < 4 * sig_r, (dE, sig_E, dr, sig_r)
+    # E_std: a heavy-tailed quantity (Coulomb cusp), its batch-to-batch spread is the yardstick
+    spread = np.sqrt(a[:, 1].var(ddof=1) + b[:, 1].var(ddof=1)) / np.sqrt(5) + 1e-12
+    assert abs(a[:, 1].mean() - b[:, 1].mean()) < 4 * spread + 0.02 * b[:, 1].mean()
+
+
+def test_backward_short_cut_respects_parameter_hooks(dev):
+    """VMC._SweepScalar: `gradE.backward()` hands the adjoint's gradient views straight to .grad -- unless a parameter carries a
+    tensor hook (register_hook / register_post_accumulate_grad_hook: DDP reducers, hook-based clipping), in which case the ordinary
+    autograd path runs and the hook fires; both paths give the same gradients."""
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 3, 3, 2.0)
+    torch.manual_seed(3)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (2048,))
+    g = model.forward_from(z); g.backward()
+    fast = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    seen = []
+    p0 = next(model.parameters())
+    h1 = p0.register_hook(lambda gr: seen.append("pre") or gr)
+    h2 = p0.register_post_accumulate_grad_hook(lambda p: seen.append("post"))
+    g = model.forward_from(z); g.backward()
+    h1.remove(); h2.remove()
+    assert seen == ["pre", "post"]
+    for a, p in zip(fast, model.parameters()):
+        assert torch.equal(a, p.grad)
+
+
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
     """GSVMC.prefetch_walkers (default on): the next iteration's Metropolis kernel is started on a side stream beside this
     iteration's adjoint.  Same seeds in the same order -> the same walkers: three training iterations with and without it
