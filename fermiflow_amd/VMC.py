@@ -21,7 +21,7 @@ import torch
 
 from . import dist as D
 from . import native
-from .orbitals import orbital_indices
+from .orbitals import orbital_indices, orbital_dim
 
 
 class _ScalarWithParamGrads(torch.autograd.Function):
@@ -133,7 +133,7 @@ class _Sweep:
     """What GSVMC and BetaVMC share: flow + local energy of given base walkers with the walker schedule and the
     step-size warm start, the lazily converted device scalars, and the checkpointable sweep state."""
 
-    def _init_sweep(self, n):
+    def _init_sweep(self, n, dim=2):
         # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats.  {"stages": False}: only the event pair around the
         # local-energy pass and its statistics -- every stage marker is a hipEventRecord, ~8 us of pipeline bubble on this GPU
         self.profile = None
@@ -157,8 +157,13 @@ class _Sweep:
         # looser than the reference's own control, src/NeuralODE/nnModule.py:161-162); what the cost classes still decide is the step a
         # walker opens with (_h_tab below) and the routing of the heavy walkers.  FERMIFLOW_SENS_TOL=10 FERMIFLOW_SENS_TOL_CLASS=8 is the
         # old policy.
-        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "1"))
-        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6"))
+        # Beyond 12 coordinates the plain solve is 5-20 x more accurate in E_loc (larger |E_loc|, more terms to average over: max error
+        # 1e-7 .. 3.7e-7 at 6 + 6 particles and 9e-8 .. 1.9e-7 at configs[4] on synthetic, trained and driver-trained flows), and one
+        # tolerance costs 20-40 % more evaluations there: those systems keep a factor 3 for the walkers of class <= 8 (measured max
+        # 4.9e-7; 10 x: 2.4e-6 at configs[4]).
+        big = n * dim > 12
+        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "3" if big else "1"))
+        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "8" if big else "6"))
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
         # (ff_walker_schedule: more than 4 % of a class rejected their first step -> x 0.93, fewer than 1 % -> x 1.02; the step is
@@ -365,7 +370,7 @@ class GSVMC(_Sweep, torch.nn.Module):
         self.cnf = cnf
         self.pair_potential = pair_potential
         self.sp_potential = sp_potential
-        self._init_sweep(nup + ndown)
+        self._init_sweep(nup + ndown, orbital_dim(tuple(self.orbitals_up) + tuple(self.orbitals_down)))
         # Persistent walkers (off by default: the reference draws fresh N(0,1) walkers and runs 100 steps in every
         # iteration, src/base_dist.py:62-64): keep the chains and advance them `persistent_steps` steps per sweep.
         self.persistent_walkers = False
@@ -556,7 +561,7 @@ class BetaVMC(_Sweep, torch.nn.Module):
         self.cnf = cnf
         self.pair_potential = pair_potential
         self.sp_potential = sp_potential
-        self._init_sweep(nup + ndown)
+        self._init_sweep(nup + ndown, orbital_dim(tuple(self.states[0][0]) + tuple(self.states[0][1])))
         self._ws = None
 
     E = property(lambda self: self._scalar("E"))

@@ -10,6 +10,16 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 W = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "trained_weights.npz"))
+NUP, NDN, DIM = (int(t) for t in os.environ.get("FF_POLICY_SHAPE", "3,3,2").split(","))
+NTRAIN = int(os.environ.get("FF_POLICY_TRAIN_ITERS", "300"))
+
+
+def build():
+    if DIM == 2:
+        return G._model(dev, NUP, NDN, 2.0)
+    import fermiflow_amd as ff
+    gs = G._model(dev, 2, 2, 2.0)
+    return ff.GSVMC(NUP, NDN, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
 
 
 def load(model, tag):
@@ -26,13 +36,22 @@ if os.environ.get("FF_POLICY_CONFIGS"):
     configs = [tuple(float(t) for t in c.split(",")) for c in os.environ["FF_POLICY_CONFIGS"].split(";")]
 tags = os.environ.get("FF_POLICY_SETS", "head,trained,driver,driver1000").split(",")
 for tag in tags:
-    model = G._model(dev, 3, 3, 2.0)
+    model = build()
     if tag == "bench_trained":      # what bench.py's trained leg measures: 300 iterations at lr 1e-4 from the synthetic weights
         from fermiflow_amd.utils import make_adam
         opt = make_adam(model.parameters(), lr=1e-4)
         torch.manual_seed(1234)
-        for i in range(300):
+        for i in range(NTRAIN):
             g = model(B); opt.zero_grad(); g.backward(); opt.step()
+    elif tag.startswith("driver_train:"):      # init_zeros() + N iterations of the reference's loop at lr 1e-2 (src/FermionHO2D.py:40-43,61-72)
+        from fermiflow_amd.utils import make_adam
+        v = model.cnf.v_wrapper.v
+        v.eta.init_zeros(); v.mu.init_zeros(); model.to(dev)
+        opt = make_adam(model.parameters(), lr=1e-2)
+        torch.manual_seed(1234)
+        for i in range(int(tag.split(":")[1])):
+            g = model(B); opt.zero_grad(); g.backward(); opt.step()
+        print("   E", model.E, "max|w1|", v.eta.fc1.weight.abs().max().item(), v.mu.fc1.weight.abs().max().item(), flush=True)
     elif tag != "head":
         load(model, tag)
     tu, td = model._tables(dev)
@@ -59,7 +78,7 @@ for tag in tags:
             torch.cuda.synchronize()
             pr, model.profile = model.profile, None
             if len(tights) <= k:
-                tights.append(native.eloc(tu, td, 3, 3, model.cnf.v_wrapper.v.net(), model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"])
+                tights.append(native.eloc(tu, td, NUP, NDN, model.cnf.v_wrapper.v.net(), model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"])
             rel = (model.Eloc - tights[k]).abs() / tights[k].abs()
             mx.append(rel.max().item()); p9999.append(rel.quantile(0.9999).item())
             cost = model.walker_cost
