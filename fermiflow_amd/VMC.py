@@ -159,14 +159,15 @@ class _Sweep:
         # old policy.
         # Beyond 12 coordinates the plain solve is 5-20 x more accurate in E_loc (larger |E_loc|, more terms to average over: max error
         # 1e-7 .. 3.7e-7 at 6 + 6 particles and 9e-8 .. 1.9e-7 at configs[4] on synthetic, trained and driver-trained flows), and one
-        # tolerance costs 20-40 % more evaluations there: those systems keep a factor 3 for the walkers of class <= 8 (measured max
-        # 4.9e-7; 10 x: 2.4e-6 at configs[4]).
-        big = n * dim > 12
-        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "3" if big else "1"))
-        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "8" if big else "6"))
+        # tolerance costs 30-40 % more evaluations there (a third step for every walker).  Those systems keep a factor for the walkers of
+        # class <= 8 -- 10 up to 24 coordinates (measured max 7.6e-7 / 4.3e-7 / 4.3e-7 at 6 + 6 particles on synthetic / trained /
+        # driver-trained flows), 5 beyond (configs[4]: 1.2e-6 / 2.6e-7; 10 x: 2.4e-6 / 7.7e-7) -- tools/probes/policy_sweep.py.
+        M = n * dim
+        self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "1" if M <= 12 else ("10" if M <= 24 else "5")))
+        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6" if M <= 12 else "8"))
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
-        # (ff_walker_schedule: more than 4 % of a class rejected their first step -> x 0.93, fewer than 1 % -> x 1.02; the step is
+        # (ff_walker_schedule: more than 20 % of a class rejected their first step -> x 0.93, fewer than 5 % -> x 1.02; the step is
         # then rounded down to interval / k: equal steps).  A fixed factor is
         # right for one set of weights only: 0.9 is accepted by 99 % of the walkers on the synthetic weights and rejected by 80 % after
         # 300 training iterations -- a whole wasted step each (29 evaluations per walker where 23 do).  Device-resident, no host round

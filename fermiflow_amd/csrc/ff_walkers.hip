@@ -1275,18 +1275,21 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
 FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
 
 // First-step scale of a cost class (ff_walker_schedule).  The local-energy pass opens every walker with scale x (the largest step the
-// flow pass accepted along the same trajectory); a first step that fails its error test costs a whole step -- six evaluations, for
-// the walker's wave -- a scale that is too small costs an extra step at the end.  On the benchmark's synthetic weights 0.9 is accepted
-// by 99 % of the walkers; after a few hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations
-// per walker where 23 do).  So the scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first
-// step -- more than 4 %: scale x 0.93; fewer than 1 %: x 1.02; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.
+// flow pass accepted along the same trajectory), rounded down to equal steps.  A first step that fails its error test costs a whole
+// step -- six evaluations, for the walker's wave -- but so does a scale that is too small, for EVERY walker of the class (one more of the
+// equal steps): a rejection rate of 10 % is worth about 0.6 evaluations per walker (2 on the four-walkers-per-wave kernel, whose walkers
+// wait for each other), the extra step 6.  On the benchmark's synthetic weights 0.9 is accepted by 99 % of the walkers; after a few
+// hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations per walker where 23 do).  So the
+// scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than 20 %: scale
+// x 0.93; fewer than 5 %: x 1.02; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (Round 5's first thresholds, 4 % and
+// 1 %, traded 6 evaluations of every walker for 7 of one in twenty: 13.9 -> 19.7 evaluations at 6 + 6 particles.)
 // Error control is untouched: every step passes the same test whatever it opened with.
 FF_D double ff_scale_update(double cur, unsigned n, unsigned nr) {
   if (!(cur > 0.0)) cur = 0.6;
   if (n >= 64u) {
     const double f = (double)nr / (double)n;
-    if (f > 0.04) cur *= 0.93;
-    else if (f < 0.01) cur *= 1.02;
+    if (f > 0.20) cur *= 0.93;
+    else if (f < 0.05) cur *= 1.02;
   }
   return fmin(1.0, fmax(0.25, cur));
 }

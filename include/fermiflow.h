@@ -125,7 +125,7 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * reference's solvers start cold, src/NeuralODE/nnModule.py:59-67): hs_out[b] = hval[b] * scale_out[cost[b]], scale a table of 32 factors
  * by cost class (scale_in; entries <= 0 read as 0.6) that FOLLOWS the passes: given the previous pass of the same batch size --
  * prev_cost (its classes), prev_hs (the steps it opened with, i.e. the previous call's hs_out), prev_he (its ff_ode.walker_h_out) --
- * a class of which more than 4 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor, fewer than 1 %
+ * a class of which more than 20 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor, fewer than 5 %
  * 1.02 x, within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  The updated table -- the one this call applies -- goes to
  * scale_out (a second buffer: workgroups read scale_in while it is written); pass it as scale_in of the next call.  prev_* may be NULL
  * (first call: scale_out = scale_in).  prev_counts (64 doubles, instead of prev_cost / prev_hs / prev_he): the same statistics already

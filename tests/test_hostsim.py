@@ -753,7 +753,7 @@ def test_one_launch_estimator_and_schedule_with_mean():
         order, hm = S.walker_order(cost, hval=h)
         assert (order == S.walker_order(cost)).all() and abs(hm - h.mean()) < 1e-14
         # ff_walker_schedule: the same order and mean, plus the first step of every walker from the factor table of its cost class --
-        # and the table follows the previous pass: classes of which > 4 % rejected their first step (he < hs) shrink by 0.93, < 1 % grow
+        # and the table follows the previous pass: classes of which > 20 % rejected their first step (he < hs) shrink by 0.93, < 5 % grow
         # by 1.02 within [0.25, 1], classes with fewer than 64 walkers and walkers without a step keep theirs
         tab = np.where(np.arange(32) <= 6, 0.9, 0.6)
         o2, hm2, hs, tab1 = S.walker_schedule(cost, h, tab)
@@ -761,7 +761,7 @@ def test_one_launch_estimator_and_schedule_with_mean():
         np.testing.assert_array_equal(hs, h * tab[np.minimum(cost, 31)])
         he = hs.copy()
         cls = np.minimum(cost, 31)
-        rej = (cls == 3) | ((cls == 5) & (rng.random(B) < 0.025)) | (cls == 31)
+        rej = (cls == 3) | ((cls == 5) & (rng.random(B) < 0.12)) | (cls == 31)
         he[rej] *= 0.5
         he[cls == 7] = 0.0                                   # a class whose walkers report no accepted step: no evidence
         _, _, hs2, tab2 = S.walker_schedule(cost, h, tab1, prev=(cost, hs, he))
@@ -769,7 +769,7 @@ def test_one_launch_estimator_and_schedule_with_mean():
         for c in range(32):
             n_c = int(((cls == c) & (he > 0)).sum()); r_c = int(((cls == c) & (he > 0) & (he < 0.999 * hs)).sum())
             if n_c >= 64:
-                want[c] = min(1.0, max(0.25, tab[c] * (0.93 if r_c / n_c > 0.04 else (1.02 if r_c / n_c < 0.01 else 1.0))))
+                want[c] = min(1.0, max(0.25, tab[c] * (0.93 if r_c / n_c > 0.20 else (1.02 if r_c / n_c < 0.05 else 1.0))))
         np.testing.assert_allclose(tab2, want, rtol=1e-15)
         np.testing.assert_array_equal(hs2, h * tab2[cls])    # the update is applied at once: this pass opens with what the last one taught
         # the same update from the statistics counted separately (ff_scale_counts: what a data-parallel run all-reduces)

@@ -91,4 +91,5 @@ for tag in tags:
             ms.append(sum(a.elapsed_time(b) for a, b in pr["pass1"]) / 3)
             dE.append(abs(model.Eloc.mean().item() / tights[k].mean().item() - 1))
         print(f"  sens_tol {st:g} class<={sc:g} sum_w {sw:g}: max err {max(mx):.2e} p99.99 {max(p9999):.2e} mean-E {max(dE):.1e} | h_scale_loose {model._h_scale_loose:g} evals {np.mean(evs):.2f} rejected steps/walker {np.mean(rej):.3f} pass {np.mean(ms):.3f} ms\n      by class: " +
-              "  ".join(f"{k}: {bmax[k]:.1e} ({bcnt[k] // nseeds})" for k in bmax), flush=True)
+              "  ".join(f"{k}: {bmax[k]:.1e} ({bcnt[k] // nseeds})" for k in bmax) +
+              ("\n      first-step factors, classes 2..14: " + " ".join(f"{v:.2f}" for v in model._h_tab[model._h_tab_cur][2:15].tolist()) if model._h_tab is not None else ""), flush=True)
