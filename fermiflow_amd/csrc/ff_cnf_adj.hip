@@ -158,42 +158,45 @@ FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict_
   ff_row_add(sW, ovf, t, rc.j, c);
 }
 
-// The five records of one accepted step (stages 0, 2, 3, 4, 5 with the b-weights of the tableau).  Within a step the
-// radius moves a little and in one direction, so the records fall on one node or on two neighbours: they are summed
-// in two register accumulators and deposited once each (24 LDS atomics instead of 60); a record on a third node (rare;
-// the branch is skipped when no lane of the wave needs it) goes separately.
+// The five records of one accepted step (stages 0, 2, 3, 4, 5 with the b-weights of the tableau).  Within a step the radius moves a
+// little and in one direction: the records are re-expanded about ONE node -- the one nearest to their mean radius -- summed in a
+// register accumulator and deposited once (12 LDS atomics per radius and step; rounds 1-4 kept two accumulators for the two
+// neighbouring nodes the records fell on: 24 atomics for most radii, 66 M per launch at config 2 -- a third of the kernel, processed at
+// less than one lane-operation per cycle and CU).  A record farther than 1.5 node spacings from the centre (a radius that moves by
+// more than 0.19 within one step: rare; the branch is skipped when no lane of the wave needs it) goes separately about its own node.
+// Truncation: the expansion is of order 11 in w1 dr with |dr| <= 1.5 h_d here, and the table is declared usable only while
+// max|w1| h_d <= 0.4 (ff_radial.h: 0.6 while |dr| <= h_d / 2 ... h_d) -- (0.6)^12 / 12! as before.
 FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& q0, const ff_rec& q2,
                       const ff_rec& q3, const ff_rec& q4, const ff_rec& q5, double hw) {
   if (hw == 0.0) return;
   const ff_rec* rc[5] = {&q0, &q2, &q3, &q4, &q5};
   const double bw[5] = {hw * FF_B0, hw * FF_B2, hw * FF_B3, hw * FF_B4, hw * FF_B5};
-  const int jA = q0.j;
-  int jB = jA;
+  constexpr double HD = 1.0 / FF_DEP_INVH;
+  double rm = 0.0;
 #pragma unroll
-  for (int e = 4; e >= 1; e--) jB = (rc[e]->j != jA) ? rc[e]->j : jB;   // the first node other than jA (jA if there is none)
-  double accA[FF_DEP_ROW], accB[FF_DEP_ROW];
+  for (int e = 0; e < 5; e++) rm += fma((double)rc[e]->j, HD, rc[e]->dr);
+  double jcf = rint(rm * (0.2 * FF_DEP_INVH));
+  jcf = fmin(fmax(jcf, 0.0), (double)(FF_DEP_NTOT - 1));
+  const int jC = (rm == rm) ? (int)jcf : 0;
+  double acc[FF_DEP_ROW];
 #pragma unroll
-  for (int k = 0; k < FF_DEP_ROW; k++) { accA[k] = 0.0; accB[k] = 0.0; }
+  for (int k = 0; k < FF_DEP_ROW; k++) acc[k] = 0.0;
 #pragma unroll
   for (int e = 0; e < 5; e++) {
-    const int j = rc[e]->j;
-    if (j == jA || j == jB) {
-      const double wA = (j == jA) ? bw[e] : 0.0, wB = (j == jA) ? 0.0 : bw[e];
-      double pk = 1.0, pm = 0.0;
+    const double dr = fma((double)(rc[e]->j - jC), HD, rc[e]->dr);
+    if (fabs(dr) <= 1.5 * HD) {
+      double pk = bw[e], pm = 0.0;      // w dr^k/k!, w dr^(k-1)/(k-1)!
 #pragma unroll
       for (int k = 0; k < FF_DEP_ROW; k++) {
-        const double c = fma(rc[e]->ca, pk, rc[e]->cb * pm);
-        accA[k] = fma(wA, c, accA[k]);
-        accB[k] = fma(wB, c, accB[k]);
+        acc[k] += fma(rc[e]->ca, pk, rc[e]->cb * pm);
         pm = pk;
-        pk = pk * rc[e]->dr * (1.0 / (k + 1));
+        pk = pk * dr * (1.0 / (k + 1));
       }
     } else {
       ff_deposit(sW, ovf, t, *rc[e], bw[e]);
     }
   }
-  ff_row_add(sW, ovf, t, jA, accA);
-  if (jB != jA) ff_row_add(sW, ovf, t, jB, accB);
+  ff_row_add(sW, ovf, t, jC, acc);
 }
 
 #ifndef FF_ADJ_WPS

@@ -60,7 +60,8 @@ FF_D void ff_sigma_derivs(double s, double* out) {
 // ---- "deposit" grid of the tabulated adjoint (ff_cnf_adj.hip): the parameter gradient of
 //   sum_records w [ca f(r) + cb f'(r)]  with  f(r) = sum_k T[j][k] dr^k/k!  is  sum_{j,k} Wacc[j][k] dT[j][k]/dtheta,
 // so the kernel only accumulates Wacc (coefficients ca dr^k/k! + cb dr^(k-1)/(k-1)!) on a coarse grid, h_d = 1/16,
-// expansion order 11, and one small kernel contracts Wacc with dT/dtheta at the end.  Usable while max|w1| h_d <= 0.6.
+// expansion order 11, and one small kernel contracts Wacc with dT/dtheta at the end.  Usable while max|w1| h_d <= 0.4
+// (the kernels expand up to 1.5 h_d from a node: ff_deposit5).
 #define FF_DEP_INVH 16.0
 #ifndef FF_DEP_NLDS
 #define FF_DEP_NLDS 128                     // nodes kept in LDS (r < 8); the rest (r < 32) goes to a global table
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __res
     tab[1] = hstep;
     tab[2] = (double)nodes;
     tab[3] = bad ? 1.0 : 0.0;
-    tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.6) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
+    tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.4) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
     for (int q = 5; q < FF_TAB_HDR; q++) tab[q] = 0.0;
   }
   if (bad) return;

@@ -1271,7 +1271,7 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
 // keep a fixed order (segment, thread, index).  Workspace: FF_ORD_BINS counters per FF_ORD_SEG walkers.
 #define FF_ORD_BINS 32
 #define FF_ORD_THREADS 256
-#define FF_ORD_SEG 2048
+#define FF_ORD_SEG 512      // (2048 until round 5: 32 workgroups for 65 536 walkers left seven eighths of the GPU idle for two launches)
 FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
 
 // First-step scale of a cost class (ff_walker_schedule).  The local-energy pass opens every walker with scale x (the largest step the
