@@ -228,7 +228,7 @@ class _Sweep:
         if warm and not per_walker_h and self.adaptive_h:
             if self._h_tab is None or self._h_tab.device != z.device:
                 tab = torch.full((2, 32), float(self._h_scale_eloc), dtype=torch.float64, device=z.device)
-                tab[:, :self.sens_tol_class + 1] = self._h_scale_loose
+                tab[:, :9] = self._h_scale_loose          # classes <= 8 open with 0.9 x the flow's step; the table takes it from there
                 self._h_tab, self._h_tab_cur, self._h_prev = tab, 0, None
             cur = self._h_tab_cur
             if D._active():

@@ -1294,6 +1294,23 @@ FF_D double ff_scale_update(double cur, unsigned n, unsigned nr) {
   return fmin(1.0, fmax(0.25, cur));
 }
 
+// Sort key of a walker in ff_walker_schedule: its cost class -- raised by four for every equal step beyond two that its local-energy pass
+// is planned to take (interval / (hval x the class's factor), rounded up).  The four walkers of a wave of the matrix-core kernel advance
+// in lockstep, so a wave takes as many evaluations as its slowest walker: walkers that will take three steps belong with each other (and
+// with the close-approach classes, which take that many anyway), not scattered over the two-step waves of their class.  The key only
+// orders the work; tolerances, routing and the table's statistics go by the class itself.
+FF_D int ff_sched_key(int c, double hv, const double* __restrict__ tab, double interval) {
+  int cc = c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c);
+  if (tab == nullptr || !(interval > 0.0) || !(hv > 0.0)) return cc;
+  double f = tab[cc];
+  if (!(f > 0.0)) f = 0.6;
+  const double hq = hv * f;
+  int k = hq >= interval ? 1 : (int)ceil(interval / hq - 1e-9);
+  k = k > 8 ? 8 : k;
+  const int key = cc + 4 * (k > 2 ? k - 2 : 0);
+  return key > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : key;
+}
+
 // pass 1: per-segment histogram (+ optionally the segment's sum of hval, fixed tree: the sweeps want the mean accepted step of
 // the flow pass, and a torch mean() was two more launches)
 // (ff_walker_schedule: + per-segment counts, by cost class, of the walkers of the PREVIOUS local-energy pass and of those whose first
@@ -1303,7 +1320,8 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
                                                                         unsigned* __restrict__ hist, const double* __restrict__ hval,
                                                                         double* __restrict__ hsum, int64_t Bprev,
                                                                         const int32_t* __restrict__ prev_cost, const double* __restrict__ prev_hs,
-                                                                        const double* __restrict__ prev_he, unsigned* __restrict__ pstat) {
+                                                                        const double* __restrict__ prev_he, unsigned* __restrict__ pstat,
+                                                                        const double* __restrict__ tab_in, double interval) {
   __shared__ unsigned h[FF_ORD_BINS], pn[FF_ORD_BINS], pr[FF_ORD_BINS];
   __shared__ double sh[FF_ORD_THREADS];
   const int t = threadIdx.x;
@@ -1312,8 +1330,9 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
   const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
   double acc = 0.0;
   for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
-    atomicAdd(&h[ff_ord_row(cost[j0 + k])], 1u);
-    if (hval) acc += hval[j0 + k];
+    const double hv = hval ? hval[j0 + k] : 0.0;
+    atomicAdd(&h[ff_ord_row(ff_sched_key(cost[j0 + k], hv, tab_in, interval))], 1u);
+    acc += hv;
   }
   if (pstat) {
     for (int k = t; k < FF_ORD_SEG && j0 + k < Bprev; k += FF_ORD_THREADS) {
@@ -1389,7 +1408,8 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   }
   for (int k = 0; k < FF_ORD_BINS; k++) cnt[k][t] = 0;
   const int64_t j0 = (int64_t)seg * FF_ORD_SEG;
-  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) cnt[ff_ord_row(cost[j0 + k])][t]++;
+  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS)
+    cnt[ff_ord_row(ff_sched_key(cost[j0 + k], hs_out ? hval[j0 + k] : 0.0, hs_out ? tab_in : nullptr, interval))][t]++;
   __syncthreads();
   if (t == 0) {
     unsigned run = 0;
@@ -1416,7 +1436,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   __syncthreads();
   for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
     const int row = ff_ord_row(cost[j0 + k]);
-    order[cnt[row][t]++] = (int32_t)(j0 + k);
+    order[cnt[ff_ord_row(ff_sched_key(cost[j0 + k], hs_out ? hval[j0 + k] : 0.0, hs_out ? tab_in : nullptr, interval))][t]++] = (int32_t)(j0 + k);
     if (hs_out) {
       // the largest step this class is trusted with -- and of the steps of that size the interval takes, the EQUAL ones: two steps of
       // 0.5 are accepted where 0.57 + 0.43 risks a rejection for the same number of evaluations
@@ -1617,7 +1637,7 @@ int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* or
   unsigned* pstat = prev_cost ? (unsigned*)(hsum + nseg) : nullptr;
   // (the previous pass is this rank's shard of the same batch: the statistics cover min(B, B_prev) = B walkers of it)
   FF_LAUNCH(ff_order_count_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (unsigned*)workspace, hval, hsum, B, prev_cost, prev_hs,
-            prev_he, pstat);
+            prev_he, pstat, scale_in ? scale_in : (const double*)nullptr, scale_in ? interval : 0.0);
   FF_LAUNCH_CHECK();
   FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order,
             (const double*)hsum, hmean, (const unsigned*)pstat, nseg, scale_in, scale_out, hval, scale_in ? hs_out : (double*)nullptr,

@@ -778,8 +778,12 @@ def test_one_launch_estimator_and_schedule_with_mean():
         _, _, hs2c, tab2c = S.walker_schedule(cost, h, tab1, counts=cnts)
         assert (tab2c == tab2).all() and (hs2c == hs2).all()
         # interval > 0: steps rounded down to interval / k
-        _, _, hs3, _ = S.walker_schedule(cost, h, tab, interval=1.0)
+        o3, _, hs3, _ = S.walker_schedule(cost, h, tab, interval=1.0)
         hq = h * tab[cls]
+        # ... and the work is ordered by class + 4 x (planned equal steps beyond two): walkers that will take a third step sit together
+        kk = np.where(hq >= 1.0, 1, np.ceil(1.0 / hq - 1e-9)).astype(int)
+        key = np.minimum(31, cls + 4 * np.maximum(0, np.minimum(kk, 8) - 2))
+        assert sorted(o3.tolist()) == list(range(B)) and (np.diff(key[o3]) <= 0).all()
         np.testing.assert_allclose(hs3, np.where(hq < 1.0, 1.0 / np.ceil(1.0 / hq - 1e-9), hq), rtol=1e-15)
         assert (hs3 <= hq * (1 + 1e-12)).all()
         if B >= 4100:      # (~100 walkers per class)
