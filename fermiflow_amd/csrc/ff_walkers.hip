@@ -1271,7 +1271,7 @@ static int mcmc_dispatch(bool noise, void* stream, int64_t B, int nup, int ndn, 
 // keep a fixed order (segment, thread, index).  Workspace: FF_ORD_BINS counters per FF_ORD_SEG walkers.
 #define FF_ORD_BINS 32
 #define FF_ORD_THREADS 256
-#define FF_ORD_SEG 512      // (2048 until round 5: 32 workgroups for 65 536 walkers left seven eighths of the GPU idle for two launches)
+#define FF_ORD_SEG 512       // (2048 until round 5: 32 workgroups for 65 536 walkers left seven eighths of the GPU idle for two launches)
 FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_BINS - 1 ? FF_ORD_BINS - 1 : c)); }   // row 0 = most expensive
 
 // First-step scale of a cost class (ff_walker_schedule).  The local-energy pass opens every walker with scale x (the largest step the
@@ -1371,45 +1371,69 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
                                                                         double* __restrict__ hs_out, double interval,
                                                                         const double* __restrict__ counts) {
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
-  // ff_walker_schedule: the first-step scale of every cost class, learned from the previous pass (ff_scale_update) -- every workgroup
-  // forms the same table from the same integer counts; workgroup 0 stores it for the next call
-  __shared__ double s_tab[FF_ORD_BINS];
-  if (tab_in && threadIdx.x < FF_ORD_BINS) {
-    const int row = threadIdx.x;                 // row 0 = class 31
-    unsigned n = 0, nr = 0;
-    if (counts) {      // the previous pass' statistics summed over every rank's shard (ff_scale_counts + the caller's all-reduce)
-      n = (unsigned)counts[FF_ORD_BINS - 1 - row]; nr = (unsigned)counts[2 * FF_ORD_BINS - 1 - row];
-    } else if (pstat)
-      for (int k = 0; k < nseg_prev; k++) { n += pstat[((int64_t)k * FF_ORD_BINS + row) * 2]; nr += pstat[((int64_t)k * FF_ORD_BINS + row) * 2 + 1]; }
-    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr);
-    s_tab[row] = v;
-    if (blockIdx.x == 0 && tab_out) tab_out[FF_ORD_BINS - 1 - row] = v;
-  }
-  if (hmean && blockIdx.x == 0 && threadIdx.x == 0) {      // the segments' sums in segment order: one fixed summation order
-    double a = 0.0;
-    for (int k = 0; k < nseg; k++) a += hsum[k];
-    hmean[0] = a / (double)B;
-  }
   __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
+  __shared__ unsigned pn[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], pr[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
   __shared__ unsigned base[FF_ORD_BINS];
+  __shared__ double s_tab[FF_ORD_BINS], s_hs[FF_ORD_THREADS];
   const int t = threadIdx.x, seg = blockIdx.x;
-  // row totals over all segments and over the earlier segments (thread t: row t % BINS, every (THREADS/BINS)-th segment)
+  // row totals over all segments and over the earlier segments (thread t: row t % BINS, every (THREADS/BINS)-th segment) -- and, the same
+  // way, the previous pass' first-step statistics by class (ff_walker_schedule)
   {
     constexpr int SL = FF_ORD_THREADS / FF_ORD_BINS;
     const int row = t % FF_ORD_BINS, sl = t / FF_ORD_BINS;
-    unsigned a = 0, b = 0;
+    unsigned a = 0, b = 0, n = 0, nr = 0;
     for (int k = sl; k < nseg; k += SL) {
       const unsigned v = hist[(int64_t)k * FF_ORD_BINS + row];
       a += v;
       b += k < seg ? v : 0u;
     }
+    if (pstat && !counts)
+      for (int k = sl; k < nseg_prev; k += SL) { n += pstat[((int64_t)k * FF_ORD_BINS + row) * 2]; nr += pstat[((int64_t)k * FF_ORD_BINS + row) * 2 + 1]; }
     tot[sl][row] = a;
     before[sl][row] = b;
+    pn[sl][row] = n;
+    pr[sl][row] = nr;
+  }
+  if (hmean && blockIdx.x == 0) {      // the segments' sums: strided partial sums, then a fixed tree -- one summation order whatever the timing
+    double a = 0.0;
+    for (int k = t; k < nseg; k += FF_ORD_THREADS) a += hsum[k];
+    s_hs[t] = a;
+  }
+  __syncthreads();
+  // ff_walker_schedule: the first-step scale of every cost class, learned from the previous pass (ff_scale_update) -- every workgroup
+  // forms the same table from the same integer counts; workgroup 0 stores it for the next call
+  if (tab_in && t < FF_ORD_BINS) {
+    const int row = t;                 // row 0 = class 31
+    unsigned n = 0, nr = 0;
+    if (counts) {      // the previous pass' statistics summed over every rank's shard (ff_scale_counts + the caller's all-reduce)
+      n = (unsigned)counts[FF_ORD_BINS - 1 - row]; nr = (unsigned)counts[2 * FF_ORD_BINS - 1 - row];
+    } else {
+      for (int sl = 0; sl < FF_ORD_THREADS / FF_ORD_BINS; sl++) { n += pn[sl][row]; nr += pr[sl][row]; }
+    }
+    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr);
+    s_tab[row] = v;
+    if (blockIdx.x == 0 && tab_out) tab_out[FF_ORD_BINS - 1 - row] = v;
+  }
+  if (hmean && blockIdx.x == 0) {
+    for (int q = FF_ORD_THREADS / 2; q > 0; q >>= 1) {
+      if (t < q) s_hs[t] += s_hs[t + q];
+      __syncthreads();
+    }
+    if (t == 0) hmean[0] = s_hs[0] / (double)B;
   }
   for (int k = 0; k < FF_ORD_BINS; k++) cnt[k][t] = 0;
   const int64_t j0 = (int64_t)seg * FF_ORD_SEG;
-  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS)
-    cnt[ff_ord_row(ff_sched_key(cost[j0 + k], hs_out ? hval[j0 + k] : 0.0, hs_out ? tab_in : nullptr, interval))][t]++;
+  constexpr int PERT = FF_ORD_SEG / FF_ORD_THREADS;
+  int krow[PERT];      // row of the sort key of this thread's walkers (ff_sched_key: a division and a ceil -- once)
+#pragma unroll
+  for (int q = 0; q < PERT; q++) {
+    const int k = t + q * FF_ORD_THREADS;
+    krow[q] = -1;
+    if (j0 + k < B) {
+      krow[q] = ff_ord_row(ff_sched_key(cost[j0 + k], hs_out ? hval[j0 + k] : 0.0, hs_out ? tab_in : nullptr, interval));
+      cnt[krow[q]][t]++;
+    }
+  }
   __syncthreads();
   if (t == 0) {
     unsigned run = 0;
@@ -1434,9 +1458,12 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
     for (int k = 0; k < PER; k++) { const unsigned c = cnt[row][part * PER + k]; cnt[row][part * PER + k] = off; off += c; }
   }
   __syncthreads();
-  for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
+#pragma unroll
+  for (int q = 0; q < PERT; q++) {
+    const int k = t + q * FF_ORD_THREADS;
+    if (krow[q] < 0) continue;
     const int row = ff_ord_row(cost[j0 + k]);
-    order[cnt[ff_ord_row(ff_sched_key(cost[j0 + k], hs_out ? hval[j0 + k] : 0.0, hs_out ? tab_in : nullptr, interval))][t]++] = (int32_t)(j0 + k);
+    order[cnt[krow[q]][t]++] = (int32_t)(j0 + k);
     if (hs_out) {
       // the largest step this class is trusted with -- and of the steps of that size the interval takes, the EQUAL ones: two steps of
       // 0.5 are accepted where 0.57 + 0.43 risks a rejection for the same number of evaluations
