@@ -122,11 +122,10 @@ def _add_generic_potentials(r, x, extra):
     return r
 
 
-# Where the sampler's side stream is released (FERMIFLOW_PREFETCH_GO): "est" -- in front of the estimator kernel, "adj" -- in front of
-# the adjoint call.  The sampler must reach the workgroup dispatcher while the adjoint's workgroups are still being placed, not
-# behind them: the adjoint launches twice as many workgroups as fit, and a kernel that arrives a microsecond after it waits for that
-# backlog -- 376 us in the trace that showed it.
-_PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "adj")
+# Where the sampler's side stream is released (FERMIFLOW_PREFETCH_GO): "kernel" (default since round 5) -- behind the adjoint's main kernel
+# (ff_ode.after_main_event), so that it runs under the small reduction kernels with the SIMDs to itself; "adj" -- in front of the adjoint
+# call (rounds 2-4: beside the adjoint kernel, while the two still fitted one SIMD together); "est" -- in front of the estimator kernel.
+_PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "kernel")
 
 
 class _Sweep:
@@ -303,23 +302,22 @@ class _Sweep:
                 st["h_counts"] = self._h_counts.clone()
         if getattr(self, "_z_prev", None) is not None:
             st["z_prev"] = self._z_prev
-        if getattr(self, "_z_next", None) is not None:      # prefetched walkers of the next iteration (GSVMC)
-            zn, done = self._z_next[0], self._z_next[1]
-            if done is not None:
-                done.synchronize()
+        q = getattr(self, "_z_queue", None)
+        if q:      # prefetched walkers of the next iterations (GSVMC), oldest first
+            for ent in q:
+                if ent[1] is not None:
+                    ent[1].synchronize()
             # they are THIS rank's shard: stamped with (rank, world, walker offset) so that no other rank mistakes them for its own
             rank, ws = D.world()
-            st["z_next"] = zn
+            st["z_queue"] = [{"z": ent[0], "seed": (int(ent[4]) if ent[4] is not None else None)} for ent in q]      # the Philox keys they were drawn with
             st["z_next_shard"] = (int(rank), int(ws), int(getattr(self.basedist, "walker_offset", 0)))
-            if len(self._z_next) > 4 and self._z_next[4] is not None:
-                st["z_next_seed"] = int(self._z_next[4])      # the Philox key they were drawn with
-            if self._z_next[3] is not None:
-                st["z_next_rng"] = self._z_next[3]            # torch's CPU generator right after that key was drawn (_prefetched_ok)
+            if q[-1][3] is not None:
+                st["z_next_rng"] = q[-1][3]            # torch's CPU generator right after the LAST key was drawn (_prefetched_ok)
         return st
 
     def set_extra_state(self, st):
         st = st or {}      # (an absent _extra_state -- a plain parameter state_dict -- is a cold sweep state)
-        self._resume_seed = None          # (a later load without prefetched walkers must not inherit an earlier load's key)
+        self._resume_seeds = []           # (a later load without prefetched walkers must not inherit an earlier load's keys)
         self._resume_rng = None
         self._h_flow = st.get("h_flow")
         self._h_tab, self._h_tab_cur, self._h_prev, self._h_counts = None, 0, None, None
@@ -331,23 +329,28 @@ class _Sweep:
         self._n_global = st.get("n_global", 0)
         if "z_prev" in st:
             self._z_prev = st["z_prev"]
-        if hasattr(self, "_z_next"):
-            self._z_next = None
-            if "z_next" in st:
+        if hasattr(self, "_z_queue"):
+            self._z_queue = []
+            ents = st.get("z_queue")
+            if ents is None and "z_next" in st:      # (checkpoints of rounds 2-4: one prefetched batch)
+                ents = [{"z": st["z_next"], "seed": st.get("z_next_seed")}]
+            if ents:
                 # The drivers write ONE checkpoint (rank 0's) and every rank loads it: only the rank the prefetched walkers belong
-                # to takes them; the others sample afresh from the restored seed -- which is what they would have drawn anyway
-                # (the Philox key comes from the restored CPU generator, the counters from the global walker index).
+                # to takes them; the others sample afresh from the restored seeds -- which is what they would have drawn anyway
+                # (the Philox keys come from the restored CPU generator, the counters from the global walker index).
                 rank, ws = D.world()
                 shard = tuple(st.get("z_next_shard", (0, 1, 0)))
                 snap = st.get("z_next_rng")
                 snap = snap.cpu() if snap is not None else None
                 if shard[0] == rank and shard[1] == ws:
-                    self._z_next = (st["z_next"], None, int(st["z_next"].shape[0]), snap, st.get("z_next_seed"))
+                    self._z_queue = [(e["z"], None, int(e["z"].shape[0]), snap, e.get("seed")) for e in ents]
                 else:
-                    # this rank re-draws ITS shard with the same key (forward()), under the owner's guard (_prefetched_ok): only if
-                    # torch's CPU generator is where it was when the key was drawn -- checkpoint.load puts it there; a
+                    # this rank re-draws ITS shard with the same keys (forward()), under the owner's guard (_prefetched_ok): only if
+                    # torch's CPU generator is where it was when the last key was drawn -- checkpoint.load puts it there; a
                     # torch.manual_seed() between the load and the sweep means fresh walkers on EVERY rank
-                    self._resume_seed, self._resume_rng = st.get("z_next_seed"), snap
+                    seeds = [e.get("seed") for e in ents]
+                    if all(sd is not None for sd in seeds):
+                        self._resume_seeds, self._resume_rng = seeds, snap
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # a state_dict without "_extra_state" (weights trained with the reference, an earlier checkpoint, another model's
@@ -386,7 +389,14 @@ class GSVMC(_Sweep, torch.nn.Module):
         # and the sampler fit one SIMD together) and costs at 12 and beyond (6.65 against 6.45 ms at 12 particles, 145 against 139 ms
         # at configs[4]: both kernels fill the SIMDs on their own and only slow each other down) -- default on up to 8 particles.
         self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1" if nup + ndown <= 8 else "0") != "0"
-        self._z_next = None          # (walkers, event on the side stream, nloc, CPU generator state after their seed was drawn)
+        # Round 5: TWO iterations ahead, released behind the adjoint kernel (ff_ode.after_main_event).  The two-wave adjoint fills the
+        # register files, so a sampler released beside it ran in its tail anyway -- 0.05 ms of interference at its start and 0.05 ms of
+        # the next iteration waiting for the walkers.  Released when the adjoint kernel ends, the sampler runs under the small
+        # latency-bound kernels behind it (table reduction, contraction, Adam, next radial table: ~150 us of mostly idle SIMDs), and
+        # with a batch in hand nobody ever waits for it.  FERMIFLOW_PREFETCH_DEPTH=1 keeps one batch ahead.
+        self.prefetch_depth = max(1, int(os.environ.get("FERMIFLOW_PREFETCH_DEPTH", "2")))
+        self._z_queue = []           # entries (walkers, event on the side stream, nloc, CPU generator state after their seed was drawn, seed)
+        self._resume_seeds, self._resume_rng = [], None
         self._side = None
 
     # energy estimate of the last forward() (python floats as in the reference, src/VMC.py:57; read lazily from the device)
@@ -438,19 +448,24 @@ class GSVMC(_Sweep, torch.nn.Module):
                 # opt-in: continue the previous sweep's chains for a few steps instead of 100 steps from N(0,1)
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,),
                                          equilibrim_steps=self.persistent_steps, x_init=self._z_prev)
-            elif self._z_next is None and self._resume_ok():
-                # resumed on a rank other than the one whose prefetched walkers the checkpoint holds: the same Philox key and this
-                # rank's walker offset give exactly the walkers the uninterrupted run prefetched here (the CPU generator is not touched)
-                z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=self._resume_seed)
+            elif not self._z_queue and self._resume_ok():
+                # resumed on a rank other than the one whose prefetched walkers the checkpoint holds: the same Philox keys and this
+                # rank's walker offset give exactly the walkers the uninterrupted run prefetched here (the CPU generator is not
+                # touched) -- all of them now, so that from here on this rank is where the owner is
+                snap = self._resume_rng
+                self._z_queue = [(self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=sd), None, nloc, snap, sd)
+                                 for sd in self._resume_seeds]
+                z = self._z_queue.pop(0)[0]
             elif self._prefetched_ok(nloc):
-                z, done = self._z_next[0], self._z_next[1]          # sampled beside the previous iteration's adjoint
+                z, done = self._z_queue[0][0], self._z_queue[0][1]          # sampled behind an earlier iteration's adjoint
+                self._z_queue.pop(0)
                 if done is not None:
                     torch.cuda.current_stream().wait_event(done)
                     z.record_stream(torch.cuda.current_stream())
             else:
+                self._z_queue = []
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,))
-            self._z_next = None
-            self._resume_seed = self._resume_rng = None
+            self._resume_seeds, self._resume_rng = [], None
             self._z_prev = z if self.persistent_walkers else None
         self._mark(ev, "mcmc")
         return self._sweep(z, batch, ev, prefetch=nloc if (self.prefetch_walkers and not self.persistent_walkers and z.is_cuda) else 0)
@@ -459,41 +474,49 @@ class GSVMC(_Sweep, torch.nn.Module):
         """The prefetched walkers stand for "sample now" only if nothing touched torch's CPU generator since their seed was drawn
         from it: after a torch.manual_seed() (or any draw) in between they are dropped and fresh ones are sampled, so re-seeding
         between iterations means what it means without the prefetch."""
-        if self._z_next is None or self.persistent_walkers or self._z_next[2] != nloc:
+        q = self._z_queue
+        if not q or self.persistent_walkers or any(ent[2] != nloc for ent in q):
             return False
-        snap = self._z_next[3]
+        snap = q[-1][3]      # (the generator right after the LAST key was drawn: the earlier entries' draws are its own history)
         return snap is None or torch.equal(snap, torch.get_rng_state())
 
+    # (rounds 2-4 kept ONE prefetched batch under these names; tests and diagnostics still read them)
+    @property
+    def _z_next(self):
+        return self._z_queue[0] if self._z_queue else None
+
+    @property
+    def _resume_seed(self):
+        return self._resume_seeds[0] if self._resume_seeds else None
+
     def _resume_ok(self):
-        """A rank that resumes from another rank's checkpoint re-draws its shard with the checkpointed Philox key -- under the same
-        condition as _prefetched_ok: nobody touched torch's CPU generator since the key was drawn."""
-        if getattr(self, "_resume_seed", None) is None or self.persistent_walkers:
+        """A rank that resumes from another rank's checkpoint re-draws its shard with the checkpointed Philox keys -- under the same
+        condition as _prefetched_ok: nobody touched torch's CPU generator since the last key was drawn."""
+        if not self._resume_seeds or self.persistent_walkers:
             return False
-        snap = getattr(self, "_resume_rng", None)
+        snap = self._resume_rng
         return snap is None or torch.equal(snap, torch.get_rng_state())
 
     def _prefetch(self, nloc, go):
-        """Next iteration's walkers on the side stream: starts when `go` (recorded on the main stream in front of the adjoint)
-        has fired plus a short delay, so that the adjoint's waves are placed first (tools/probes/overlap.py: the other order
-        serialises the two kernels)."""
+        """Walkers of the iterations ahead on the side stream, until prefetch_depth batches are in hand: released when `go` fires -- the
+        event the adjoint call records behind its main kernel (ff_ode.after_main_event)."""
         if self._side is None:
             # (FERMIFLOW_PREFETCH_PRIORITY: stream priority of the sampler's stream, lower number = served first; default 0)
             self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
+        from .base_dist import _draw_seed
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
-            # One short kernel in front of the sampler lets the adjoint's waves be placed first -- with nothing here the Metropolis
-            # waves fill every SIMD first and the two kernels run one after the other (2.34 ms per iteration at config 2).  How long
-            # it spins is measured, not derived: with the column kernel of round 2 an empty launch was best (2.04-2.05 ms, 40 us:
-            # 2.07-2.10); since the local-energy pass ends on a stream join (DESIGN.md 3g) the empty launch leaves the pair's overlap
-            # to chance (1.82-1.89 ms, adjoint stage 0.64-0.72) and 10 us makes it stick (1.807-1.814, 0.625; 20 us: 1.817, 40 us: 1.825;
-            # tools/probes/bench_spread.sh).  FERMIFLOW_PREFETCH_DELAY_US overrides.
-            native.stream_delay(float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "10")))
-            from .base_dist import _draw_seed
-            seed = _draw_seed()
-            z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
-            done = torch.cuda.Event()
-            done.record()
-        self._z_next = (z, done, nloc, torch.get_rng_state(), seed)
+            delay = float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "0"))
+            if delay > 0:
+                native.stream_delay(delay)
+            while len(self._z_queue) < self.prefetch_depth:
+                seed = _draw_seed()
+                z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
+                done = torch.cuda.Event()
+                done.record()
+                self._z_queue.append((z, done, nloc, None, seed))
+        snap = torch.get_rng_state()
+        self._z_queue = [(e[0], e[1], e[2], snap, e[4]) for e in self._z_queue]
 
     def forward_from(self, z, batch=None):
         """forward() on GIVEN base walkers z (nloc, n, 2) -- this rank's shard of a global batch of `batch` walkers
@@ -532,12 +555,19 @@ class GSVMC(_Sweep, torch.nn.Module):
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
             go = go_early
+            after = None
             if prefetch and go is None:
                 go = torch.cuda.Event()
-                go.record()
+                if _PREFETCH_GO == "adj":
+                    go.record()
+                else:      # default: recorded by the library right behind the adjoint's main kernel
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
+                    go.record(self._side)      # (creates the handle; the library re-records it on the main stream)
+                    after = go
             _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
                                        need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
-                                       walker_h_init=he, walker_h_scale=1.25)
+                                       walker_h_init=he, walker_h_scale=1.25, after_main_event=after)
             if prefetch:
                 self._prefetch(prefetch, go)
             D.all_reduce_sum_(gp)

@@ -708,6 +708,12 @@ ff_dep_contract_kernel(ff_net net, const double* __restrict__ off_table, const d
     const double rj = (double)j * (1.0 / FF_DEP_INVH);
     const double sg = ff_sigmoid(fma(w1, rj, b1));
     const double* W = &s_W[j * FF_DEP_ROW];
+    {      // a node nothing was deposited on (every node beyond the largest radius of the batch: three quarters of the table) contributes nothing
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < FF_DEP_ROW; k++) any = any || (W[k] != 0.0);
+      if (!any) continue;
+    }
     double wk = 1.0, wkm = 0.0, prev = 0.0;   // w1^k, k w1^(k-1), sigma^(k)
 #pragma unroll 1
     for (int n = 0; n <= FF_DEP_ROW; n++) {
@@ -904,6 +910,11 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     return FF_EUNSUPPORTED;
   }
   FF_LAUNCH_CHECK();
+  // ff_ode.after_main_event: whoever waits for it runs under the small kernels below, not beside the one above
+  if (ode->after_main_event && hipEventRecord((hipEvent_t)ode->after_main_event, (hipStream_t)stream) != hipSuccess) {
+    ff_set_error("ff_cnf_adjoint: hipEventRecord(after_main_event) failed");
+    return FF_ELAUNCH;
+  }
   const int nblk = (int)adj_grid(B, G);
   {
     const int ntab = (int)adj_grid(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);     // workgroups (= private tables) of the tabulated kernel

@@ -94,9 +94,13 @@ typedef struct ff_ode {
    * default): those kernels leave the sensitivities in the workspace and the finish kernels run.  The same value must be given
    * to ff_eloc_nd_workspace_bytes. */
   int32_t compact_finish;
+  /* ff_cnf_adjoint* only, optional (NULL).  A hipEvent_t the call records on `stream` right behind its dominant kernel -- in front of the
+   * small kernels that reduce and contract the parameter gradient.  What waits on it (the sampler of a later iteration, in the
+   * package) then runs under those latency-bound kernels instead of beside the adjoint kernel (ABI 106). */
+  void* after_main_event;
 } ff_ode;
 
-int ff_version(void);   /* 105; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 106; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */

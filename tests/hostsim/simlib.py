@@ -23,7 +23,7 @@ class FFOde(C.Structure):
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
                 ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double),
-                ("compact_finish", C.c_int32)]
+                ("compact_finish", C.c_int32), ("after_main_event", C.c_void_p)]
 
 
 def build():
@@ -181,7 +181,7 @@ def _ode(t0, t1, rtol, atol, steps=None, order=None, compact=False):
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
                  q(_WARM.get("h_out")), qi(_WARM.get("wclass")), float(_WARM.get("sens_tol", 1.0)), float(_WARM.get("h_scale_loose", 0.0)),
                  int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))), int(_WARM.get("heavy_class", 0)),
-                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)), int(bool(compact)))
+                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)), int(bool(compact)), None)
 
 
 def walker_order(cost, hval=None):

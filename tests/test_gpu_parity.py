@@ -919,9 +919,10 @@ def test_backward_short_cut_respects_parameter_hooks(dev):
 
 
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
-    """GSVMC.prefetch_walkers (default on): the next iteration's Metropolis kernel is started on a side stream beside this
-    iteration's adjoint.  Same seeds in the same order -> the same walkers: three training iterations with and without it
-    end in bit-identical energies and parameters; the prefetched walkers are part of the checkpoint state."""
+    """GSVMC.prefetch_walkers (default on): the Metropolis kernels of the next two iterations run on a side stream, released behind
+    this iteration's adjoint kernel (ff_ode.after_main_event).  Same seeds in the same order -> the same walkers: three training
+    iterations with and without it end in bit-identical energies and parameters; the prefetched walkers are part of the checkpoint
+    state."""
     import __graft_entry__ as Gm
     from fermiflow_amd.utils import make_adam
     out = []
@@ -942,7 +943,7 @@ def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
     for a, b in zip(out[0][1], out[1][1]):
         assert torch.equal(a, b)
     st_on, st_off = out[0][2].get_extra_state(), out[1][2].get_extra_state()
-    assert "z_next" in st_on and st_on["z_next"].shape == (4096, 6, 2) and "z_next" not in st_off
+    assert len(st_on["z_queue"]) == 2 and all(e["z"].shape == (4096, 6, 2) for e in st_on["z_queue"]) and "z_queue" not in st_off      # two batches ahead
     # re-seeding between iterations is honoured: the prefetched walkers are dropped when torch's generator was touched
     m = out[0][2]
     torch.manual_seed(77); m(4096); e1 = m.E
