@@ -59,6 +59,7 @@
 template <int N, int D, int MODE, bool TAB>
 __global__ void __launch_bounds__(FF_WAVE, (MODE == 0 && TAB && N * D <= 12) ? 3 : FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
+  if constexpr (MODE == 0) FF_SETPRIO();      // the flow pass runs beside the tail of the prefetched sampler (ff_common.h)
   using Gm = ff_geom<N, D>;
   constexpr int M = Gm::M, G = Gm::G, P = Gm::P, R = Gm::RA;
   constexpr int NH = MODE == 0 ? 1 : (MODE == 1 ? 2 : 4);

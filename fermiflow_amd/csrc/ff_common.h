@@ -189,10 +189,13 @@ FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
 //     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
 //     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
 #define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// wave priority for the instruction arbiter (0..3): the kernels of the critical path raise theirs where they run beside the prefetched
-// Metropolis kernel.  Measured (tools/probes/r04_ab2.sh, config 2): with priority 3 in the two reduction kernels behind the adjoint the adjoint stage goes 0.576 -> 0.532 ms and the wait for the prefetched walkers 0.040 -> 0.070: the SIMDs are busy either way, the iteration does not change.  Default 0 (off).
+// wave priority for the instruction arbiter (0..3): the small kernels of the critical path raise theirs, because they run beside the
+// prefetched Metropolis kernel.  Round 4 measured this as zero-sum (the adjoint stage 0.576 -> 0.532 ms, the wait for the walkers 0.040
+// -> 0.070: somebody waited for the sampler either way) and left it off.  Since round 5 the sampler works two iterations ahead and
+// nobody waits for it: what it takes from the kernels beside it is simply lost (ff_dep_contract_kernel: 48 us beside it, 14 alone),
+// so they go first.  Default 3; -DFF_PRIO=0 switches it off.
 #ifndef FF_PRIO
-#define FF_PRIO 0
+#define FF_PRIO 3
 #endif
 #ifdef FF_HOSTSIM
 #define FF_SETPRIO() do {} while (0)

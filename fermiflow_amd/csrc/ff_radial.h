@@ -79,6 +79,7 @@ FF_D void ff_sigma_derivs(double s, double* out) {
 #define FF_TAB_GRID 256                     // one workgroup per CU: 2 x 2049 nodes (h = 1/64) in one round, 2 x 16385 in four
 #endif
 __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __restrict__ tab) {
+  FF_SETPRIO();
   __shared__ double sm[128];
   const int tid = threadIdx.x;
   double w = 0.0;

@@ -1322,6 +1322,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
                                                                         const int32_t* __restrict__ prev_cost, const double* __restrict__ prev_hs,
                                                                         const double* __restrict__ prev_he, unsigned* __restrict__ pstat,
                                                                         const double* __restrict__ tab_in, double interval) {
+  FF_SETPRIO();
   __shared__ unsigned h[FF_ORD_BINS], pn[FF_ORD_BINS], pr[FF_ORD_BINS];
   __shared__ double sh[FF_ORD_THREADS];
   const int t = threadIdx.x;
@@ -1370,6 +1371,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
                                                                         double* __restrict__ tab_out, const double* __restrict__ hval,
                                                                         double* __restrict__ hs_out, double interval,
                                                                         const double* __restrict__ counts) {
+  FF_SETPRIO();
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
   __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
   __shared__ unsigned pn[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], pr[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
