@@ -585,7 +585,8 @@ def main():
                 "bound": "fp64-valu", "achieved": a_adj, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": a_adj / PEAK_FP64_TFLOPS,
                 "avg_launch_ms": ms_adj, "rhs_evals_per_walker": adj_evals / wpg, "flop_per_walker_eval": flop_adj,
                 "note": "LDS-atomic and latency bound: two independent waves per workgroup share the deposit table (ticketed deposits); per "
-                        "accepted step 5 records per radius go into it -- a third of the kernel (0.38 ms without deposits)"}
+                        "accepted step the 5 stage records of a radius are re-expanded about one node and deposited once (12 LDS atomics; rounds 1-4: "
+                        "two rows); stand-alone call with a cold start (17 evaluations) -- inside the iteration the kernel runs 13 evaluations"}
             ratio_kernel = (nup == ndown and 1 <= nup <= 6) or (ndown == 0 and 2 <= nup <= 6)
             # the determinant-ratio kernels (round 4) do less than the reference's step: no exp per particle, no log per determinant
             # -- priced at what they execute: proposal 4 n, r^2 sums 4 n, polynomial rows ~5 n, determinants ~n_s^3,

@@ -3,8 +3,9 @@
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load it; fermiflow_amd/ never does.
  *
- * Parity status: PINNED.  Checked (tests/test_oracle_golden.py) against golden vectors produced by
- * importing the reference itself (tests/golden/make_golden.py, groups g1..g6) and against the
+ * Parity status: PINNED, d = 2 and d = 3.  Checked (tests/test_oracle_golden.py) against golden vectors produced by
+ * importing the reference itself (tests/golden/make_golden.py, groups g1..g6; g7: the reference's dimension-generic
+ * code on (B, n, 3) walkers with 3-D orbitals that are products of its own HO2D closures) and against the
  * reference's own known-answer tests (tests/test_basedist.py:5-129: E_loc == sum of orbital energies).
  *
  * Third-party arithmetic that is not in /root/reference: the ODE solver.  The reference calls
@@ -471,7 +472,8 @@ int ffo_eloc(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, 
              const double* x, double* logp, double* grad, double* lap, double* V, double* eloc) {
   return eloc_any(B, nup, ndn, 2, tab_up, tab_dn, wstate, net, t0, t1, rtol, atol, Zc, use_ho, x, logp, grad, lap, V, eloc);
 }
-/* the same in three dimensions (HO3D orbitals; no upstream code) */
+/* the same in three dimensions (HO3D orbitals: no upstream orbital list; pinned to the reference's dimension-generic code by
+ * tests/golden/g7_3d.npz) */
 int ffo_eloc3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                const ffo_net* net, double t0, double t1, double rtol, double atol, double Zc, int use_ho,
                const double* x, double* logp, double* grad, double* lap, double* V, double* eloc) {

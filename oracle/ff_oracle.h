@@ -19,7 +19,7 @@ int ffo_logprob(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_d
 int ffo_mcmc_noise(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                    int steps, double tau, const double* g0, const double* g, const double* u,
                    double* x_out, double* logp_out, uint8_t* accept_out);
-/* HO3D counterparts (d = 3; no upstream code: SURVEY 8(f).4) */
+/* HO3D counterparts (d = 3; no upstream orbital list: SURVEY 8(f).4 -- pinned by tests/golden/g7_3d.npz) */
 int ffo_orbitals3d(const int* k, int nk, const double* pts, int npts, double* out);
 int ffo_logprob3d(int64_t B, int nup, int ndn, const int* tab_up, const int* tab_dn, const int* wstate,
                   const double* x, double* logp, double* grad, double* lap);
