@@ -307,7 +307,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
   //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
   // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
-  constexpr int RW = 2 * D + 8;
+  constexpr int RW = (2 * D + 8) | 1;     // odd: the row lanes read the same field of many records at a time (an even stride puts them on a few bank groups)
   constexpr int QF0 = D, QF1 = D + 1, QGQ = D + 2, QPW = D + 3, QRI2 = 2 * D + 4, QF2 = 2 * D + 5, QBC = 2 * D + 6;
 
   __shared__ ff_wtab s_w[TAB ? 1 : 2][TAB ? 1 : FF_HPAD];
