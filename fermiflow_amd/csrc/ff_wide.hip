@@ -681,6 +681,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       }      // rep
 #endif
       s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
+      FF_STAMP(8);
       if (s == 99) break;
     }
     // -------------------------------------------------------------------- results

@@ -36,6 +36,6 @@ for it in range(iters):
           " ".join(f"{k}={v:.2f}" for k, v in st.items()) + f"  sens-kernel={p1[0].elapsed_time(p1[1]):.2f} ms  evals/walker={stats[0] / B:.2f} "
           f"max steps={stats[1]} rejected={stats[2]} fail={stats[3]}", flush=True)
     if os.environ.get("FERMIFLOW_LIB", "").endswith("stamps.so"):
-        st8 = model.profile["eloc_stats"][0][8:26].view(torch.int64)[:9].double()
-        names8 = ["publish", "radii + S product", "heads + records", "S to LDS + row lanes", "J product", "R2", "2nd-order sums", "consume"]
+        st8 = model.profile["eloc_stats"][0][8:26].view(torch.int64)[:9].double()      # (stamp 8: behind ff_dp5_consume2)
+        names8 = ["publish", "radii + S product", "heads + records", "S to LDS + row lanes", "J product", "R2", "2nd-order sums", "stage coefficients (+ walker prologue)", "consume"]
         print("   ticks per evaluation: " + "  ".join(f"{nm} {v / stats[0]:.0f}" for nm, v in zip(names8, st8.tolist())) + f"   total {st8.sum().item() / stats[0]:.0f}")
