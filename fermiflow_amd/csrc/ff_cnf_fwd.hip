@@ -56,8 +56,11 @@
 // is compiled for three waves per SIMD (<= 168 registers, no scratch; left alone hipcc drifted from 159 to 169 registers
 // with an unrelated change and the flow pass went from 112 to 143 us).  Larger walkers and delta_logp (MODE 1) would spill
 // under that bound; the local-energy kernel (MODE 2) needs the whole register file.
+#ifndef FF_FLOW_WAVES
+#define FF_FLOW_WAVES 3      // waves per SIMD the tabulated flow kernel is compiled for (165 registers; 4: 128 + 140 B of scratch, 5: 95 + 280 B)
+#endif
 template <int N, int D, int MODE, bool TAB>
-__global__ void __launch_bounds__(FF_WAVE, (MODE == 0 && TAB && N * D <= 12) ? 3 : FF_FWD_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(FF_WAVE, (MODE == 0 && TAB && N * D <= 12) ? FF_FLOW_WAVES : FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
   if constexpr (MODE == 0) FF_SETPRIO();      // the flow pass runs beside the tail of the prefetched sampler (ff_common.h)
   using Gm = ff_geom<N, D>;
