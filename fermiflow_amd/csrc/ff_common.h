@@ -188,7 +188,11 @@ FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
 // --- NV sigmoids side by side.  Written step by step over the NV lanes-of-work with scheduling fences in between:
 //     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
 //     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
+#ifndef FF_NO_SCHED_FENCE
 #define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FF_SCHED_FENCE() do {} while (0)      // (A/B knob)
+#endif
 // wave priority for the instruction arbiter (0..3): the small kernels of the critical path raise theirs, because they run beside the
 // prefetched Metropolis kernel.  Round 4 measured this as zero-sum (the adjoint stage 0.576 -> 0.532 ms, the wait for the walkers 0.040
 // -> 0.070: somebody waited for the sampler either way) and left it off.  Since round 5 the sampler works two iterations ahead and
