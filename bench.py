@@ -474,7 +474,7 @@ def main():
                          "matrix peak)" if f32_path else "v_mfma_f64_16x16x4") + " (2 x 2 M^3 of the priced flops), the rest fp64 VALU"
                          if kind == "wide" else ("four walkers per wave, two waves per SIMD; J' = A J and S = J J^T on v_mfma_f64_4x4x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU; "
                           "the flops are those of the S = J J^T formulation this kernel runs (the column sweep of rounds 1-2 priced 13575 per evaluation at 6 particles); "
-                          "avg_launch_ms spans the whole pass: the 0.4 % of the walkers of cost class >= 12 run beside it on the one-walker-per-wave kernel "
+                          "avg_launch_ms spans the whole pass: the walkers of the highest cost classes (>= 16 at 12 coordinates: 0.04 %; >= 12 below) run beside it on the one-walker-per-wave kernel "
                           "(ff_wide_eloc_kernel<2, 1, true, double, false>, DESIGN.md 3g), their evaluations are in the count") if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
@@ -503,7 +503,7 @@ def main():
                                   + (f"(sensitivity components of walkers with flow cost class <= {model.sens_tol_class}: x{model.sens_tol:g}; " if model.sens_tol > 1.0
                                      else "(one tolerance for every component; ") +
                                   (f"first step of the local-energy pass by cost class from the learned table; " if getattr(model, "adaptive_h", False) else "")
-                                  + (f"walkers of class >= {model.heavy_class or 12}: x{model.heavy_tol or 0.3:g} on the one-walker-per-wave kernel; "
+                                  + (f"walkers of class >= {model.heavy_class or (16 if n * dim >= 12 else 12)}: x{model.heavy_tol or 0.3:g} on the one-walker-per-wave kernel; "
                                      if (dim == 2 and n <= 6 and model.heavy_class >= 0) else "") +
                                   f"step-size warm start {'on' if model.warm_start else 'off'}; "
                                   f"walker prefetch {'on' if getattr(model, 'prefetch_walkers', False) else 'off'}), "

@@ -166,8 +166,9 @@ class _Sweep:
         self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6" if M <= 12 else "8"))
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
-        # (ff_walker_schedule: more than 20 % of a class rejected their first step -> x 0.93, fewer than 5 % -> x 1.02; the step is
-        # then rounded down to interval / k: equal steps).  A fixed factor is
+        # (ff_walker_schedule: more than 20 % of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
+        # three or more planned steps accepted a step of the plan one shorter -> x 1.02; the step is then rounded down to interval / k:
+        # equal steps).  A fixed factor is
         # right for one set of weights only: 0.9 is accepted by 99 % of the walkers on the synthetic weights and rejected by 80 % after
         # 300 training iterations -- a whole wasted step each (29 evaluations per walker where 23 do).  Device-resident, no host round
         # trip; FERMIFLOW_ADAPTIVE_H=0 keeps the fixed factors (0.9 for class <= 6, _h_scale_eloc beyond).
@@ -177,7 +178,7 @@ class _Sweep:
         self._h_prev = None          # (cost, hs, he) of the previous local-energy pass
         self._h_counts = None        # data-parallel runs: its first-step statistics, summed over the ranks, instead
         self._h_counts_local = None
-        # routing of the local-energy pass (ff_ode.heavy_class / heavy_tol / sum_weight; 0 = the library's defaults 12, 0.3, 4;
+        # routing of the local-energy pass (ff_ode.heavy_class / heavy_tol / sum_weight; 0 = the library's defaults 12 (16 at 12 coordinates), 0.3, 4;
         # heavy_class < 0: no routing).  Reference semantics -- one tolerance, one kernel for every walker -- are
         # sens_tol = 1, heavy_class = -1 (FERMIFLOW_SENS_TOL=1 FERMIFLOW_HEAVY_CLASS=-1).
         self.heavy_class = int(os.environ.get("FERMIFLOW_HEAVY_CLASS", "0"))
@@ -261,7 +262,7 @@ class _Sweep:
         self._h_counts_local = None
         if hs is not None:
             if D._active():
-                self._h_counts_local = native.scale_counts(cost, hs, he)
+                self._h_counts_local = native.scale_counts(cost, hs, he, interval=t1 - t0)
             else:
                 self._h_prev = (cost, hs, he)
         _add_generic_potentials(r, x, extra)
@@ -324,7 +325,8 @@ class _Sweep:
         if st.get("h_tab") is not None:
             self._h_tab = torch.stack([st["h_tab"], st["h_tab"]]).contiguous()
             self._h_prev = tuple(st["h_prev"]) if st.get("h_prev") is not None else None
-            self._h_counts = st.get("h_counts")
+            hc = st.get("h_counts")
+            self._h_counts = hc if (hc is not None and hc.numel() == native.SCALE_COUNTS) else None      # (64 before ABI 107: one update skipped)
         self._dev = dict(st.get("dev", {}))
         self._n_global = st.get("n_global", 0)
         if "z_prev" in st:

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
-ABI_VERSION = 106      # ff_version() of the library this binding was written against (include/fermiflow.h)
+ABI_VERSION = 107      # ff_version() of the library this binding was written against (include/fermiflow.h)
 
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
@@ -140,7 +140,7 @@ def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, wa
     """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
     walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start);
     walker_h_uniform: walker_h_init is a 1-element tensor, the first step of every walker;
-    heavy_class / heavy_tol / sum_weight: routing threshold and tolerances of the local-energy pass (0: library defaults 12, 0.3, 4;
+    heavy_class / heavy_tol / sum_weight: routing threshold and tolerances of the local-energy pass (0: library defaults 12 (16 at 12 coordinates), 0.3, 4;
     heavy_class < 0: no routing); compact_finish: ff_eloc_nd finishes walkers in the one-walker-per-workgroup kernels' epilogue
     (compact workspace beyond 24 coordinates; include/fermiflow.h)."""
     for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),

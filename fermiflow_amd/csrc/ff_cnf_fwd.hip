@@ -1306,15 +1306,21 @@ static int64_t fwd_queue_blocks() {
 }
 
 // Routing of the local-energy pass by cost class.  A launch cannot end before its longest chain of steps has: a walker with a
-// particle passing the origin takes 20-30 steps of 7 dependent evaluations, 3.7-5.5 us each for a lone wave of the several-walkers-
+// particle passing the origin takes 20-30 steps of 7 dependent evaluations, 3.4-5.5 us each for a wave of the several-walkers-
 // per-wave kernels -- as long as the other 99.6 % of the walkers need the whole GPU.  The one-walker-per-wave kernel of ff_wide.hip
 // runs one evaluation in 2.6 us.  With cost classes at hand (ff_ode.walker_class: the sweeps pass the flow pass's) the walkers of
-// class >= ff_ode.heavy_class (default 12: 0.4 % at config 2) therefore go to that kernel, launched first on the caller's stream (one wave per
+// class >= ff_ode.heavy_class therefore go to that kernel, launched first on the caller's stream (one wave per
 // walker; its 292 registers keep the SIMD to itself), and everyone else to the throughput kernel on a side stream, both joined
 // before anything else runs.  Which kernel integrates a walker depends on the walker's own class only, never on the batch it is
-// part of or on the order of work.  The heavy walkers are also the ones whose E_loc error is largest (the embedded error estimate
+// part of or on the order of work.  The heavy walkers are also among the ones whose E_loc error is largest (the embedded error estimate
 // underrates the kink they pass) and their chain has slack now: they are integrated at ff_ode.heavy_tol (default 0.3) x (rtol, atol).
-#define FF_HEAVY_CLASS_DEFAULT 12
+// The default threshold by system size (round 5, bench.py at 20 and at 200 steps, thresholds 12 .. 20 and none): routing pays while
+// the pass is bound by its longest chain and costs once it is bound by the work -- every routed walker holds a SIMD that two waves
+// of the throughput kernel would share (292 + 253 registers do not fit one file), and the fork and the join add 12 us each end.
+// Up to 4 particles (5 in d = 2) the chain rules: class >= 12 (0.4-0.6 % of a batch; 3 particles: pass 0.507 -> 0.463 ms, none:
+// 0.507).  At 12 coordinates the work does -- and more so as the flow trains: class >= 16 (0.04-0.1 %): pass 0.806 -> 0.796 ms on the
+// benchmark's weights (none: 0.833), 1.08 -> 1.02 ms 200 iterations later (none: 1.00), trained flows 1.33 -> 1.25 (none: 1.20).
+#define FF_HEAVY_CLASS_DEFAULT(M_) ((M_) >= 12 ? 16 : 12)
 #define FF_HEAVY_TOL_DEFAULT 0.3
 #define FF_SUM_WEIGHT_DEFAULT 4.0
 // One side stream + two events per DEVICE, created on the first routed call on that device and shared by every host thread:
@@ -1379,7 +1385,9 @@ static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F lau
   if (a.heavy_tol > 0.0) { h.rtol *= a.heavy_tol; h.atol *= a.heavy_tol; }
   l.heavy_mode = 2;
   // placed first: a persistent grid takes every register file it finds
+#ifndef FF_DIAG_NO_HEAVY      // (timing diagnostic: the throughput kernel without its neighbour; the heavy walkers' outputs are then garbage)
   if (ff_wide_eloc_heavy(stream, n, d, h, 1024) != FF_OK) { (void)hipGetLastError(); return FF_ROUTE_NONE; }
+#endif
   launch_table(side->stream, l);
   // With the fused finish the throughput kernel writes its walkers' local energies itself; the heavy route's walkers leave their
   // sensitivities in the workspace and take the two finish kernels, filtered by class -- enqueued HERE, behind the heavy kernel on
@@ -1632,7 +1640,7 @@ static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const 
   a.wclass = ode->walker_class; a.sens_class = ode->sens_tol_class;
   a.sens_w = ode->sens_tol > 1.0 ? 1.0 / ode->sens_tol : 1.0;
   a.h_scale_loose = ode->walker_h_scale_loose > 0.0 ? ode->walker_h_scale_loose : fabs(ode->walker_h_scale);
-  a.heavy_class = ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT : ode->heavy_class;      // (< 0: no routing)
+  a.heavy_class = ode->heavy_class == 0 ? FF_HEAVY_CLASS_DEFAULT(n * d) : ode->heavy_class;      // (< 0: no routing)
   a.heavy_tol = ode->heavy_tol > 0.0 ? ode->heavy_tol : FF_HEAVY_TOL_DEFAULT;
   a.sum_w = ode->sum_weight > 0.0 ? ode->sum_weight : FF_SUM_WEIGHT_DEFAULT;
   if (fin) a.fin = *fin;

@@ -1281,17 +1281,33 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // wait for each other), the extra step 6.  On the benchmark's synthetic weights 0.9 is accepted by 99 % of the walkers; after a few
 // hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations per walker where 23 do).  So the
 // scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than 20 %: scale
-// x 0.93; fewer than 5 %: x 1.02; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (Round 5's first thresholds, 4 % and
+// x 0.93; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (Round 5's first thresholds, 4 % and
 // 1 %, traded 6 evaluations of every walker for 7 of one in twenty: 13.9 -> 19.7 evaluations at 6 + 6 particles.)
+// Growth (x 1.02) needs fewer than 5 % rejections AND evidence that a plan one step shorter would pass: of the n3 walkers that were
+// planned for k >= 3 equal steps, ne accepted -- somewhere along the trajectory, where the step-size control of the solver tried it
+// -- a step as large as the interval / (k - 1) of the shorter plan; growth wants n3 >= 16 and ne >= 0.7 n3.  Without that condition
+// the table probes blindly: 200 iterations into the benchmark's training run every class sat at three steps of 1/3 with no
+// rejections, grew by 1.02 for four iterations until two steps of 1/2 were planned, had 40-70 % of them rejected, shrank, and so
+// on -- one iteration in five at 24 evaluations per walker instead of 21 (tools/probes/h_table_drift.py); with it the same walkers
+// report ne / n3 = 0.00-0.05 at three steps and the table stays.  (Walkers planned for two steps cannot show such a step -- the
+// second one is capped by the rest of the interval -- and have nothing to gain short of a single step; they do not vote.)
 // Error control is untouched: every step passes the same test whatever it opened with.
-FF_D double ff_scale_update(double cur, unsigned n, unsigned nr) {
+FF_D double ff_scale_update(double cur, unsigned n, unsigned nr, unsigned n3, unsigned ne) {
   if (!(cur > 0.0)) cur = 0.6;
   if (n >= 64u) {
     const double f = (double)nr / (double)n;
     if (f > 0.20) cur *= 0.93;
-    else if (f < 0.05) cur *= 1.02;
+    else if (f < 0.05 && n3 >= 16u && (double)ne >= 0.7 * (double)n3) cur *= 1.02;
   }
   return fmin(1.0, fmax(0.25, cur));
+}
+// the two votes of one walker of the previous pass for ff_scale_update: bit 0 -- it was planned for three or more equal steps (without an
+// interval: every walker), bit 1 -- and accepted a step of the plan one shorter (without an interval: 1.25 x the step it opened with)
+FF_D unsigned ff_scale_votes(double hs0, double he0, double interval) {
+  if (!(interval > 0.0)) return 1u | (he0 >= 1.25 * hs0 ? 2u : 0u);
+  const double k = rint(interval / hs0);
+  if (k < 3.0) return 0u;
+  return 1u | (he0 >= 0.999 * interval / (k - 1.0) ? 2u : 0u);
 }
 
 // Sort key of a walker in ff_walker_schedule: its cost class -- raised by four for every equal step beyond two that its local-energy pass
@@ -1323,10 +1339,10 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
                                                                         const double* __restrict__ prev_he, unsigned* __restrict__ pstat,
                                                                         const double* __restrict__ tab_in, double interval) {
   FF_SETPRIO();
-  __shared__ unsigned h[FF_ORD_BINS], pn[FF_ORD_BINS], pr[FF_ORD_BINS];
+  __shared__ unsigned h[FF_ORD_BINS], pn[FF_ORD_BINS], pr[FF_ORD_BINS], p3[FF_ORD_BINS], pe[FF_ORD_BINS];
   __shared__ double sh[FF_ORD_THREADS];
   const int t = threadIdx.x;
-  if (t < FF_ORD_BINS) { h[t] = 0; pn[t] = 0; pr[t] = 0; }
+  if (t < FF_ORD_BINS) { h[t] = 0; pn[t] = 0; pr[t] = 0; p3[t] = 0; pe[t] = 0; }
   __syncthreads();
   const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
   double acc = 0.0;
@@ -1342,6 +1358,9 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
         const int row = ff_ord_row(prev_cost[j0 + k]);
         atomicAdd(&pn[row], 1u);
         if (he0 < 0.999 * hs0) atomicAdd(&pr[row], 1u);
+        const unsigned v = ff_scale_votes(hs0, he0, interval);
+        if (v & 1u) atomicAdd(&p3[row], 1u);
+        if (v & 2u) atomicAdd(&pe[row], 1u);
       }
     }
   }
@@ -1349,8 +1368,8 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
   __syncthreads();
   if (t < FF_ORD_BINS) hist[(int64_t)blockIdx.x * FF_ORD_BINS + t] = h[t];
   if (pstat && t < FF_ORD_BINS) {
-    pstat[((int64_t)blockIdx.x * FF_ORD_BINS + t) * 2] = pn[t];
-    pstat[((int64_t)blockIdx.x * FF_ORD_BINS + t) * 2 + 1] = pr[t];
+    unsigned* ps = pstat + ((int64_t)blockIdx.x * FF_ORD_BINS + t) * 4;
+    ps[0] = pn[t]; ps[1] = pr[t]; ps[2] = p3[t]; ps[3] = pe[t];
   }
   if (hval) {
     for (int q = FF_ORD_THREADS / 2; q > 0; q >>= 1) {
@@ -1375,6 +1394,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
   __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
   __shared__ unsigned pn[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], pr[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
+  __shared__ unsigned p3[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], pe[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
   __shared__ unsigned base[FF_ORD_BINS];
   __shared__ double s_tab[FF_ORD_BINS], s_hs[FF_ORD_THREADS];
   const int t = threadIdx.x, seg = blockIdx.x;
@@ -1383,18 +1403,23 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   {
     constexpr int SL = FF_ORD_THREADS / FF_ORD_BINS;
     const int row = t % FF_ORD_BINS, sl = t / FF_ORD_BINS;
-    unsigned a = 0, b = 0, n = 0, nr = 0;
+    unsigned a = 0, b = 0, n = 0, nr = 0, n3 = 0, ne = 0;
     for (int k = sl; k < nseg; k += SL) {
       const unsigned v = hist[(int64_t)k * FF_ORD_BINS + row];
       a += v;
       b += k < seg ? v : 0u;
     }
     if (pstat && !counts)
-      for (int k = sl; k < nseg_prev; k += SL) { n += pstat[((int64_t)k * FF_ORD_BINS + row) * 2]; nr += pstat[((int64_t)k * FF_ORD_BINS + row) * 2 + 1]; }
+      for (int k = sl; k < nseg_prev; k += SL) {
+        const unsigned* ps = pstat + ((int64_t)k * FF_ORD_BINS + row) * 4;
+        n += ps[0]; nr += ps[1]; n3 += ps[2]; ne += ps[3];
+      }
     tot[sl][row] = a;
     before[sl][row] = b;
     pn[sl][row] = n;
     pr[sl][row] = nr;
+    p3[sl][row] = n3;
+    pe[sl][row] = ne;
   }
   if (hmean && blockIdx.x == 0) {      // the segments' sums: strided partial sums, then a fixed tree -- one summation order whatever the timing
     double a = 0.0;
@@ -1406,13 +1431,14 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
   // forms the same table from the same integer counts; workgroup 0 stores it for the next call
   if (tab_in && t < FF_ORD_BINS) {
     const int row = t;                 // row 0 = class 31
-    unsigned n = 0, nr = 0;
+    unsigned n = 0, nr = 0, n3 = 0, ne = 0;
     if (counts) {      // the previous pass' statistics summed over every rank's shard (ff_scale_counts + the caller's all-reduce)
-      n = (unsigned)counts[FF_ORD_BINS - 1 - row]; nr = (unsigned)counts[2 * FF_ORD_BINS - 1 - row];
+      const int c = FF_ORD_BINS - 1 - row;
+      n = (unsigned)counts[c]; nr = (unsigned)counts[FF_ORD_BINS + c]; n3 = (unsigned)counts[2 * FF_ORD_BINS + c]; ne = (unsigned)counts[3 * FF_ORD_BINS + c];
     } else {
-      for (int sl = 0; sl < FF_ORD_THREADS / FF_ORD_BINS; sl++) { n += pn[sl][row]; nr += pr[sl][row]; }
+      for (int sl = 0; sl < FF_ORD_THREADS / FF_ORD_BINS; sl++) { n += pn[sl][row]; nr += pr[sl][row]; n3 += p3[sl][row]; ne += pe[sl][row]; }
     }
-    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr);
+    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr, n3, ne);
     s_tab[row] = v;
     if (blockIdx.x == 0 && tab_out) tab_out[FF_ORD_BINS - 1 - row] = v;
   }
@@ -1611,42 +1637,43 @@ int ff_potential(void* stream, int64_t B, int n, int d, double Z, int use_ho, co
   return FF_OK;
 }
 
-// counts[c] += walkers of class c of this pass that opened with a step, counts[32 + c] += those of them whose first step was rejected
+// counts[c] += walkers of class c of this pass that opened with a step, counts[32 + c] += those of them whose first step was rejected,
+// counts[64 + c] / counts[96 + c] += the two votes of ff_scale_votes
 // (integers in doubles: exact whatever the order of the atomics, and what an all-reduce over ranks adds up)
 __global__ void __launch_bounds__(FF_ORD_THREADS) ff_scale_counts_kernel(int64_t B, const int32_t* __restrict__ cost, const double* __restrict__ hs,
-                                                                         const double* __restrict__ he, double* __restrict__ counts) {
-  __shared__ unsigned pn[FF_ORD_BINS], pr[FF_ORD_BINS];
+                                                                         const double* __restrict__ he, double interval, double* __restrict__ counts) {
+  __shared__ unsigned pc[4][FF_ORD_BINS];
   const int t = threadIdx.x;
-  if (t < FF_ORD_BINS) { pn[t] = 0; pr[t] = 0; }
+  if (t < 4 * FF_ORD_BINS) pc[t / FF_ORD_BINS][t % FF_ORD_BINS] = 0;
   __syncthreads();
   const int64_t j0 = (int64_t)blockIdx.x * FF_ORD_SEG;
   for (int k = t; k < FF_ORD_SEG && j0 + k < B; k += FF_ORD_THREADS) {
     const double hs0 = hs[j0 + k], he0 = he[j0 + k];
     if (hs0 > 0.0 && he0 > 0.0) {
       const int c = FF_ORD_BINS - 1 - ff_ord_row(cost[j0 + k]);
-      atomicAdd(&pn[c], 1u);
-      if (he0 < 0.999 * hs0) atomicAdd(&pr[c], 1u);
+      atomicAdd(&pc[0][c], 1u);
+      if (he0 < 0.999 * hs0) atomicAdd(&pc[1][c], 1u);
+      const unsigned v = ff_scale_votes(hs0, he0, interval);
+      if (v & 1u) atomicAdd(&pc[2][c], 1u);
+      if (v & 2u) atomicAdd(&pc[3][c], 1u);
     }
   }
   __syncthreads();
-  if (t < FF_ORD_BINS) {
-    if (pn[t]) atomicAdd(&counts[t], (double)pn[t]);
-    if (pr[t]) atomicAdd(&counts[FF_ORD_BINS + t], (double)pr[t]);
-  }
+  if (t < 4 * FF_ORD_BINS && pc[t / FF_ORD_BINS][t % FF_ORD_BINS]) atomicAdd(&counts[t], (double)pc[t / FF_ORD_BINS][t % FF_ORD_BINS]);
 }
 
-int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double* counts64) {
-  FF_CHECK(B >= 0 && counts64 && (B == 0 || (cost && hs && he)), FF_EINVAL, "ff_scale_counts: bad argument");
+int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double interval, double* counts128) {
+  FF_CHECK(B >= 0 && counts128 && (B == 0 || (cost && hs && he)), FF_EINVAL, "ff_scale_counts: bad argument");
   if (B == 0) return FF_OK;
-  FF_LAUNCH(ff_scale_counts_kernel, (unsigned)((B + FF_ORD_SEG - 1) / FF_ORD_SEG), FF_ORD_THREADS, stream, B, cost, hs, he, counts64);
+  FF_LAUNCH(ff_scale_counts_kernel, (unsigned)((B + FF_ORD_SEG - 1) / FF_ORD_SEG), FF_ORD_THREADS, stream, B, cost, hs, he, interval, counts128);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }
 
-// [nseg][BINS] histogram | nseg segment sums of hval | [nseg][BINS][2] statistics of the previous pass (ff_walker_schedule)
+// [nseg][BINS] histogram | nseg segment sums of hval | [nseg][BINS][4] statistics of the previous pass (ff_walker_schedule)
 size_t ff_walker_order_workspace_bytes(int64_t B) {
   const size_t nseg = (size_t)((B + FF_ORD_SEG - 1) / FF_ORD_SEG > 0 ? (B + FF_ORD_SEG - 1) / FF_ORD_SEG : 1);
-  return sizeof(unsigned) * FF_ORD_BINS * nseg + sizeof(double) * nseg + sizeof(unsigned) * 2 * FF_ORD_BINS * nseg;
+  return sizeof(unsigned) * FF_ORD_BINS * nseg + sizeof(double) * nseg + sizeof(unsigned) * 4 * FF_ORD_BINS * nseg;
 }
 
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,

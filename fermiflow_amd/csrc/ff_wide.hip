@@ -285,6 +285,24 @@ FF_D double ff_quad_sum(double v) {
   return v;
 }
 
+// Heavy route (one wave per workgroup, grid-stride over the schedule): the wave looks at this workgroup's next 64 entries AT ONCE and
+// returns the first one at or behind bq whose walker is of class >= heavy_class (or something >= B).  Walking the entries one by
+// one -- two dependent loads each, and 99.6 % of them light -- kept every one of the 1024 workgroups resident for ~100 us with a
+// register file to itself (292 registers: no room beside it for a wave of the throughput kernel, launched right behind): the whole
+// pass started that much later, 1.00 -> 1.10 ms once it is long enough not to hide it behind its longest chain
+// (tools/probes/heavy_neighbour.py, pass_timeline.py).
+FF_D int64_t ff_wide_next_heavy(const ff_fwd_args& A, int64_t bq, int lane) {
+  while (bq < A.B) {
+    const int64_t q = bq + (int64_t)lane * gridDim.x;
+    bool hv = false;
+    if (q < A.B) hv = A.wclass[A.order ? (int64_t)A.order[q] : q] >= A.heavy_class;
+    const unsigned long long m = ff_wave_ballot(hv);
+    if (m) return bq + (int64_t)__builtin_ctzll(m) * gridDim.x;
+    bq += (int64_t)FF_WAVE * gridDim.x;
+  }
+  return bq;
+}
+
 #ifndef FF_WIDE_T1_WAVES
 #define FF_WIDE_T1_WAVES 1
 #endif
@@ -333,6 +351,14 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     if (A.evt && *A.evt != A.evt_id) return;
     if (tid < FF_WAVE) { ff_fill_exp2_table(s_e2, tid); ff_load_weights(s_w, A.net, tid); }
   }
+  // heavy route: a workgroup with no heavy walker among its entries leaves before it has set anything up
+  int64_t bq_first = blockIdx.x;
+  if constexpr (T == 1) {
+    if (A.heavy_mode == 1 && !A.queue) {
+      bq_first = ff_wide_next_heavy(A, bq_first, tid);
+      if (bq_first >= A.B) return;
+    }
+  }
   bool off_table = false;
   if (tid < 4) s_st[tid] = 0;
   for (int e = tid; e < MP * JS; e += NTHR) { s_J[e] = (TJ)0; s_A[e] = (TJ)0; }
@@ -374,12 +400,15 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #endif
 
   bool degrees_known = false;      // (fused finish: the orbitals' Hermite degrees are in LDS)
-  for (int64_t bq = blockIdx.x;; bq += gridDim.x) {
+  for (int64_t bq = bq_first;; bq += gridDim.x) {
     if (A.queue) {   // persistent grid: next walker from the launch's work counter (heavy walkers sit at the front)
       __syncthreads();
       if (tid == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();
       bq = s_next;
+    }
+    if constexpr (T == 1) {
+      if (A.heavy_mode == 1 && !A.queue) bq = ff_wide_next_heavy(A, bq, tid);
     }
     if (bq >= A.B) break;
     const int64_t b = ff_opt_load(A.order, true, bq, A.y_in, (int32_t)bq);

@@ -314,16 +314,23 @@ def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, co
     pc, ph, pe = prev if prev is not None else (None, None, None)
     if prev is not None and not (pc.numel() == ph.numel() == pe.numel() == cost.numel()):
         raise ValueError("walker_schedule: the previous pass must have this call's batch size")
+    if counts is not None and not (counts.numel() == SCALE_COUNTS and counts.dtype == torch.float64 and counts.is_contiguous()):
+        raise ValueError(f"walker_schedule: counts must be the {SCALE_COUNTS} doubles of scale_counts")
     L.check(L.lib().ff_walker_schedule(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean),
                                        L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.ptr(counts), L.f64(abs(float(interval))), L.ptr(hs)),
             "ff_walker_schedule")
     return order, hmean, hs
 
 
-def scale_counts(cost, hs, he):
-    """ff_scale_counts: 64 doubles [walkers by cost class | of them, first step rejected] of a local-energy pass (this rank's shard)"""
-    counts = torch.zeros(64, dtype=torch.float64, device=cost.device)
-    L.check(L.lib().ff_scale_counts(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(hs), L.ptr(he), L.ptr(counts)), "ff_scale_counts")
+SCALE_COUNTS = 128      # doubles of ff_scale_counts / ff_walker_schedule's prev_counts (include/fermiflow.h)
+
+
+def scale_counts(cost, hs, he, interval=0.0):
+    """ff_scale_counts: 128 doubles [walkers by cost class | of them, first step rejected | planned for >= 3 equal steps of `interval` | of
+    those, accepted a step of the plan one shorter] of a local-energy pass (this rank's shard)"""
+    counts = torch.zeros(SCALE_COUNTS, dtype=torch.float64, device=cost.device)
+    L.check(L.lib().ff_scale_counts(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(hs), L.ptr(he), L.f64(abs(float(interval))), L.ptr(counts)),
+            "ff_scale_counts")
     return counts
 
 

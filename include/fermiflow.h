@@ -79,7 +79,8 @@ typedef struct ff_ode {
   /* Local-energy pass with walker_class set, up to 6 particles in d = 2 (0 = the library's default for each).  Walkers of class
    * >= heavy_class (a particle passing the origin: 0.4 % of a batch, 20-30 steps each) are integrated by the one-walker-per-wave
    * kernel, started first, at heavy_tol x (rtol, atol), beside the throughput kernel that takes everyone else -- which kernel
-   * integrates a walker depends on its own class only.  Defaults: heavy_class 12, heavy_tol 0.3; heavy_class < 0: no routing.
+   * integrates a walker depends on its own class only.  Defaults: heavy_class 12 (16 at n d = 12 coordinates, where the pass is bound by
+   * its work, not by its longest chain: csrc/ff_cnf_fwd.hip), heavy_tol 0.3; heavy_class < 0: no routing.
    * sum_weight: weight of the two scalar components Delta and lap_x Delta in the error norm of the matrix-core kernel
    * (4-6 particles), which carries each as ONE number where the column and row kernels carry per-lane partial sums (default 4;
    * 1: the plain RMS norm -- fewer steps near a kink, E_loc error up to 3e-6 there). */
@@ -100,7 +101,7 @@ typedef struct ff_ode {
   void* after_main_event;
 } ff_ode;
 
-int ff_version(void);   /* 106; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 107; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
@@ -129,10 +130,13 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * reference's solvers start cold, src/NeuralODE/nnModule.py:59-67): hs_out[b] = hval[b] * scale_out[cost[b]], scale a table of 32 factors
  * by cost class (scale_in; entries <= 0 read as 0.6) that FOLLOWS the passes: given the previous pass of the same batch size --
  * prev_cost (its classes), prev_hs (the steps it opened with, i.e. the previous call's hs_out), prev_he (its ff_ode.walker_h_out) --
- * a class of which more than 20 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor, fewer than 5 %
- * 1.02 x, within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  The updated table -- the one this call applies -- goes to
+ * a class of which more than 20 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor; one with fewer
+ * than 5 % gets 1.02 x IF its walkers showed that a plan one step shorter would pass (ABI 107): of those planned for k >= 3 equal steps
+ * (at least 16), 70 % accepted a step >= interval / (k - 1) somewhere along the way (prev_he, the largest step the pass accepted;
+ * without an interval: every walker votes, with a step >= 1.25 x the one it opened with); within [0.25, 1]; classes with fewer than 64
+ * walkers keep theirs.  The updated table -- the one this call applies -- goes to
  * scale_out (a second buffer: workgroups read scale_in while it is written); pass it as scale_in of the next call.  prev_* may be NULL
- * (first call: scale_out = scale_in).  prev_counts (64 doubles, instead of prev_cost / prev_hs / prev_he): the same statistics already
+ * (first call: scale_out = scale_in).  prev_counts (128 doubles, instead of prev_cost / prev_hs / prev_he): the same statistics already
  * counted -- ff_scale_counts of the previous pass, summed over the ranks by the caller (fermiflow_amd adds them to the estimator's
  * all-reduce), so that every rank of a data-parallel run holds the same table.  interval > 0 (= |t1 - t0| of the pass): the step is rounded DOWN to interval / k, the equal steps
  * that cover the interval in as many steps as the scaled one would.  Integer counts and a fixed rule: the table is a deterministic function of the passes before it.  Pass hs_out
@@ -140,9 +144,11 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
                        const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
                        const double* prev_counts, double interval, double* hs_out);
-/* counts64[c] += walkers of cost class c that opened a local-energy pass with a step (hs > 0) and finished it (he > 0), counts64[32 + c] +=
- * those whose first step was rejected (he < hs); the caller zeroes counts64.  Integers held in doubles: exact in any order. */
-int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double* counts64);
+/* counts128[c] += walkers of cost class c that opened a local-energy pass with a step (hs > 0) and finished it (he > 0), counts128[32 + c]
+ * += those whose first step was rejected (he < hs), counts128[64 + c] += those planned for three or more equal steps of `interval`,
+ * counts128[96 + c] += those of them that accepted a step of the plan one shorter (ff_walker_schedule's growth condition; interval as
+ * there); the caller zeroes counts128.  Integers held in doubles: exact in any order, and a sum over ranks is the global count. */
+int ff_scale_counts(void* stream, int64_t B, const int32_t* cost, const double* hs, const double* he, double interval, double* counts128);
 const char* ff_last_error(void);
 /* Kernel family of the fused CNF kernels (ff_cnf_generate, ff_cnf_delta_logp, ff_eloc_sensitivities, ff_cnf_adjoint*):
  * 0 (default) = by particle number -- one wave per walker group up to 12 particles in d = 2 / 4 in d = 3, one walker per

@@ -208,9 +208,9 @@ def walker_schedule(cost, hval, scale_in, prev=None, interval=0.0, counts=None):
     return order, hm[0], hs, scale_out
 
 
-def scale_counts(cost, hs, he):
-    cost = _i(cost); counts = np.zeros(64)
-    _ck(lib().ff_scale_counts(None, C.c_int64(len(cost)), _p(cost), _p(_d(hs)), _p(_d(he)), _p(counts)))
+def scale_counts(cost, hs, he, interval=0.0):
+    cost = _i(cost); counts = np.zeros(128)
+    _ck(lib().ff_scale_counts(None, C.c_int64(len(cost)), _p(cost), _p(_d(hs)), _p(_d(he)), C.c_double(interval), _p(counts)))
     return counts
 
 

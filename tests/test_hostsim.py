@@ -417,7 +417,7 @@ def test_matrix_core_kernel_every_block_count(nup, ndn, B):
 
 
 def test_local_energy_routing_by_cost_class():
-    """launch_mfma (csrc/ff_cnf_fwd.hip): with cost classes the walkers of class >= ff_ode.heavy_class (default 12) are integrated by the
+    """launch_mfma (csrc/ff_cnf_fwd.hip): with cost classes the walkers of class >= ff_ode.heavy_class (default 12 below 12 coordinates) are integrated by the
     one-walker-per-wave kernel (csrc/ff_wide.hip), the others by the four-walkers-per-wave matrix-core kernel.  Every walker is
     integrated exactly once and agrees with the oracle; a walker's result depends on its own class only -- not on the order of
     work, not on the rest of the batch."""
@@ -753,8 +753,26 @@ def test_one_launch_estimator_and_schedule_with_mean():
         order, hm = S.walker_order(cost, hval=h)
         assert (order == S.walker_order(cost)).all() and abs(hm - h.mean()) < 1e-14
         # ff_walker_schedule: the same order and mean, plus the first step of every walker from the factor table of its cost class --
-        # and the table follows the previous pass: classes of which > 20 % rejected their first step (he < hs) shrink by 0.93, < 5 % grow
-        # by 1.02 within [0.25, 1], classes with fewer than 64 walkers and walkers without a step keep theirs
+        # and the table follows the previous pass: classes of which > 20 % rejected their first step (he < hs) shrink by 0.93; classes
+        # with < 5 % grow by 1.02 if 70 % of their voters (without an interval: every walker) accepted a step of the plan one shorter
+        # (without an interval: 1.25 x the opening step); within [0.25, 1]; classes with fewer than 64 walkers and walkers without a
+        # step keep theirs
+        def rule(tab, cls, hs, he, interval):
+            want = tab.copy()
+            ok = (he > 0) & (hs > 0)
+            if interval > 0:
+                k = np.rint(interval / np.where(hs > 0, hs, 1.0))
+                vote = ok & (k >= 3)
+                yes = vote & (he >= 0.999 * interval / np.maximum(k - 1, 1))
+            else:
+                vote, yes = ok, ok & (he >= 1.25 * hs)
+            for c in range(32):
+                m = cls == c
+                n_c, r_c, v_c, y_c = int((m & ok).sum()), int((m & ok & (he < 0.999 * hs)).sum()), int((m & vote).sum()), int((m & yes).sum())
+                if n_c >= 64:
+                    f = 0.93 if r_c / n_c > 0.20 else (1.02 if (r_c / n_c < 0.05 and v_c >= 16 and y_c >= 0.7 * v_c) else 1.0)
+                    want[c] = min(1.0, max(0.25, tab[c] * f))
+            return want
         tab = np.where(np.arange(32) <= 6, 0.9, 0.6)
         o2, hm2, hs, tab1 = S.walker_schedule(cost, h, tab)
         assert (o2 == order).all() and hm2 == hm and (tab1 == tab).all()
@@ -763,18 +781,17 @@ def test_one_launch_estimator_and_schedule_with_mean():
         cls = np.minimum(cost, 31)
         rej = (cls == 3) | ((cls == 5) & (rng.random(B) < 0.12)) | (cls == 31)
         he[rej] *= 0.5
+        he[(cls <= 1) | (cls == 6)] *= 1.3                   # these accepted a step well beyond the one they opened with: room to grow
+        he[(cls == 9) & (rng.random(B) < 0.5)] *= 1.3        # only half of this class did: it stays (and so do 2, 4, 8: no rejections, no evidence)
         he[cls == 7] = 0.0                                   # a class whose walkers report no accepted step: no evidence
         _, _, hs2, tab2 = S.walker_schedule(cost, h, tab1, prev=(cost, hs, he))
-        want = tab.copy()
-        for c in range(32):
-            n_c = int(((cls == c) & (he > 0)).sum()); r_c = int(((cls == c) & (he > 0) & (he < 0.999 * hs)).sum())
-            if n_c >= 64:
-                want[c] = min(1.0, max(0.25, tab[c] * (0.93 if r_c / n_c > 0.20 else (1.02 if r_c / n_c < 0.05 else 1.0))))
+        want = rule(tab, cls, hs, he, 0.0)
         np.testing.assert_allclose(tab2, want, rtol=1e-15)
         np.testing.assert_array_equal(hs2, h * tab2[cls])    # the update is applied at once: this pass opens with what the last one taught
         # the same update from the statistics counted separately (ff_scale_counts: what a data-parallel run all-reduces)
         cnts = S.scale_counts(cost, hs, he)
-        assert cnts[:32].sum() == ((he > 0) & (hs > 0)).sum() and cnts[32:].sum() == ((he > 0) & (he < 0.999 * hs)).sum()
+        assert cnts[:32].sum() == ((he > 0) & (hs > 0)).sum() and cnts[32:64].sum() == ((he > 0) & (he < 0.999 * hs)).sum()
+        assert (cnts[64:96] == cnts[:32]).all() and cnts[96:].sum() == ((he > 0) & (he >= 1.25 * hs)).sum()
         _, _, hs2c, tab2c = S.walker_schedule(cost, h, tab1, counts=cnts)
         assert (tab2c == tab2).all() and (hs2c == hs2).all()
         # interval > 0: steps rounded down to interval / k
@@ -786,5 +803,20 @@ def test_one_launch_estimator_and_schedule_with_mean():
         assert sorted(o3.tolist()) == list(range(B)) and (np.diff(key[o3]) <= 0).all()
         np.testing.assert_allclose(hs3, np.where(hq < 1.0, 1.0 / np.ceil(1.0 / hq - 1e-9), hq), rtol=1e-15)
         assert (hs3 <= hq * (1 + 1e-12)).all()
+        # with an interval the voters are the walkers planned for k >= 3 equal steps, and the evidence a step >= interval / (k - 1)
+        k3 = np.rint(1.0 / hs3)
+        he3 = hs3.copy()
+        he3[(cls == 12) | (cls == 20)] = (1.0 / np.maximum(k3 - 1, 1))[(cls == 12) | (cls == 20)]      # (k = 2 walkers among them report 1.0: no vote)
+        he3[cls == 15] *= 1.2                                # larger steps, but short of the shorter plan's (k <= 5: 1.25 x at least)
+        he3[(cls == 15) & (k3 > 5)] = hs3[(cls == 15) & (k3 > 5)]
+        _, _, hs4, tab4 = S.walker_schedule(cost, h, tab, prev=(cost, hs3, he3), interval=1.0)
+        want4 = rule(tab, cls, hs3, he3, 1.0)
+        np.testing.assert_allclose(tab4, want4, rtol=1e-15)
+        cnts3 = S.scale_counts(cost, hs3, he3, interval=1.0)
+        assert cnts3[64:96].sum() == ((k3 >= 3) & (hs3 > 0)).sum()
+        _, _, hs4c, tab4c = S.walker_schedule(cost, h, tab, counts=cnts3, interval=1.0)
+        assert (tab4c == tab4).all() and (hs4c == hs4).all()
         if B >= 4100:      # (~100 walkers per class)
-            assert tab2[3] == tab[3] * 0.93 and tab2[0] == min(1.0, tab[0] * 1.02) and tab2[7] == tab[7]
+            assert tab2[3] == tab[3] * 0.93 and tab2[0] == min(1.0, tab[0] * 1.02) and tab2[6] == min(1.0, tab[6] * 1.02)
+            assert tab2[7] == tab[7] and tab2[9] == tab[9] and tab2[2] == tab[2] and tab2[5] == tab[5]
+            assert tab4[12] == tab[12] * 1.02 and tab4[20] == tab[20] * 1.02 and tab4[15] == tab[15] and tab4[3] == tab[3]

@@ -64,7 +64,7 @@ for tag in tags:
         rej = []
         model._h_flow = None
         mx, p9999, evs, ms, dE = [], [], [], [], []
-        buckets = [("<=4", 0, 4), ("5", 5, 5), ("6", 6, 6), ("7", 7, 7), ("8", 8, 8), ("9-11", 9, 11), (">=12", 12, 99)]
+        buckets = [("<=4", 0, 4), ("5", 5, 5), ("6", 6, 6), ("7", 7, 7), ("8", 8, 8), ("9-11", 9, 11), ("12-13", 12, 13), ("14-15", 14, 15), (">=16", 16, 99)]
         bmax = {b[0]: 0.0 for b in buckets}; bcnt = {b[0]: 0 for b in buckets}
         for k in range(nseeds):
             if len(zs) <= k:
