@@ -126,6 +126,7 @@ def _add_generic_potentials(r, x, extra):
 # (ff_ode.after_main_event), so that it runs under the small reduction kernels with the SIMDs to itself; "adj" -- in front of the adjoint
 # call (rounds 2-4: beside the adjoint kernel, while the two still fitted one SIMD together); "est" -- in front of the estimator kernel.
 _PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "kernel")
+_ADJOINT_OPEN = os.environ.get("FERMIFLOW_ADJOINT_OPEN", "flow")      # "eloc": the adjoint opens with 1.25 x the local-energy pass's step (rounds 2-4)
 
 
 class _Sweep:
@@ -270,7 +271,24 @@ class _Sweep:
         if prof is not None:
             prof.setdefault("pass1", []).append(p1)
             prof.setdefault("eloc_stats", []).append(r["stats"])
+        self._hg_last = hg      # the largest step every walker's flow pass accepted (the adjoint opens with it: _adjoint_open)
         return x, r, he
+
+    def _adjoint_open(self, he):
+        """Warm start of the adjoint pass (ff_ode.walker_h_init / _scale / _equal).  Rounds 2-4 opened it with 1.25 x the largest step
+        the walker's LOCAL-ENERGY pass accepted -- but the sensitivities are the stiffest of the three systems, and once they need three
+        steps of 1/3 the adjoint was opened with 0.42: never rejected, and a third step for every walker whose second step did not grow
+        by 1.4 x.  The adjoint follows the flow's own trajectory with a linear costate: it opens with 1.1 x the largest step the
+        walker's FLOW pass accepted, rounded down to equal steps of the interval (config 2, 200 iterations into the benchmark's
+        training: 15.9 -> 14.2 evaluations per walker, no rejections; 12 particles: 13.7 -> 13.1, rejected first steps 4 % -> 0.06 %;
+        configs[4]: 20.7 -> 18.9, 19 % -> 3 %; 1.3 x: 36 % rejected there -- tools/probes/adjoint_open.py).
+        FERMIFLOW_ADJOINT_OPEN=eloc keeps the old rule."""
+        hg = getattr(self, "_hg_last", None)
+        if not self.warm_start or he is None:
+            return {}
+        if hg is None or _ADJOINT_OPEN == "eloc":
+            return dict(walker_h_init=he, walker_h_scale=1.25)
+        return dict(walker_h_init=hg, walker_h_scale=1.1, walker_h_equal=True)
 
     def _reduce_with_counts(self, buf):
         """all-reduce of the estimator's sums with the first-step statistics of this pass riding along (one collective, not two)"""
@@ -567,9 +585,12 @@ class GSVMC(_Sweep, torch.nn.Module):
                         self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
                     go.record(self._side)      # (creates the handle; the library re-records it on the main stream)
                     after = go
-            _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
-                                       need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
-                                       walker_h_init=he, walker_h_scale=1.25, after_main_event=after)
+            adj = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
+                                     need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
+                                     after_main_event=after, want_stats=prof is not None, **self._adjoint_open(he))
+            gp = adj[1]
+            if prof is not None:
+                prof.setdefault("adjoint_stats", []).append(adj[2])
             if prefetch:
                 self._prefetch(prefetch, go)
             D.all_reduce_sum_(gp)
@@ -737,7 +758,7 @@ class BetaVMC(_Sweep, torch.nn.Module):
             self.logp_states_all = logp_all.to(self.log_state_weights.device)
             self._mark(ev, "estimator")
             _, gp = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol, need_gx=False,
-                                       energy=(Eloc, mean_e, 1.0 / nglob, ws), walker_h_init=he, walker_h_scale=1.25)
+                                       energy=(Eloc, mean_e, 1.0 / nglob, ws), **self._adjoint_open(he))
             D.all_reduce_sum_(gp)
             self._mark(ev, "adjoint")
         if prof is not None:

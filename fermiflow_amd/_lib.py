@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
-ABI_VERSION = 107      # ff_version() of the library this binding was written against (include/fermiflow.h)
+ABI_VERSION = 108      # ff_version() of the library this binding was written against (include/fermiflow.h)
 
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
@@ -34,7 +34,7 @@ class FFOde(C.Structure):
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
                 ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double),
-                ("compact_finish", C.c_int32), ("after_main_event", C.c_void_p)]
+                ("compact_finish", C.c_int32), ("after_main_event", C.c_void_p), ("walker_h_equal", C.c_int32)]
 
 
 def lib():
@@ -136,13 +136,14 @@ class Net:
 
 def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, walker_h_init=None, walker_h_scale=1.0,
         walker_h_out=None, walker_h_uniform=False, walker_class=None, sens_tol=1.0, sens_tol_class=0,
-        walker_h_scale_loose=0.0, heavy_class=0, heavy_tol=0.0, sum_weight=0.0, compact_finish=False, after_main_event=None):
+        walker_h_scale_loose=0.0, heavy_class=0, heavy_tol=0.0, sum_weight=0.0, compact_finish=False, after_main_event=None, walker_h_equal=False):
     """ff_ode; walker_cost (out) / walker_order (in): optional int32 tensors of length B (scheduling aids);
     walker_h_init (in) / walker_h_out (out): optional float64 tensors of length B (step-size warm start);
     walker_h_uniform: walker_h_init is a 1-element tensor, the first step of every walker;
     heavy_class / heavy_tol / sum_weight: routing threshold and tolerances of the local-energy pass (0: library defaults 12 (16 at 12 coordinates), 0.3, 4;
     heavy_class < 0: no routing); compact_finish: ff_eloc_nd finishes walkers in the one-walker-per-workgroup kernels' epilogue
-    (compact workspace beyond 24 coordinates; include/fermiflow.h)."""
+    (compact workspace beyond 24 coordinates; include/fermiflow.h); walker_h_equal: flow and adjoint passes round the opening step
+    walker_h_init x walker_h_scale down to equal steps of the interval."""
     for name, tns, dt in (("walker_cost", walker_cost, torch.int32), ("walker_order", walker_order, torch.int32),
                           ("walker_h_init", walker_h_init, torch.float64), ("walker_h_out", walker_h_out, torch.float64),
                           ("walker_class", walker_class, torch.int32)):
@@ -152,4 +153,4 @@ def ode(t0, t1, rtol, atol, max_steps=0, walker_cost=None, walker_order=None, wa
     return FFOde(float(t0), float(t1), float(rtol), float(atol), int(max_steps), p(walker_cost), p(walker_order),
                  p(walker_h_init), float(walker_h_scale), p(walker_h_out), p(walker_class), float(sens_tol), float(walker_h_scale_loose),
                  int(sens_tol_class), int(bool(walker_h_uniform)), int(heavy_class), float(heavy_tol), float(sum_weight), int(bool(compact_finish)),
-                 (int(after_main_event.cuda_event) or None) if after_main_event is not None else None)
+                 (int(after_main_event.cuda_event) or None) if after_main_event is not None else None, int(bool(walker_h_equal)))

@@ -123,7 +123,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
     S.begin(A.ta, A.tb, true);
     ff_dp5_ctl C;
     C.rtol = A.rtol; C.atol = A.atol; C.nt_inv = 1.0 / (2.0 * M); C.max_steps = A.max_steps;
-    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
+    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);      // (ff_ode.walker_h_equal: rounded by ff_open_steps_kernel in front of the launch)
     if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
     C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
     const double hwarm0 = C.hwarm;
@@ -330,7 +330,7 @@ ff_wide_adj_kernel(ff_adj_args A, int n) {
     S.begin(A.ta, A.tb, true);
     ff_dp5_ctl C;
     C.rtol = A.rtol; C.atol = A.atol; C.nt_inv = 1.0 / (2.0 * M); C.max_steps = A.max_steps;
-    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
+    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);      // (ff_ode.walker_h_equal: rounded by ff_open_steps_kernel in front of the launch)
     if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
     C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
     const double hwarm0 = C.hwarm;

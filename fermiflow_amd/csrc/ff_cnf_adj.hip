@@ -45,6 +45,7 @@ struct ff_adj_args {
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
   double h_scale;          // negative: h_init holds ONE entry used by every walker (ff_ode.walker_h_uniform), scale = -h_scale
+  int h_equal;             // the opening step rounded down to equal steps of the interval (ff_ode.walker_h_equal)
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): processing order of the walkers (ff_ode.walker_order)
@@ -308,7 +309,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     ff_stepper S;
     S.begin(A.ta, A.tb, valid);
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale);
+    const double hwarm = ff_open_step(ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.z_in, 0.0) * fabs(A.h_scale), A.ta, A.tb, A.h_equal);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -802,6 +803,17 @@ static void launch_adj(void* stream, const ff_adj_args& a_in) {
   }
 }
 
+// ff_ode.walker_h_equal for the one-walker-per-workgroup adjoint kernels: their opening steps are rounded HERE, in a launch of its own
+// (5 us in front of 1-30 ms), not in their walker prologue as everywhere else.  With ff_open_step in that prologue -- and the flag zero --
+// ff_wide_adjtab_kernel<3, 4, 1> failed every walker of a 20-particle batch on the GPU (not in the host simulator; no scratch, four
+// more VGPRs; the kernel spills 114 scalar registers into vector lanes and the change moved that; tools/check_agpr_spills.py finds
+// nothing): the kernels stay byte for byte what the parity tests pinned.
+__global__ void __launch_bounds__(256) ff_open_steps_kernel(int64_t B, const double* __restrict__ h_init, double scale, double ta, double tb,
+                                                            double* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = ff_open_step(h_init[b] * scale, ta, tb, 1);
+}
+
 extern "C" {
 
 static size_t adj_table_doubles(int64_t B, int Gtab) {   // one private table per workgroup of the tabulated kernel + Wtot
@@ -820,7 +832,7 @@ static bool adj_is_wide(int n, int d) {
 
 // doubles of the layout one kernel family uses (0: that family does not serve (n, d))
 static size_t adj_ws_doubles(bool wide, int64_t B, int n, int d, int He, int Hm) {
-  if (wide) return ff_wide_supported(n, d) ? adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1 : 0;
+  if (wide) return ff_wide_supported(n, d) ? adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1 + (size_t)B : 0;   // (+ B: opening steps, ff_ode.walker_h_equal)
   const bool narrow = (d == 2 && n >= 1 && n <= 12) || (d == 3 && n >= 2 && n <= 4);
   const int G = adj_G(n, d);
   return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d) * FF_ADJ_WPW) + 1 : 0;
@@ -871,7 +883,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out; a.h_equal = ode->walker_h_equal;
   a.z_in = z_t0; a.az_in = a_z; a.ad_in = a_d; a.w_e = w_e; a.w_mean = w_mean; a.w_index = w_index; a.w_scale = w_scale; a.gx_out = grad_x; a.rows = (double*)workspace; a.stats = stats;
   const bool wide = adj_is_wide(n, d);      // the family of THIS call, read once: layout, memset and launches below all follow it
   {
@@ -890,6 +902,12 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     FF_LAUNCH(ff_zero_kernel, 48, 256, stream, wt, (size_t)2 * FF_DEP_NTOT * FF_DEP_ROW + 1);
   }
   int G = 0;
+  if (wide && a.h_equal && a.h_init) {
+    const int64_t nh = a.h_scale < 0.0 ? 1 : B;      // (walker_h_uniform: one entry)
+    double* hs = a.off_table + 1;
+    FF_LAUNCH(ff_open_steps_kernel, (unsigned)((nh + 255) / 256), 256, stream, nh, a.h_init, fabs(a.h_scale), a.ta, a.tb, hs);
+    a.h_init = hs; a.h_scale = a.h_scale < 0.0 ? -1.0 : 1.0; a.h_equal = 0;
+  }
   if (wide) {
     // lanes per walker: two waves up to 128 radii (pairs + one-body), four beyond; one radius per lane up to 22 particles
     const int nr = n * (n + 1) / 2, Wv = nr <= 128 ? 2 : 4, nq = (nr + 64 * Wv - 1) / (64 * Wv);

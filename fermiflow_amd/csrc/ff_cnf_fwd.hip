@@ -200,7 +200,8 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     // warm start (ff_ode.walker_h_init): the step size to try first, instead of the probe evaluation of the Hairer start
     // (local-energy pass) walkers of a low cost class: looser tolerance for the sensitivity components, larger first step
     const bool loose = MODE == 2 && ff_opt_load(A.wclass, valid, b, A.y_in, (int32_t)0x7fffffff) <= A.sens_class;
-    const double hwarm = ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale));
+    const double hwarm = ff_open_step(ff_opt_load(A.h_init, valid, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * (loose ? A.h_scale_loose : fabs(A.h_scale)),
+                                      A.ta, A.tb, MODE == 2 ? 0 : A.h_equal);
     const bool warm = hwarm > 0.0;
     double hmax_acc = 0.0;
     int s = -2, nev = 0;
@@ -1582,7 +1583,7 @@ int ff_cnf_generate(void* stream, int64_t B, int n, int d, const ff_net* net, co
   a.B = B; a.net = *net; a.ta = ode->t0; a.tb = ode->t1; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out; a.h_equal = ode->walker_h_equal;
   a.y_in = z; a.y_out = x_out; a.stats = stats;
   return dispatch_fwd<0>(stream, n, d, a);
 }
@@ -1597,7 +1598,7 @@ int ff_cnf_delta_logp(void* stream, int64_t B, int n, int d, const ff_net* net, 
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out; a.h_equal = ode->walker_h_equal;
   a.y_in = x; a.y_out = z_out; a.dl_out = dlogp_out; a.stats = stats;
   return dispatch_fwd<1>(stream, n, d, a);
 }
@@ -1635,7 +1636,7 @@ static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const 
   a.B = B; a.net = *net; a.ta = ode->t1; a.tb = ode->t0; a.rtol = ode->rtol; a.atol = ode->atol;
   a.max_steps = ode->max_steps > 0 ? ode->max_steps : 10000;
   a.wcost = ode->walker_cost; a.order = ode->walker_order;
-  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out;
+  a.h_init = ode->walker_h_init; a.h_scale = ode->walker_h_uniform ? -fabs(ode->walker_h_scale) : fabs(ode->walker_h_scale); a.h_out = ode->walker_h_out; a.h_equal = ode->walker_h_equal;
   a.y_in = x; a.y_out = w.z0; a.dl_out = w.dl; a.Jt = w.Jt; a.kbar = w.kbar; a.dD = w.dD; a.Lpart = w.Lp; a.stats = stats;
   a.wclass = ode->walker_class; a.sens_class = ode->sens_tol_class;
   a.sens_w = ode->sens_tol > 1.0 ? 1.0 / ode->sens_tol : 1.0;

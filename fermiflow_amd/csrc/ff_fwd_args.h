@@ -18,6 +18,7 @@ struct ff_fwd_args {
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
   double h_scale;          // negative: h_init holds ONE entry used by every walker (ff_ode.walker_h_uniform), scale = -h_scale
+  int h_equal;             // flow kernels: the opening step rounded down to equal steps of the interval (ff_ode.walker_h_equal)
   double* h_out;           // optional (B): largest step size accepted for every walker in this call (ff_ode.walker_h_out)
   int32_t* wcost;         // optional (B): attempted steps of every walker (ff_ode.walker_cost)
   const int32_t* order;    // optional (B): workgroups take walkers in this order (ff_ode.walker_order); results stay in place

@@ -154,6 +154,24 @@ FF_D double ff_pow02(double x, float e) {
 }
 
 // Wave-wide OR of per-lane flag words (bit 0: still integrating, bit 1: just rejected a step); wave-uniform result.
+// The step a warm-started walker opens with (ff_ode.walker_h_init x walker_h_scale) -- with ff_ode.walker_h_equal rounded DOWN to
+// interval / k, the equal steps that cover the interval in as many steps as it would: two steps of 1/2 pass where 0.42 + 0.58 needs the
+// second one to grow by 1.4 x, which the step-size control only grants after an error below 0.11 of the tolerance (flow and adjoint
+// kernels; the local-energy pass gets its opening steps rounded by ff_walker_schedule).
+// (Selects, not a per-lane branch: a divergent join in a walker prologue is where ROCm 7.2's register allocator misplaces its AGPR
+// copies -- DESIGN.md 10 -- and `if (h > 0 && h < interval)` written as a branch did break ff_wide_adjtab_kernel<3, 4, .> at 20 particles:
+// every walker failed, with walker_h_equal = 0.  The flag itself is uniform.)
+FF_D double ff_open_step(double h, double ta, double tb, int equal) {
+  if (equal) {
+    const double interval = fabs(tb - ta);
+    const bool round = h > 0.0 && h < interval;
+    const double hs = round ? h : interval;
+    const double r = interval / ceil(interval / hs - 1e-9);
+    h = round ? r : h;
+  }
+  return h;
+}
+
 // Two ballots -- no LDS traffic, no barrier (64 lanes OR-ing into one LDS word serialise: that cost ~10 % of the
 // local-energy kernel).
 FF_D int ff_wave_or(int* s_any, int lane, int flags) {

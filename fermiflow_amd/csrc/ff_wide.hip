@@ -134,7 +134,7 @@ ff_wide_flow_kernel(ff_fwd_args A, int n) {
     S.begin(A.ta, A.tb, true);
     ff_dp5_ctl C;
     C.rtol = A.rtol; C.atol = A.atol; C.nt_inv = 1.0 / (double)(M + (MODE == 1 ? 1 : 0)); C.max_steps = A.max_steps;
-    C.hwarm = ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale);
+    C.hwarm = ff_open_step(ff_opt_load(A.h_init, true, A.h_scale < 0.0 ? 0 : b, A.y_in, 0.0) * fabs(A.h_scale), A.ta, A.tb, A.h_equal);
     if (!(C.hwarm > 0.0)) C.hwarm = 0.0;
     C.h0v = 0.0; C.d1v = 0.0; C.hmax_acc = 0.0;
     const double hwarm0 = C.hwarm;
@@ -306,11 +306,14 @@ FF_D int64_t ff_wide_next_heavy(const ff_fwd_args& A, int64_t bq, int lane) {
 #ifndef FF_WIDE_T1_WAVES
 #define FF_WIDE_T1_WAVES 1
 #endif
+#ifndef FF_WIDE_T2_WAVES
+#define FF_WIDE_T2_WAVES 1      // workgroups per SIMD pair the two-wave instantiations are compiled for (A/B knob: 2 = at most 256 registers)
+#endif
 // FIN: with the fused finish (ff_ode::compact_finish) as the epilogue of every walker.  A template parameter, not a run-time branch: the
 // epilogue's registers and LDS would otherwise weigh on the instantiations that run without it -- the T = 1 kernel of the heavy-walker
 // route went from 292 to 380 registers and config 2's pass from 0.809 to 0.832 ms with the branch merely compiled in.
 template <int D, int T, bool TAB, class TJ, bool FIN>
-__global__ void __launch_bounds__(FF_WAVE * T, T == 1 ? FF_WIDE_T1_WAVES : 1)
+__global__ void __launch_bounds__(FF_WAVE * T, T == 1 ? FF_WIDE_T1_WAVES : (T == 2 ? FF_WIDE_T2_WAVES : 1))
 ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   typedef ff_wide_mma<TJ> MMA;
   constexpr bool F32 = sizeof(TJ) == 4;

@@ -99,9 +99,16 @@ typedef struct ff_ode {
    * small kernels that reduce and contract the parameter gradient.  What waits on it (the sampler of a later iteration, in the
    * package) then runs under those latency-bound kernels instead of beside the adjoint kernel (ABI 106). */
   void* after_main_event;
+  /* Flow and adjoint passes with walker_h_init set: nonzero rounds the step a walker opens with, walker_h_init x walker_h_scale, DOWN to
+   * t_span / k -- the equal steps that cover the interval in as many steps as it would (ABI 108).  The sweeps open the adjoint with
+   * 1.1 x the largest step the walker's flow pass accepted, rounded this way: two steps of 1/2 where 0.42 + 0.58 needed the second
+   * step to grow by 1.4 x, which the step-size control grants to half of the walkers only (config 2 after 200 training iterations:
+   * 15.9 -> 14.2 evaluations per walker; 12 particles: 13.7 -> 13.1 with 4 % -> 0.06 % of the first steps rejected; configs[4]: 20.7 ->
+   * 18.9, 19 % -> 3 %).  The local-energy pass ignores it: ff_walker_schedule rounds its opening steps.  Error control is untouched. */
+  int32_t walker_h_equal;
 } ff_ode;
 
-int ff_version(void);   /* 107; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 108; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */

@@ -23,7 +23,7 @@ class FFOde(C.Structure):
                 ("walker_h_init", C.c_void_p), ("walker_h_scale", C.c_double), ("walker_h_out", C.c_void_p),
                 ("walker_class", C.c_void_p), ("sens_tol", C.c_double), ("walker_h_scale_loose", C.c_double), ("sens_tol_class", C.c_int32),
                 ("walker_h_uniform", C.c_int32), ("heavy_class", C.c_int32), ("heavy_tol", C.c_double), ("sum_weight", C.c_double),
-                ("compact_finish", C.c_int32), ("after_main_event", C.c_void_p)]
+                ("compact_finish", C.c_int32), ("after_main_event", C.c_void_p), ("walker_h_equal", C.c_int32)]
 
 
 def build():
@@ -169,10 +169,10 @@ _WARM = {}     # set by warm(h_init=..., h_scale=..., h_out=...) for the next ca
 
 
 def warm(h_init=None, h_scale=1.0, h_out=None, uniform=False, max_steps=0, wclass=None, sens_tol=1.0, sens_class=0, h_scale_loose=0.0,
-         heavy_class=0, heavy_tol=0.0, sum_weight=0.0):
+         heavy_class=0, heavy_tol=0.0, sum_weight=0.0, h_equal=False):
     _WARM.clear()
     _WARM.update(h_init=h_init, h_scale=h_scale, h_out=h_out, uniform=uniform, max_steps=max_steps, wclass=wclass, sens_tol=sens_tol, sens_class=sens_class,
-                 h_scale_loose=h_scale_loose, heavy_class=heavy_class, heavy_tol=heavy_tol, sum_weight=sum_weight)
+                 h_scale_loose=h_scale_loose, heavy_class=heavy_class, heavy_tol=heavy_tol, sum_weight=sum_weight, h_equal=h_equal)
 
 
 def _ode(t0, t1, rtol, atol, steps=None, order=None, compact=False):
@@ -181,7 +181,7 @@ def _ode(t0, t1, rtol, atol, steps=None, order=None, compact=False):
     return FFOde(t0, t1, rtol, atol, int(_WARM.get("max_steps", 0)), q(steps), q(order), q(_WARM.get("h_init")), float(_WARM.get("h_scale", 1.0)),
                  q(_WARM.get("h_out")), qi(_WARM.get("wclass")), float(_WARM.get("sens_tol", 1.0)), float(_WARM.get("h_scale_loose", 0.0)),
                  int(_WARM.get("sens_class", 0)), int(bool(_WARM.get("uniform", False))), int(_WARM.get("heavy_class", 0)),
-                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)), int(bool(compact)), None)
+                 float(_WARM.get("heavy_tol", 0.0)), float(_WARM.get("sum_weight", 0.0)), int(bool(compact)), None, int(bool(_WARM.get("h_equal", False))))
 
 
 def walker_order(cost, hval=None):

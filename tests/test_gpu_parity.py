@@ -651,6 +651,14 @@ def test_step_size_warm_start(dev):
     assert int(sw[0]) < 0.75 * int(sc[0])
     err = lambda g: ((g - g_t).norm() / g_t.norm()).item()
     assert err(g_w) < 1e-6 and err(g_w) < 10 * err(g_c) + 1e-8, (err(g_w), err(g_c))
+    # ff_ode.walker_h_equal (ABI 108; what the sweeps open the adjoint with since round 5: 1.1 x the FLOW pass's step, rounded down to
+    # equal steps of the interval): the same call as with the rounded steps passed explicitly, as many evaluations as the old rule on
+    # these weights (two steps either way; the gain is on trained flows: DESIGN.md 4), and as accurate
+    hr = 1.0 / torch.ceil(1.0 / (hg * 1.1) - 1e-9).clamp(min=1.0)
+    _, g_e, se = native.cnf_adjoint(net, *args, 1e-6, 1e-8, need_gx=False, want_stats=True, walker_h_init=hg, walker_h_scale=1.1, walker_h_equal=True)
+    _, g_r, sr = native.cnf_adjoint(net, *args, 1e-6, 1e-8, need_gx=False, want_stats=True, walker_h_init=hr, walker_h_scale=1.0)
+    assert torch.equal(se[:4], sr[:4]) and torch.equal(g_e, g_r)
+    assert int(se[0]) <= 1.01 * int(sw[0]) and int(se[3]) == 0 and err(g_e) < 1e-6 and err(g_e) < 10 * err(g_c) + 1e-8, (se[:4], sw[:4], err(g_e))
     # the sweep uses it by default; switching it off changes the estimate only at the solver-tolerance level
     Es = []
     for flag in (True, False):

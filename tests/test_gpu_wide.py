@@ -239,6 +239,15 @@ def test_config5_local_energy_vs_oracle(dev, bits, capsys):
     gxo, gpo, _ = O.cnf_adjoint(zo, dlo, az, ad, net, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(N(gx), gxo, atol=1e-6 * max(1.0, np.abs(gxo).max()))
     np.testing.assert_allclose(N(gp), gpo, atol=1e-6 * np.abs(gpo).max())
+    # ff_ode.walker_h_equal on the one-walker-per-workgroup adjoint (ff_open_steps_kernel in front of the launch): the same call as with
+    # the rounded steps passed explicitly, and the oracle's gradient
+    targs = (torch.as_tensor(zo, device=dev), torch.as_tensor(az, device=dev), torch.as_tensor(ad, device=dev), 0.0, 1.0, 1e-9, 1e-11)
+    h = torch.tensor([0.21, 0.3, 0.46, 1.2], dtype=torch.float64, device=dev)
+    hr = torch.where(h * 1.1 < 1.0, 1.0 / torch.ceil(1.0 / (h * 1.1) - 1e-9), h * 1.1)
+    ge = native.cnf_adjoint(v.net(), *targs, want_stats=True, walker_h_init=h, walker_h_scale=1.1, walker_h_equal=True)
+    gr = native.cnf_adjoint(v.net(), *targs, want_stats=True, walker_h_init=hr, walker_h_scale=1.0)
+    assert torch.equal(ge[0], gr[0]) and torch.equal(ge[1], gr[1]) and torch.equal(ge[2][:4], gr[2][:4]) and int(ge[2][3]) == 0
+    np.testing.assert_allclose(N(ge[1]), gpo, atol=1e-6 * np.abs(gpo).max())
 
 
 @pytest.mark.parametrize("nup,ndn,dim", [(3, 3, 2), (2, 1, 2), (7, 6, 2), (12, 12, 2), (5, 4, 3), (10, 10, 3)])

@@ -267,7 +267,7 @@ def test_compact_finish_workspace_sizes():
     from fermiflow_amd import _lib, native
     lib = _lib.lib()
     assert lib.ff_version() == _lib.ABI_VERSION >= 104
-    assert C.sizeof(_lib.FFOde) % 8 == 0 and _lib.FFOde._fields_[-2][0] == "compact_finish" and _lib.FFOde._fields_[-1][0] == "after_main_event"
+    assert C.sizeof(_lib.FFOde) % 8 == 0 and [f[0] for f in _lib.FFOde._fields_[-3:]] == ["compact_finish", "after_main_event", "walker_h_equal"]
     full = lambda B, n, d: lib.ff_eloc_workspace_bytes(C.c_int64(B), n, d)
     nd = lambda B, n, d, c: lib.ff_eloc_nd_workspace_bytes(C.c_int64(B), n, d, c)
     for (n, d) in ((6, 2), (12, 2), (8, 3)):                 # M <= 24

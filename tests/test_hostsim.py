@@ -731,6 +731,59 @@ def test_wide_adjoint_far_radii_take_the_overflow_list():
     np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
 
 
+def test_opening_steps_rounded_to_equal_steps():
+    """ff_ode.walker_h_equal (ABI 108): the flow and adjoint passes round the step a warm-started walker opens with -- walker_h_init x
+    walker_h_scale -- DOWN to t_span / k.  Equal, bit for bit, to passing the rounded steps themselves: narrow adjoint kernel (in its
+    walker prologue), one-walker-per-workgroup adjoint kernels (ff_open_steps_kernel in front of the launch; per-walker and uniform
+    entry), flow kernel."""
+    rng = np.random.default_rng(11)
+    He = Hm = 8
+    eta = [rng.normal(size=He) * 0.5, rng.normal(size=He) * 0.3, rng.normal(size=He) * 0.05]
+    mu = [rng.normal(size=Hm) * 0.5, rng.normal(size=Hm) * 0.3, rng.normal(size=Hm) * 0.05]
+    net = S.Net(eta, mu, table=True)
+    B = 6
+    z = rng.normal(size=(B, 3, 2)) * 0.8
+    az, ad = rng.normal(size=z.shape), rng.normal(size=B)
+    h = np.array([0.38, 0.46, 0.55, 0.31, 1.4, 0.26])
+    want = np.where(h * 1.1 < 1.0, 1.0 / np.ceil(1.0 / (h * 1.1) - 1e-9), h * 1.1)      # 1/3 1/2 1/2 1/3 1.54 1/4
+    assert np.allclose(want, [1 / 3, 0.5, 0.5, 1 / 3, 1.54, 0.25])
+
+    def adjoint(family, **w):
+        prev = S.lib().ff_set_kernel_family(family)
+        S.warm(**w)
+        try:
+            return S.cnf_adjoint(z, az, ad, net, rtol=1e-7, atol=1e-9)
+        finally:
+            S.warm()
+            S.lib().ff_set_kernel_family(prev)
+    for family in (0, 1):
+        a = adjoint(family, h_init=h, h_scale=1.1, h_equal=True)
+        b = adjoint(family, h_init=want, h_scale=1.0)
+        c = adjoint(family, h_init=h, h_scale=1.1)
+        assert a[2][3] == 0 and (a[0] == b[0]).all() and (a[2] == b[2]).all(), family
+        # (the parameter gradient: the two waves of a narrow workgroup deposit into one table in whatever order the host simulator's
+        # threads arrive -- an ulp between two identical calls)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(a[1], c[1], rtol=1e-5, atol=1e-8)           # the same gradient to the solver's tolerance
+        # uniform entry (ff_ode.walker_h_uniform): one step for every walker
+        u = adjoint(family, h_init=np.array([0.46]), h_scale=1.1, h_equal=True, uniform=True)
+        v = adjoint(family, h_init=np.array([0.5]), h_scale=1.0, uniform=True)
+        assert (u[0] == v[0]).all() and (u[2] == v[2]).all(), family
+        np.testing.assert_allclose(u[1], v[1], rtol=1e-13, atol=1e-15)
+    # flow pass
+    S.warm(h_init=np.array([0.46]), h_scale=1.1, h_equal=True, uniform=True)
+    try:
+        xa, sa = S.cnf_generate(z, net)
+    finally:
+        S.warm()
+    S.warm(h_init=np.array([0.5]), h_scale=1.0, uniform=True)
+    try:
+        xb, sb = S.cnf_generate(z, net)
+    finally:
+        S.warm()
+    assert (xa == xb).all() and (sa == sb).all()
+
+
 def test_one_launch_estimator_and_schedule_with_mean():
     """Round-4 launch diet.  ff_energy_estimate: the four estimator sums from many workgroups, joined in segment order by the
     workgroup that finishes last, and -- single rank -- E, the centred sum of squares and the surrogate in the same launch: equal

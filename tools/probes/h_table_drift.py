@@ -18,7 +18,9 @@ for it in range(N):
     if probe:
         st = m.profile["eloc_stats"][0]
         torch.cuda.synchronize()
-        line = "it %4d evals %.2f max-acc %d E %.4f hflow %.4f" % (it, st[0].item() / B, st[1].item(), m.E, float(m._h_flow.mean()))
+        sa = m.profile["adjoint_stats"][0]
+        line = "it %4d evals %.2f max-acc %d E %.4f hflow %.4f adjoint evals %.2f rej/walker %.3f" % (
+            it, st[0].item() / B, st[1].item(), m.E, float(m._h_flow.mean()), sa[0].item() / B, sa[2].item() / B)
         if m._h_tab is not None and m._h_prev is not None:
             tab = m._h_tab[m._h_tab_cur].cpu()
             c, hs, he = (t.cpu() for t in m._h_prev)
