@@ -18,7 +18,7 @@ SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",
     "ff_mcmc_sample_noise", "ff_mcmc_sample", "ff_mcmc_continue", "ff_rng_fill", "ff_mlp_eval", "ff_backflow_v_div", "ff_potential", "ff_radial_table_bytes", "ff_radial_table_build",
     "ff_cnf_generate", "ff_cnf_delta_logp", "ff_cnf_adjoint_workspace_bytes", "ff_cnf_adjoint", "ff_cnf_adjoint_energy", "ff_reduce_energy", "ff_energy_finish", "ff_stream_delay",
-    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_state_sums", "ff_beta_buffer_doubles", "ff_beta_state_partials", "ff_beta_finish", "ff_logprob3d", "ff_mcmc_sample_noise3d", "ff_mcmc_sample3d", "ff_eloc_finish3d", "ff_backflow_v_div_f32", "ff_walker_order_workspace_bytes", "ff_walker_order", "ff_set_kernel_family", "ff_set_sens_precision", "ff_shutdown", "ff_walker_order_mean", "ff_energy_estimate_workspace_bytes", "ff_energy_estimate", "ff_mlp_eval_nd", "ff_backflow_vjp", "ff_eloc_nd", "ff_eloc_nd_workspace_bytes", "ff_rng_fill3d", "ff_walker_schedule", "ff_scale_counts", "ff_comm_unique_id", "ff_comm_init", "ff_comm_allreduce", "ff_comm_destroy",
+    "ff_eloc_workspace_bytes", "ff_eloc", "ff_eloc_sensitivities", "ff_eloc_finish", "ff_reduce_moments", "ff_state_sums", "ff_beta_buffer_doubles", "ff_beta_state_partials", "ff_beta_finish", "ff_logprob3d", "ff_mcmc_sample_noise3d", "ff_mcmc_sample3d", "ff_eloc_finish3d", "ff_backflow_v_div_f32", "ff_walker_order_workspace_bytes", "ff_walker_order", "ff_set_kernel_family", "ff_set_sens_precision", "ff_shutdown", "ff_walker_order_mean", "ff_energy_estimate_workspace_bytes", "ff_energy_estimate", "ff_mlp_eval_nd", "ff_backflow_vjp", "ff_eloc_nd", "ff_eloc_nd_workspace_bytes", "ff_rng_fill3d", "ff_walker_schedule", "ff_scale_counts", "ff_comm_unique_id", "ff_comm_init", "ff_comm_allreduce", "ff_comm_destroy", "ff_adam_step",
 ]
 
 

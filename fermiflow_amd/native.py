@@ -346,6 +346,15 @@ def reduce_moments(e, shift=0.0, shift_dev=None, shift_dev_scale=1.0, out=None):
     return out
 
 
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    """ff_adam_step: one Adam update of the given fp64 device tensors (lists of equal length) in one launch."""
+    n = len(params)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+    L.check(L.lib().ff_adam_step(L.stream(), n, sizes, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), L.f64(lr), L.f64(beta1), L.f64(beta2),
+                                 L.f64(eps), L.f64(weight_decay), L.i64(step)), "ff_adam_step")
+
+
 def stream_delay(microseconds):
     """ff_stream_delay on the current stream."""
     L.check(L.lib().ff_stream_delay(L.stream(), L.f64(microseconds)), "ff_stream_delay")

@@ -4,6 +4,8 @@ The reference obtains grad and Laplacian of log p by 1 + n*d extra autograd pass
 ODE solves.  Here they come out of one native pass; `f` must therefore be one of the callables that know
 how to do that (GSVMC.logp / BetaVMC.logp bound methods, or a FreeFermion.log_prob closure made by
 `freefermion_logp`)."""
+import torch
+
 from . import native
 from .orbitals import orbital_indices, orbital_dim
 
@@ -33,12 +35,60 @@ def y_grad_laplacian(f, x):
     return fn(x)
 
 
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam for fp64 parameters on the GPU with the whole update in ONE launch (ff_adam_step: the single-tensor formula of
+    torch/optim/adam.py operation for operation).  Same hyper-parameters, same per-parameter state -- step (a CPU scalar tensor),
+    exp_avg, exp_avg_sq -- so state_dicts move between the two in both directions.  No amsgrad, no maximize, no closure-less tricks:
+    anything this class does not do raises, it never falls back to another implementation silently."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("FusedAdam: lr >= 0, eps >= 0, weight_decay >= 0, betas in [0, 1)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import native
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps, gs, ms, vs, steps = [], [], [], [], set()
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if not (p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() and g.dtype == torch.float64 and g.is_cuda and not g.is_sparse):
+                    raise RuntimeError("FusedAdam serves contiguous fp64 parameters on the GPU with dense fp64 gradients (make_adam picks "
+                                       "torch.optim.Adam for everything else)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                steps.add(int(st["step"].item()))
+                ps.append(p); gs.append(g if g.is_contiguous() else g.contiguous()); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            if not ps:
+                continue
+            b1, b2 = group["betas"]
+            for t in sorted(steps):      # (parameters that joined later have their own count: one launch per distinct count)
+                sel = [k for k, p in enumerate(ps) if int(self.state[p]["step"].item()) == t]
+                pick = lambda xs: [xs[k] for k in sel]
+                native.adam_step(pick(ps), pick(gs), pick(ms), pick(vs), float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], t)
+        return loss
+
+
 def make_adam(params, lr):
-    """torch.optim.Adam as the reference's drivers build it (src/FermionHO2D.py:61, lr = 1e-2) -- with PyTorch's fused
-    implementation when every parameter lives on the GPU: the same update in 1 launch instead of 7 (each tiny launch is
-    ~5 us of a 2.5 ms iteration).  FERMIFLOW_FUSED_ADAM=0 keeps the default implementation."""
+    """torch.optim.Adam as the reference's drivers build it (src/FermionHO2D.py:61, lr = 1e-2) -- as FusedAdam (one launch of the
+    library's own kernel) when every parameter is an fp64 tensor on the GPU, torch.optim.Adam otherwise.  FERMIFLOW_FUSED_ADAM=torch
+    takes PyTorch's fused implementation instead (rounds 2-4: two multi-tensor launches, 24 us each for 300 numbers),
+    FERMIFLOW_FUSED_ADAM=0 the default one (seven launches)."""
     import os
-    import torch
     params = list(params)
-    fused = os.environ.get("FERMIFLOW_FUSED_ADAM", "1") != "0" and len(params) > 0 and all(p.is_cuda for p in params)
-    return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
+    mode = os.environ.get("FERMIFLOW_FUSED_ADAM", "1")
+    on_gpu = len(params) > 0 and all(p.is_cuda for p in params)
+    if mode == "1" and on_gpu and all(p.dtype == torch.float64 and p.is_contiguous() for p in params):
+        return FusedAdam(params, lr=lr)
+    return torch.optim.Adam(params, lr=lr, fused=True) if (mode != "0" and on_gpu) else torch.optim.Adam(params, lr=lr)

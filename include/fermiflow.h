@@ -326,6 +326,12 @@ int ff_reduce_moments(void* stream, int64_t B, const double* e, double shift, co
  * ff_mcmc_sample on a side stream a moment AFTER the adjoint kernel of the main stream -- launched the other way round
  * the Metropolis waves fill every SIMD first and the two kernels run one after the other instead of side by side. */
 int ff_stream_delay(void* stream, double microseconds);
+/* torch.optim.Adam (src/FermionHO2D.py:61, src/BetaFermionHO2D.py) over `ntensors` fp64 device tensors in ONE launch: params, grads,
+ * exp_avg, exp_avg_sq are HOST arrays of device pointers, sizes their element counts; `step` is the 1-based count of this update
+ * (the caller's: nothing is read back).  The single-tensor formula of torch/optim/adam.py operation for operation, weight_decay as its
+ * L2 term; no amsgrad, no maximize.  (PyTorch's fused Adam takes two multi-tensor launches of 24 us for the 300 numbers of the flow.) */
+int ff_adam_step(void* stream, int ntensors, const int64_t* sizes, double* const* params, const double* const* grads, double* const* exp_avg,
+                 double* const* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step);
 int ff_reduce_energy(void* stream, int64_t B, const double* e, const double* logp, const double* shift_dev, double* sums4);
 int ff_energy_finish(void* stream, const double* sums4, const double* shift_dev, int64_t n_global, double* est3);
 /* The same estimator in ONE launch of many workgroups (ff_reduce_energy is a single workgroup: 19 us at 65 536 walkers): sums4 as

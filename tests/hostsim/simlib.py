@@ -208,6 +208,15 @@ def walker_schedule(cost, hval, scale_in, prev=None, interval=0.0, counts=None):
     return order, hm[0], hs, scale_out
 
 
+def adam_step(params, grads, m, v, lr, beta1, beta2, eps, wd, step):
+    """ff_adam_step on lists of float64 arrays (updated in place)"""
+    n = len(params)
+    arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs])
+    sizes = (C.c_int64 * n)(*[x.size for x in params])
+    _ck(lib().ff_adam_step(None, n, sizes, arr(params), arr(grads), arr(m), arr(v), C.c_double(lr), C.c_double(beta1), C.c_double(beta2),
+                           C.c_double(eps), C.c_double(wd), C.c_int64(step)))
+
+
 def scale_counts(cost, hs, he, interval=0.0):
     cost = _i(cost); counts = np.zeros(128)
     _ck(lib().ff_scale_counts(None, C.c_int64(len(cost)), _p(cost), _p(_d(hs)), _p(_d(he)), C.c_double(interval), _p(counts)))

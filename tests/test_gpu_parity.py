@@ -934,6 +934,43 @@ def test_backward_short_cut_respects_parameter_hooks(dev):
         np.testing.assert_allclose(N(p.grad), N(a), rtol=1e-5, atol=1e-7 * float(a.abs().max()))
 
 
+def test_fused_adam_equals_torch_adam(dev):
+    """fermiflow_amd.utils.FusedAdam (ff_adam_step: every tensor of the flow in one launch) against torch.optim.Adam's default
+    implementation on the same gradients (src/FermionHO2D.py:61 builds the latter): parameters to 2e-15 over ten steps, a changed lr
+    honoured (param_groups), and the optimizer state moves between the two classes in both directions."""
+    import __graft_entry__ as Gm
+    from fermiflow_amd.utils import FusedAdam, make_adam
+    ma, mb = Gm._model(dev, 3, 3, 2.0), Gm._model(dev, 3, 3, 2.0)
+    oa, ob = make_adam(ma.parameters(), lr=1e-2), torch.optim.Adam(mb.parameters(), lr=1e-2)
+    assert isinstance(oa, FusedAdam)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for it in range(10):
+        if it == 6:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 3e-3
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            g = torch.randn(pa.shape, generator=gen, dtype=torch.float64).to(dev)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-15, atol=1e-17), it
+    # state_dicts are interchangeable: continue each run with the OTHER class
+    oc, od = torch.optim.Adam(ma.parameters(), lr=1e-2), FusedAdam(mb.parameters(), lr=1e-2)
+    oc.load_state_dict(oa.state_dict()); od.load_state_dict(ob.state_dict())
+    for it in range(3):
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            g = torch.randn(pa.shape, generator=gen, dtype=torch.float64).to(dev)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oc.step(); od.step()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-15, atol=1e-17), it
+    # what it does not serve it refuses
+    q = torch.nn.Parameter(torch.zeros(3, dtype=torch.float32, device=dev)); q.grad = torch.ones_like(q)
+    with pytest.raises(RuntimeError):
+        FusedAdam([q], lr=1e-2).step()
+    assert isinstance(make_adam([q], lr=1e-2), torch.optim.Adam)
+
+
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):
     """GSVMC.prefetch_walkers (default on): the Metropolis kernels of the next two iterations run on a side stream, released behind
     this iteration's adjoint kernel (ff_ode.after_main_event).  Same seeds in the same order -> the same walkers: three training

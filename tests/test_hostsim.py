@@ -731,6 +731,33 @@ def test_wide_adjoint_far_radii_take_the_overflow_list():
     np.testing.assert_allclose(gp, gpo, atol=1e-6 * max(1.0, np.abs(gpo).max()))
 
 
+def test_adam_step_equals_torch_adam():
+    """ff_adam_step (one launch for all tensors) against torch.optim.Adam's default implementation (src/FermionHO2D.py:61), fp64, over
+    several steps, with and without weight decay, tensors of different sizes including more than one launch's worth (16)."""
+    import torch
+    rng = np.random.default_rng(4)
+    for wd, nt in ((0.0, 6), (0.01, 19)):
+        shapes = [(int(rng.integers(1, 70)),) for _ in range(nt)]
+        p0 = [rng.normal(size=sh) for sh in shapes]
+        tp = [torch.tensor(a.copy(), dtype=torch.float64, requires_grad=True) for a in p0]
+        opt = torch.optim.Adam(tp, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        mine = [a.copy() for a in p0]
+        m = [np.zeros_like(a) for a in p0]; v = [np.zeros_like(a) for a in p0]
+        for step in range(1, 8):
+            gs = [rng.normal(size=sh) * (10.0 if step == 3 else 1.0) for sh in shapes]
+            for t, g in zip(tp, gs):
+                t.grad = torch.tensor(g.copy())
+            opt.step()
+            S.adam_step(mine, gs, m, v, 1e-2, 0.9, 0.999, 1e-8, wd, step)
+            for a, t in zip(mine, tp):
+                np.testing.assert_allclose(a, t.detach().numpy(), rtol=2e-15, atol=1e-17)
+        st = opt.state[tp[0]]
+        np.testing.assert_allclose(m[0], st["exp_avg"].numpy(), rtol=1e-15, atol=1e-18)
+        np.testing.assert_allclose(v[0], st["exp_avg_sq"].numpy(), rtol=1e-15, atol=1e-18)
+    with pytest.raises(RuntimeError):
+        S.adam_step(mine, gs, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0)      # step counts from 1
+
+
 def test_opening_steps_rounded_to_equal_steps():
     """ff_ode.walker_h_equal (ABI 108): the flow and adjoint passes round the step a warm-started walker opens with -- walker_h_init x
     walker_h_scale -- DOWN to t_span / k.  Equal, bit for bit, to passing the rounded steps themselves: narrow adjoint kernel (in its
