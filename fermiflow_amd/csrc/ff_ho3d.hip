@@ -126,15 +126,23 @@ FF_D double ff3_add_rn(double a, double b) { double r = a + b; FF_OPAQUE(r); ret
 // the respective one-lane kernel.  g0 without NOISE: the walkers to continue from (ff_mcmc_continue).
 // NS: compile-time capacity of a species' determinant (8, 10 or 12: the matrix row of a lane and every elimination loop have that many
 // entries -- at configs[4], 10 x 10, a sixth less than with FF_MAX_NS)
+#ifndef FF_ROWS_WAVES
+#define FF_ROWS_WAVES 4      // waves per SIMD the sixteen-lane sampler is compiled for (115 registers; A/B knob)
+#endif
 template <int D, bool NOISE, int NS>
-__global__ void __launch_bounds__(FF_WAVE)
+__global__ void __launch_bounds__(FF_WAVE, FF_ROWS_WAVES)
 ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up, const int* __restrict__ tab_dn,
                     const int* __restrict__ wstate, int steps, double tau, const double* __restrict__ g0,
                     const double* __restrict__ g, const double* __restrict__ u, uint64_t seed, int64_t woff,
                     double* __restrict__ x_out, double* __restrict__ logp_out, uint8_t* __restrict__ accept, int* __restrict__ acc_count) {
   __shared__ double s_row[2][4][NS];            // the pivot row of a column, double-buffered by column parity: ONE barrier per column
   __shared__ int s_deg[4][NS][D];               // Hermite degrees of the group's orbitals
-  __shared__ double s_h[FF_WAVE][D][8];         // per lane: h_0..h_7 of each coordinate of its particle
+  // per lane: h_0 .. h_{MDL-1} of each coordinate of its particle.  Degrees beyond (orbitals past the fourth shell: 10 per species in
+  // d = 2, 20 in d = 3 -- excited many-body states of BetaVMC) are re-run through the recurrence where they are needed (same operations,
+  // same bits).  With all eight degrees tabulated this array alone was 12 of the kernel's 14.6 KB of LDS: ten workgroups per CU, 2.5
+  // waves per SIMD for a kernel whose every column of the elimination waits for a pivot.
+  constexpr int MDL = 4;
+  __shared__ double s_h[FF_WAVE][D][MDL];
   __shared__ int s_md;
   const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
   const int64_t gid = (int64_t)blockIdx.x * 4 + grp;
@@ -180,20 +188,31 @@ ff_mcmc_rows_kernel(int64_t B, int nup, int ndn, const int* __restrict__ tab_up,
       double hm = 1.0, h = FF_REC_A[0] * xx[c];
       s_h[lane][c][0] = 1.0;
       s_h[lane][c][1] = h;
-      for (int m = 1; m < md; m++) {
+      const int mtab = md < MDL - 1 ? md : MDL - 1;
+      for (int m = 1; m < mtab; m++) {
         const double hn = fma(FF_REC_A[m] * xx[c], h, -FF_REC_B[m] * hm);
         hm = h;
         h = hn;
         s_h[lane][c][m + 1] = h;
       }
     }
+    auto hdeg = [&](int c, int dg) -> double {      // (dg is uniform within the group)
+      if (dg < MDL) return s_h[lane][c][dg];
+      double hm = 1.0, h = FF_REC_A[0] * xx[c];
+      for (int m = 1; m < dg; m++) {
+        const double hn = fma(FF_REC_A[m] * xx[c], h, -FF_REC_B[m] * hm);
+        hm = h;
+        h = hn;
+      }
+      return h;
+    };
 #pragma unroll
     for (int j = 0; j < NS; j++) {
       double v = 0.0;
       if (j < ns) {
         v = gs;
 #pragma unroll
-        for (int c = 0; c < D; c++) v *= s_h[lane][c][s_deg[grp][j][c]];
+        for (int c = 0; c < D; c++) v *= hdeg(c, s_deg[grp][j][c]);
       }
       A[j] = v;
     }

@@ -493,6 +493,20 @@ def test_ho3d_logprob_and_sampler(golden):
     xo, lpo, acco = O.mcmc_noise3d(g0, g, u, 3, 2)
     assert (acc == acco).all() and (x == xo).all()
     np.testing.assert_allclose(lp, lpo, atol=1e-12)
+    # orbitals of the fifth shell and beyond: Hermite degrees >= 4, past the four the sampler tabulates per lane in LDS (round 5:
+    # those are re-run through the recurrence) -- same chain as the oracle's, bit for bit, in d = 3 and in d = 2
+    iu, idn = np.array([0, 3, 21, 30]), np.array([1, 25, 34])
+    g0, g, u = rng.randn(3, 7, 3), rng.randn(4, 3, 7, 3), rng.rand(4, 3)
+    x, lp, acc = S.mcmc_noise3d(g0, g, u, 4, 3, tab_up=iu, tab_dn=idn)
+    xo, lpo, acco = O.mcmc_noise3d(g0, g, u, 4, 3, tab_up=iu, tab_dn=idn)
+    assert (acc == acco).all() and (x == xo).all()
+    np.testing.assert_allclose(lp, lpo, atol=1e-12)
+    iu, idn = np.array([0, 2, 5, 9, 12, 17, 27]), np.array([1, 4, 10, 14, 20, 22])
+    g0, g, u = rng.randn(2, 13, 2), rng.randn(3, 2, 13, 2), rng.rand(3, 2)
+    x, lp, acc = S.mcmc_noise(g0, g, u, 7, 6, tab_up=iu, tab_dn=idn)
+    xo, lpo, acco = O.mcmc_noise(g0, g, u, 7, 6, tab_up=iu, tab_dn=idn)
+    assert (acc == acco).all() and (x == xo).all()
+    np.testing.assert_allclose(lp, lpo, atol=1e-12)
     xs, lps, cnt = S.mcmc3d(6, 4, 4, 8, 99)          # Philox sampler: closed shells 0..1 for both spins
     assert np.isfinite(xs).all() and 0 < cnt.sum() <= 6 * 8
     np.testing.assert_allclose(lps, O.logprob3d(xs, 4, 4, derivs=False), atol=1e-11)
