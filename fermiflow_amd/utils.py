@@ -46,6 +46,12 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: lr >= 0, eps >= 0, weight_decay >= 0, betas in [0, 1)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():      # (torch's fused Adam keeps `step` on the device: reading it there would wait for the GPU every update)
+            if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         from . import native

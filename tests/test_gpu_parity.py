@@ -964,6 +964,16 @@ def test_fused_adam_equals_torch_adam(dev):
         oc.step(); od.step()
         for pa, pb in zip(ma.parameters(), mb.parameters()):
             assert torch.allclose(pa, pb, rtol=2e-15, atol=1e-17), it
+    # a checkpoint of PyTorch's FUSED Adam (rounds 2-4 of this package: `step` lives on the device there) loads too, its step counts brought
+    # to the host
+    of = torch.optim.Adam(ma.parameters(), lr=1e-2, fused=True)
+    for pa in ma.parameters():
+        pa.grad = torch.ones_like(pa)
+    of.step()
+    oe = FusedAdam(ma.parameters(), lr=1e-2); oe.load_state_dict(of.state_dict())
+    assert all(not st["step"].is_cuda and float(st["step"]) == 1.0 for st in oe.state.values())
+    oe.step()
+    assert all(float(st["step"]) == 2.0 for st in oe.state.values())
     # what it does not serve it refuses
     q = torch.nn.Parameter(torch.zeros(3, dtype=torch.float32, device=dev)); q.grad = torch.ones_like(q)
     with pytest.raises(RuntimeError):
