@@ -475,7 +475,7 @@ def main():
                          if kind == "wide" else ("four walkers per wave, two waves per SIMD; J' = A J and S = J J^T on v_mfma_f64_4x4x4 (2 x 2 M^3 of the priced flops), the rest fp64 VALU; "
                           "the flops are those of the S = J J^T formulation this kernel runs (the column sweep of rounds 1-2 priced 13575 per evaluation at 6 particles); "
                           "avg_launch_ms spans the whole pass: the walkers of the highest cost classes (>= 16 at 12 coordinates: 0.04 %; >= 12 below) run beside it on the one-walker-per-wave kernel "
-                          "(ff_wide_eloc_kernel<2, 1, true, double, false>, DESIGN.md 3g), their evaluations are in the count") if kind == "mfma" else
+                          "(ff_wide_eloc_kernel<2, 1, true, double, true>, which finishes them too; DESIGN.md 3g), their evaluations are in the count") if kind == "mfma" else
                          "fp64 VALU (instruction-issue) bound: the schema's hbm|mfma do not describe it; no MFMA is issued "
                          "(the MLPs are 1->H->1; FF_ELOC_KERNEL=mfma selects the matrix-core variant of this kernel)") +
                         ("; peak = MI355X fp32 matrix peak" if f32_path else "; peak = MI355X fp64 vector = fp64 matrix peak"),
@@ -487,11 +487,12 @@ def main():
                 # without a fused finish write and re-read is traffic, not algorithm; `workspace_bytes` states it)
                 "algorithmic_bytes": wpg * 8 * (4 * M + 5),
                 "workspace_bytes": 0 if (kind == "mfma" and nup == ndown) else wpg * 8 * (M * M + 4 * M + 1)}
-    # every kernel of the pass between the two events (routing: the heavy walkers' kernel and their two finish kernels run beside /
-    # in the shadow of the throughput kernel): their counters are added up
+    # every kernel of the pass between the two events (routing: the heavy walkers' kernel runs beside the throughput kernel): their
+    # counters are added up
     pass_kernels = [kname.split("<")[0] + "<" + kname.split("<")[1].split(">")[0]]
     if kind in ("mfma", "columns") and dim == 2 and n <= 6 and model.heavy_class >= 0 and radial == "table":
-        pass_kernels += ["ff_wide_eloc_kernel<2, 1, true, double, false>"] + (["ff_eloc_slater_fixed_kernel", "ff_eloc_contract_kernel"] if (kind == "mfma" and nup == ndown) else [])
+        # (beside a throughput kernel with the fused finish the heavy kernel finishes its walkers itself: its FIN instantiation)
+        pass_kernels += ["ff_wide_eloc_kernel<2, 1, true, double, true>" if (kind == "mfma" and nup == ndown) else "ff_wide_eloc_kernel<2, 1, true, double, false>"]
     roofline["kernels_of_the_pass"] = pass_kernels
 
     out = {"metric": "walker-steps/sec (full VMC iteration: 100 MCMC steps + generate + E_loc + grad + Adam)",

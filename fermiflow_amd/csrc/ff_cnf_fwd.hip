@@ -1383,6 +1383,13 @@ static int launch_routed(void* stream, int n, int d, const ff_fwd_args& a, F lau
   ff_fwd_args h = a, l = a;
   h.queue = nullptr; h.heavy_mode = 1;      // grid-stride over every walker, the light ones skipped
   if (!throughput_fuses) h.fin.on = 0;
+#ifndef FF_WIDE_NO_FIN
+  // Beside a throughput kernel that finishes its walkers itself the heavy kernel does too (its FIN instantiation): two launches less
+  // -- the filtered finish kernels walked the whole batch for a few dozen walkers -- and no sensitivities in the workspace.  Round 4
+  // measured that as slower (pass 0.809 -> 0.832 ms) and left it to ff_ode.compact_finish; what it had measured was the heavy kernel's
+  // residency (342 instead of 292 registers on a thousand SIMDs for ~100 us: see ff_wide_next_heavy) -- since round 5: 0.795 either way.
+  else h.fin.on |= 2;
+#endif
   if (a.heavy_tol > 0.0) { h.rtol *= a.heavy_tol; h.atol *= a.heavy_tol; }
   l.heavy_mode = 2;
   // placed first: a persistent grid takes every register file it finds

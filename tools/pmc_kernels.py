@@ -10,9 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 KERNELS = {"local-energy sensitivities + fused finish (two-wave matrix-core kernel)": "ff_eloc_mfma_kernel<6, 2, true, 2>",
-           "local-energy sensitivities (heavy route: the highest cost classes, one walker per wave)": "ff_wide_eloc_kernel<2, 1, true, double, false>",
-           "heavy route: Slater table": "ff_eloc_slater_fixed_kernel<3>",
-           "heavy route: contraction": "ff_eloc_contract_kernel",
+           "local-energy sensitivities + finish (heavy route: the highest cost classes, one walker per wave)": "ff_wide_eloc_kernel<2, 1, true, double, true>",
            "theta-gradient adjoint (two waves per workgroup)": "ff_ode_adjtab_kernel<6, 2, 2>",
            "Metropolis sampler (beside the adjoint)": "ff_mcmc_spin_philox_kernel<3>",
            "flow": "ff_ode_fwd_kernel<6, 2, 0, true>"}
