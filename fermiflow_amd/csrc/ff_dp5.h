@@ -150,8 +150,8 @@ FF_D float ff_t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c);
 FF_D double ff_t_rcp(double x) { return ff_rcp(x); }
 FF_D float ff_t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp: error norms only
 
-template <int NA, class TA, class C3A, int NB, class C3B, class WB, class G>
-FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, TA* yA, TA* c0A, TA* c1A, TA* c2A, C3A& c3A, const TA* outA, double wA_,
+template <int NA, class TA, class C3A, int NB, class C3B, class YA, class WB, class G>
+FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, TA* c1A, TA* c2A, C3A& c3A, const TA* outA, double wA_,
                          double* yB, double* c0B, double* c1B, double* c2B, C3B& c3B, const double* outB, WB wgtB, G gsum) {
   const double h = S.h, rtol = C.rtol, atol = C.atol;
   const TA hA = (TA)h, rtA = (TA)rtol, atA = (TA)atol, wA = (TA)wA_;

@@ -306,6 +306,12 @@ FF_D int64_t ff_wide_next_heavy(const ff_fwd_args& A, int64_t bq, int lane) {
 #ifndef FF_WIDE_T1_WAVES
 #define FF_WIDE_T1_WAVES 1
 #endif
+#ifndef FF_WIDE_C3_FROM
+#define FF_WIDE_C3_FROM 2       // waves per walker from which the fp64 kernel keeps its error accumulator in lane-private LDS columns (A/B knob)
+#endif
+#ifndef FF_WIDE_Y_FROM
+#define FF_WIDE_Y_FROM 99       // waves per walker from which (up to two) the fp64 kernel keeps the J part of y in LDS as well (A/B knob)
+#endif
 #ifndef FF_WIDE_T2_WAVES
 #define FF_WIDE_T2_WAVES 1      // workgroups per SIMD pair the two-wave instantiations are compiled for (A/B knob: 2 = at most 256 registers)
 #endif
@@ -324,7 +330,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   constexpr int RCAP = NCAP * (NCAP + 1) / 2;
   constexpr int NQ = (RCAP + NTHR - 1) / NTHR;
   constexpr int NPK = (NCAP + 3) / 4;                  // partners per row lane
-  constexpr bool C3_LDS = T >= 3 && TAB && !F32;       // (the direct-evaluation variant needs the LDS for its weight tables)
+  constexpr bool C3_LDS = T >= FF_WIDE_C3_FROM && TAB && !F32;       // (the direct-evaluation variant needs the LDS for its weight tables)
   // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
   //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
   // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
@@ -337,7 +343,9 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   __shared__ __attribute__((aligned(16))) TJ s_A[MP * JS];   // A = dv/dz with row M = -grad div
   __shared__ __attribute__((aligned(16))) double s_rec[(RCAP + 1) * RW];   // + one record that stays zero
   __shared__ double s_z[MP], s_kb[MP], s_red[NTHR], s_red2[16];
+  constexpr bool Y_LDS = T >= FF_WIDE_Y_FROM && T <= 2 && TAB && !F32;      // the J part of y as well (two waves per walker: LDS to spare)
   __shared__ TJ s_c3[C3_LDS ? NVJ * NTHR : 1];
+  __shared__ TJ s_yJ[Y_LDS ? NVJ * NTHR : 1];
   __shared__ double s_c3s[C3_LDS ? NVS * NTHR : 1];
   __shared__ int s_st[4];
   __shared__ long long s_next;
@@ -419,7 +427,8 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       const bool heavy = A.wclass[b] >= A.heavy_class;
       if (heavy != (A.heavy_mode == 1)) continue;
     }
-    TJ yJ[NVJ], c0J[NVJ], c1J[NVJ], c2J[NVJ];
+    TJ c0J[NVJ], c1J[NVJ], c2J[NVJ];
+    ff_wide_vec<TJ, NVJ, NTHR, Y_LDS> yJ(s_yJ, tid);
     ff_wide_vec<TJ, NVJ, NTHR, C3_LDS> c3J(s_c3, tid);
     double y[NVS], c0[NVS], c1[NVS], c2[NVS];
     ff_wide_vec<double, NVS, NTHR, C3_LDS> c3(s_c3s, tid);
@@ -712,7 +721,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       }
       }      // rep
 #endif
-      s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
+      s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3), decltype(yJ)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
       FF_STAMP(8);
       if (s == 99) break;
     }
