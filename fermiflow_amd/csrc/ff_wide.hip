@@ -309,6 +309,9 @@ FF_D int64_t ff_wide_next_heavy(const ff_fwd_args& A, int64_t bq, int lane) {
 #ifndef FF_WIDE_C3_FROM
 #define FF_WIDE_C3_FROM 2       // waves per walker from which the fp64 kernel keeps its error accumulator in lane-private LDS columns (A/B knob)
 #endif
+#ifndef FF_WIDE_C3_F32
+#define FF_WIDE_C3_F32 0        // ... and the fp32-sensitivity instantiations too (A/B knob)
+#endif
 #ifndef FF_WIDE_Y_FROM
 #define FF_WIDE_Y_FROM 99       // waves per walker from which (up to two) the fp64 kernel keeps the J part of y in LDS as well (A/B knob)
 #endif
@@ -330,7 +333,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
   constexpr int RCAP = NCAP * (NCAP + 1) / 2;
   constexpr int NQ = (RCAP + NTHR - 1) / NTHR;
   constexpr int NPK = (NCAP + 3) / 4;                  // partners per row lane
-  constexpr bool C3_LDS = T >= FF_WIDE_C3_FROM && TAB && !F32;       // (the direct-evaluation variant needs the LDS for its weight tables)
+  constexpr bool C3_LDS = T >= FF_WIDE_C3_FROM && TAB && (!F32 || FF_WIDE_C3_F32);       // (the direct-evaluation variant needs the LDS for its weight tables)
   // record of a radius: written by R1: [0,D) rho  [D] f0 = eta  [D+1] eta'/r  [D+2] gq = c phi'/r  [D+3, 2D+3) D_v[kbar] part
   //   [2D+4] 1/r^2  [2D+5] eta''  [2D+6] c phi''      (c = 2 for pairs, 1 for one-body radii; phi = eta' r + D eta)
   // written by R2: [D+3, 2D+3) the second-order source of kbar (the R1 entry is dead by then)
