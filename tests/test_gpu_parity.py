@@ -865,6 +865,38 @@ def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
     assert max(worst) <= max(1.5 * max(plain), 3e-6), (worst, plain)
 
 
+def test_first_step_table_settles_on_a_trained_flow(dev, capsys):
+    """The learned first-step table (ff_walker_schedule) on a flow whose sensitivities need three steps of 1/3 per walker (the "trained"
+    set of tests/golden/trained_weights.npz): without a growth condition every class cycled -- no rejections at three steps, x 1.02 for
+    four passes until two steps of 1/2 were planned, 40-70 % of them rejected, x 0.93, and again: one pass in five at 24 evaluations per
+    walker instead of 21 (round 5, tools/probes/h_table_drift.py).  Growth now needs evidence that the shorter plan would hold
+    (ff_scale_update); here: 40 sweeps of fresh walkers on fixed weights, and over the last 20 the evaluations per walker stay within
+    +- 2 % of their mean and no factor of a populated class grows."""
+    import os
+    import __graft_entry__ as Gm
+    model = Gm._model(dev, 3, 3, 2.0)
+    _load_weight_set(model, np.load(os.path.join(os.path.dirname(__file__), "golden", "trained_weights.npz")), "trained")
+    torch.manual_seed(77)
+    evals, tabs = [], []
+    for it in range(40):
+        model.profile = {"stages": False}
+        with torch.no_grad():
+            model(65536)
+        pr, model.profile = model.profile, None
+        evals.append(int(pr["eloc_stats"][0][0].item()) / 65536)
+        tabs.append(model._h_tab[model._h_tab_cur][2:9].clone())
+    late = np.array(evals[20:])
+    steps = torch.stack(tabs[20:])[1:] - torch.stack(tabs[20:])[:-1]
+    grown, shrunk = int((steps > 1e-12).sum()), int((steps < -1e-12).sum())
+    with capsys.disabled():
+        print(f"\n[first-step table on a trained flow] evaluations per walker, sweeps 20-39: mean {late.mean():.2f}, min {late.min():.2f}, max {late.max():.2f}; "
+              f"factor updates of classes 2..8 in that window: {grown} up, {shrunk} down")
+    assert late.max() - late.min() < 0.04 * late.mean(), late
+    # (a class whose rejection rate sits at the 20 % threshold may still take a step down on some batch; what must not happen is the
+    # climb back towards a plan its walkers have shown no room for)
+    assert grown == 0 and shrunk <= 2, (grown, shrunk)
+
+
 @pytest.mark.parametrize("shape", ["c2", "c5"])
 def test_throughput_sampler_distribution_vs_parity_sampler(dev, shape, capsys):
     """VERDICT r04 next #8.  The production Metropolis kernels (FreeFermion.sample: Philox, Box-Muller on the fp32 transcendentals,
