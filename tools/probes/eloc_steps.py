@@ -8,6 +8,14 @@ from fermiflow_amd import native
 dev = torch.device("cuda:0")
 B = 65536
 model = G._model(dev, 3, 3, 2.0)
+if len(sys.argv) > 1 and sys.argv[1] != "head":      # a weight set of tests/golden/trained_weights.npz: trained | driver | driver1000
+    W = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "trained_weights.npz"))
+    v = model.cnf.v_wrapper.v
+    with torch.no_grad():
+        for nm, m in (("eta", v.eta), ("mu", v.mu)):
+            m.fc1.weight.copy_(torch.as_tensor(W[f"{sys.argv[1]}_{nm}_w1"]).reshape(-1, 1))
+            m.fc1.bias.copy_(torch.as_tensor(W[f"{sys.argv[1]}_{nm}_b1"]))
+            m.fc2.weight.copy_(torch.as_tensor(W[f"{sys.argv[1]}_{nm}_w2"]).reshape(1, -1))
 cap = {}
 orig = native.eloc
 def eloc(*a, **k):
@@ -21,13 +29,14 @@ def eloc(*a, **k):
     return r
 native.eloc = eloc
 torch.manual_seed(5)
-for it in range(8):
-    model(B)
+for it in range(12):
+    with torch.no_grad():
+        model(B)
 steps, order, cost = cap["steps"].cpu().numpy(), cap["order"].cpu().numpy(), model.walker_cost.cpu().numpy()
 hs = cap["hs"].cpu().numpy()
 print("wave-level evals/walker (kernel statistic):", cap["stats"][0].item() / B, "rejected/walker", cap["stats"][2].item() / B)
 print("attempted steps per walker: " + " ".join(f"{s}:{(steps == s).sum()}" for s in range(1, 12)))
-light = cost < 12
+light = cost < 16
 so = steps[order]
 lo = light[order]
 w = so[lo][: (lo.sum() // 4) * 4].reshape(-1, 4)
