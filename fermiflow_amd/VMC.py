@@ -167,7 +167,7 @@ class _Sweep:
         self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6" if M <= 12 else "8"))
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
-        # (ff_walker_schedule: more than 20 % of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
+        # (ff_walker_schedule: more than 10 % of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
         # three or more planned steps accepted a step of the plan one shorter -> x 1.02; the step is then rounded down to interval / k:
         # equal steps).  A fixed factor is
         # right for one set of weights only: 0.9 is accepted by 99 % of the walkers on the synthetic weights and rejected by 80 % after

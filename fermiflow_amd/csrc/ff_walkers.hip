@@ -1313,8 +1313,12 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // equal steps): a rejection rate of 10 % is worth about 0.6 evaluations per walker (2 on the four-walkers-per-wave kernel, whose walkers
 // wait for each other), the extra step 6.  On the benchmark's synthetic weights 0.9 is accepted by 99 % of the walkers; after a few
 // hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations per walker where 23 do).  So the
-// scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than 20 %: scale
-// x 0.93; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (Round 5's first thresholds, 4 % and
+// scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than 10 %: scale
+// x 0.93; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (10 %, not the 20 % a walker on its own would
+// tolerate: the four walkers of a matrix-core wave advance in lockstep, a rejection costs its WAVE two more attempts, and at a rate p
+// that is 1 - (1 - p)^4 of the waves -- 34 % at p = 0.10, 59 % at 0.20.  Measured on settled tables, tools/probes/table_settle.py:
+// trained flow 24.4 -> 23.9 evaluations per walker and pass 1.218 -> 1.170 ms, driver-1000 32.5 -> 31.2 and 1.586 -> 1.527 ms,
+// nothing on the driver-300 and synthetic weights; 0.07: 23.8 / 30.6, passes 1.179 / 1.508.)  (Round 5's first thresholds, 4 % and
 // 1 %, traded 6 evaluations of every walker for 7 of one in twenty: 13.9 -> 19.7 evaluations at 6 + 6 particles.)
 // Growth (x 1.02) needs fewer than 5 % rejections AND evidence that a plan one step shorter would pass: of the n3 walkers that were
 // planned for k >= 3 equal steps, ne accepted -- somewhere along the trajectory, where the step-size control of the solver tried it
@@ -1325,11 +1329,14 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // report ne / n3 = 0.00-0.05 at three steps and the table stays.  (Walkers planned for two steps cannot show such a step -- the
 // second one is capped by the rest of the interval -- and have nothing to gain short of a single step; they do not vote.)
 // Error control is untouched: every step passes the same test whatever it opened with.
+#ifndef FF_SHRINK_AT
+#define FF_SHRINK_AT 0.10      // (0.20 until the end of round 5; A/B knob)
+#endif
 FF_D double ff_scale_update(double cur, unsigned n, unsigned nr, unsigned n3, unsigned ne) {
   if (!(cur > 0.0)) cur = 0.6;
   if (n >= 64u) {
     const double f = (double)nr / (double)n;
-    if (f > 0.20) cur *= 0.93;
+    if (f > FF_SHRINK_AT) cur *= 0.93;
     else if (f < 0.05 && n3 >= 16u && (double)ne >= 0.7 * (double)n3) cur *= 1.02;
   }
   return fmin(1.0, fmax(0.25, cur));

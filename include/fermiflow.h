@@ -137,7 +137,7 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * reference's solvers start cold, src/NeuralODE/nnModule.py:59-67): hs_out[b] = hval[b] * scale_out[cost[b]], scale a table of 32 factors
  * by cost class (scale_in; entries <= 0 read as 0.6) that FOLLOWS the passes: given the previous pass of the same batch size --
  * prev_cost (its classes), prev_hs (the steps it opened with, i.e. the previous call's hs_out), prev_he (its ff_ode.walker_h_out) --
- * a class of which more than 20 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor; one with fewer
+ * a class of which more than 10 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor; one with fewer
  * than 5 % gets 1.02 x IF its walkers showed that a plan one step shorter would pass (ABI 107): of those planned for k >= 3 equal steps
  * (at least 16), 70 % accepted a step >= interval / (k - 1) somewhere along the way (prev_he, the largest step the pass accepted;
  * without an interval: every walker votes, with a step >= 1.25 x the one it opened with); within [0.25, 1]; classes with fewer than 64
