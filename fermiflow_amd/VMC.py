@@ -167,13 +167,25 @@ class _Sweep:
         self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6" if M <= 12 else "8"))
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
-        # (ff_walker_schedule: more than 10 % of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
+        # (ff_walker_schedule: more than _h_shrink_at of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
         # three or more planned steps accepted a step of the plan one shorter -> x 1.02; the step is then rounded down to interval / k:
         # equal steps).  A fixed factor is
         # right for one set of weights only: 0.9 is accepted by 99 % of the walkers on the synthetic weights and rejected by 80 % after
         # 300 training iterations -- a whole wasted step each (29 evaluations per walker where 23 do).  Device-resident, no host round
         # trip; FERMIFLOW_ADAPTIVE_H=0 keeps the fixed factors (0.9 for class <= 6, _h_scale_eloc beyond).
         self.adaptive_h = os.environ.get("FERMIFLOW_ADAPTIVE_H", "1") != "0"
+        # The rejection rate from which a class's factor shrinks, by the number G of walkers the local-energy kernel advances in lockstep
+        # (a rejected first step costs the whole wave two more attempts, and at a rate p that is 1 - (1 - p)^G of the waves):
+        # 1 - 0.65^(1/G) within [0.06, 0.25] -- 0.10 at the matrix-core kernel's four (measured on settled tables, tools/probes/
+        # table_settle.py: trained flow 24.4 -> 23.9 evaluations per walker against 0.20, driver-1000 32.5 -> 31.2), 0.25 for the
+        # one-walker-per-workgroup kernels (configs[4]: 0.10 costs 3.4 % more evaluations than 0.20 there).  Kernels by shape: csrc/
+        # ff_cnf_fwd.hip dispatch_fwd (column sweep up to 3 particles: 64 / (n d) walkers per wave; matrix-core kernel 4-6: four; row
+        # layout 7-8: two; one walker per wave beyond, and from 5 particles in d = 3).
+        if dim == 2:
+            G = min(16, 64 // (2 * n)) if n <= 3 else (4 if n <= 6 else (2 if n <= 8 else 1))
+        else:
+            G = max(1, 64 // (3 * n)) if n <= 4 else 1
+        self._h_shrink_at = float(os.environ.get("FERMIFLOW_SHRINK_AT", min(0.25, max(0.06, 1.0 - 0.65 ** (1.0 / G)))))
         self._h_tab = None           # [2, 32] device table (double-buffered), row _h_tab_cur is current
         self._h_tab_cur = 0
         self._h_prev = None          # (cost, hs, he) of the previous local-energy pass
@@ -236,11 +248,12 @@ class _Sweep:
                 # data-parallel: the table follows the statistics of the GLOBAL batch (counted per shard behind the pass, summed in the
                 # estimator's all-reduce: _reduce_with_counts) -- every rank holds the same factors whatever the sharding
                 order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], None, interval=t1 - t0,
-                                                                 counts=self._h_counts)
+                                                                 counts=self._h_counts, shrink_at=self._h_shrink_at)
                 self._h_counts = None
             else:
                 prev = self._h_prev if (self._h_prev is not None and self._h_prev[0].shape[0] == nloc and self._h_prev[0].device == z.device) else None
-                order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], prev, interval=t1 - t0)
+                order, self._h_flow, hs = native.walker_schedule(cost, hg, self._h_tab[cur], self._h_tab[1 - cur], prev, interval=t1 - t0,
+                                                                 shrink_at=self._h_shrink_at)
             self._h_tab_cur = 1 - cur
         elif warm and not per_walker_h:
             order, self._h_flow = native.walker_order(cost, hval=hg)      # the schedule and the mean accepted step from the same launches

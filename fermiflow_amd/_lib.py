@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FERMIFLOW_LIB") or os.path.join(_HERE, "libfermiflow_hip.so")   # env: A/B builds in tools/
 _LIB = None
 
-ABI_VERSION = 108      # ff_version() of the library this binding was written against (include/fermiflow.h)
+ABI_VERSION = 109      # ff_version() of the library this binding was written against (include/fermiflow.h)
 
 SYMBOLS = [
     "ff_version", "ff_last_error", "ff_fermion_states", "ff_slater_logabsdet_fwd", "ff_slater_logabsdet_bwd", "ff_logprob",

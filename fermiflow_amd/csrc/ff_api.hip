@@ -45,7 +45,7 @@ std::vector<Subset> subsets(const double* price, int n, int k, double pmax) {
 }  // namespace
 
 extern "C" {
-int ff_version(void) { return 108; }   // 108: ff_ode gained walker_h_equal; 107: ff_scale_counts takes the interval and fills 128 counts, ff_walker_schedule reads as many (no struct change); 106: ff_ode gained after_main_event; 105: ff_walker_schedule, ff_rng_fill3d (no struct change); 104: ff_ode gained compact_finish; 103: ff_ode gained heavy_class / heavy_tol / sum_weight (102: walker_class / sens_tol / walker_h_scale_loose / sens_tol_class)
+int ff_version(void) { return 109; }   // 109: ff_walker_schedule takes shrink_at (no struct change); 108: ff_ode gained walker_h_equal; 107: ff_scale_counts takes the interval and fills 128 counts, ff_walker_schedule reads as many (no struct change); 106: ff_ode gained after_main_event; 105: ff_walker_schedule, ff_rng_fill3d (no struct change); 104: ff_ode gained compact_finish; 103: ff_ode gained heavy_class / heavy_tol / sum_weight (102: walker_class / sens_tol / walker_h_scale_loose / sens_tol_class)
 const char* ff_last_error(void) { return g_ff_err; }
 
 // Orbitals.fermion_states (src/orbitals.py:33-54), host code, no GPU involved.  See include/fermiflow.h.

@@ -1313,9 +1313,9 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // equal steps): a rejection rate of 10 % is worth about 0.6 evaluations per walker (2 on the four-walkers-per-wave kernel, whose walkers
 // wait for each other), the extra step 6.  On the benchmark's synthetic weights 0.9 is accepted by 99 % of the walkers; after a few
 // hundred training iterations 80 % of them reject it (tools/probes/policy_sweep.py: 29 evaluations per walker where 23 do).  So the
-// scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than 10 %: scale
-// x 0.93; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (10 %, not the 20 % a walker on its own would
-// tolerate: the four walkers of a matrix-core wave advance in lockstep, a rejection costs its WAVE two more attempts, and at a rate p
+// scale follows the pass: of the n walkers of the class in the previous pass nr rejected their first step -- more than shrink_at: scale
+// x 0.93; within [0.25, 1]; classes with fewer than 64 walkers keep theirs.  (shrink_at is the caller's, by how many walkers the
+// local-energy kernel advances in lockstep; 10 % at four, not the 20 % a walker on its own would tolerate: the four walkers of a matrix-core wave advance in lockstep, a rejection costs its WAVE two more attempts, and at a rate p
 // that is 1 - (1 - p)^4 of the waves -- 34 % at p = 0.10, 59 % at 0.20.  Measured on settled tables, tools/probes/table_settle.py:
 // trained flow 24.4 -> 23.9 evaluations per walker and pass 1.218 -> 1.170 ms, driver-1000 32.5 -> 31.2 and 1.586 -> 1.527 ms,
 // nothing on the driver-300 and synthetic weights; 0.07: 23.8 / 30.6, passes 1.179 / 1.508.)  (Round 5's first thresholds, 4 % and
@@ -1329,15 +1329,12 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // report ne / n3 = 0.00-0.05 at three steps and the table stays.  (Walkers planned for two steps cannot show such a step -- the
 // second one is capped by the rest of the interval -- and have nothing to gain short of a single step; they do not vote.)
 // Error control is untouched: every step passes the same test whatever it opened with.
-#ifndef FF_SHRINK_AT
-#define FF_SHRINK_AT 0.10      // (0.20 until the end of round 5; A/B knob)
-#endif
-FF_D double ff_scale_update(double cur, unsigned n, unsigned nr, unsigned n3, unsigned ne) {
+FF_D double ff_scale_update(double cur, unsigned n, unsigned nr, unsigned n3, unsigned ne, double shrink_at) {
   if (!(cur > 0.0)) cur = 0.6;
   if (n >= 64u) {
     const double f = (double)nr / (double)n;
-    if (f > FF_SHRINK_AT) cur *= 0.93;
-    else if (f < 0.05 && n3 >= 16u && (double)ne >= 0.7 * (double)n3) cur *= 1.02;
+    if (f > shrink_at) cur *= 0.93;
+    else if (f < 0.5 * shrink_at && n3 >= 16u && (double)ne >= 0.7 * (double)n3) cur *= 1.02;
   }
   return fmin(1.0, fmax(0.25, cur));
 }
@@ -1429,7 +1426,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
                                                                         int nseg_prev, const double* __restrict__ tab_in,
                                                                         double* __restrict__ tab_out, const double* __restrict__ hval,
                                                                         double* __restrict__ hs_out, double interval,
-                                                                        const double* __restrict__ counts) {
+                                                                        const double* __restrict__ counts, double shrink_at) {
   FF_SETPRIO();
   __shared__ unsigned cnt[FF_ORD_BINS][FF_ORD_THREADS + 1];
   __shared__ unsigned tot[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS], before[FF_ORD_THREADS / FF_ORD_BINS][FF_ORD_BINS];
@@ -1478,7 +1475,7 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_place_kernel(int64_t 
     } else {
       for (int sl = 0; sl < FF_ORD_THREADS / FF_ORD_BINS; sl++) { n += pn[sl][row]; nr += pr[sl][row]; n3 += p3[sl][row]; ne += pe[sl][row]; }
     }
-    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr, n3, ne);
+    const double v = ff_scale_update(tab_in[FF_ORD_BINS - 1 - row], n, nr, n3, ne, shrink_at);
     s_tab[row] = v;
     if (blockIdx.x == 0 && tab_out) tab_out[FF_ORD_BINS - 1 - row] = v;
   }
@@ -1718,7 +1715,7 @@ size_t ff_walker_order_workspace_bytes(int64_t B) {
 
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
                        const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
-                       const double* prev_counts, double interval, double* hs_out) {
+                       const double* prev_counts, double interval, double* hs_out, double shrink_at) {
   FF_CHECK(B >= 0 && (B == 0 || (cost && order && workspace)), FF_EINVAL, "ff_walker_order: bad argument");
   FF_CHECK((hval == nullptr) == (hmean == nullptr), FF_EINVAL, "ff_walker_order_mean: hval and hmean go together");
   FF_CHECK(B < ((int64_t)1 << 31), FF_EUNSUPPORTED, "ff_walker_order: B >= 2^31");
@@ -1737,13 +1734,13 @@ int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* or
   FF_LAUNCH_CHECK();
   FF_LAUNCH(ff_order_place_kernel, (unsigned)nseg, FF_ORD_THREADS, stream, B, cost, (const unsigned*)workspace, nseg, order,
             (const double*)hsum, hmean, (const unsigned*)pstat, nseg, scale_in, scale_out, hval, scale_in ? hs_out : (double*)nullptr,
-            interval, prev_counts);
+            interval, prev_counts, shrink_at > 0.0 ? (shrink_at < 0.02 ? 0.02 : (shrink_at > 0.5 ? 0.5 : shrink_at)) : 0.10);
   FF_LAUNCH_CHECK();
   return FF_OK;
 }
 
 int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean) {
-  return ff_walker_schedule(stream, B, cost, order, workspace, hval, hmean, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr);
+  return ff_walker_schedule(stream, B, cost, order, workspace, hval, hmean, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0.0);
 }
 
 int ff_walker_order(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace) {

@@ -300,7 +300,7 @@ def walker_order(cost, hval=None):
     return order, hmean
 
 
-def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, counts=None):
+def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, counts=None, shrink_at=0.0):
     """ff_walker_schedule: (order, mean(hval) as a 1-element tensor, hs) with hs[b] = hval[b] * scale_in[cost[b]] -- the step every walker's
     local-energy pass opens with; scale_out receives the table updated from the previous pass prev = (cost, hs, he) (None: copied)."""
     cost = cost.contiguous()
@@ -317,7 +317,8 @@ def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, co
     if counts is not None and not (counts.numel() == SCALE_COUNTS and counts.dtype == torch.float64 and counts.is_contiguous()):
         raise ValueError(f"walker_schedule: counts must be the {SCALE_COUNTS} doubles of scale_counts")
     L.check(L.lib().ff_walker_schedule(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean),
-                                       L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.ptr(counts), L.f64(abs(float(interval))), L.ptr(hs)),
+                                       L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.ptr(counts), L.f64(abs(float(interval))), L.ptr(hs),
+                                       L.f64(shrink_at)),
             "ff_walker_schedule")
     return order, hmean, hs
 

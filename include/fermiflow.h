@@ -108,7 +108,7 @@ typedef struct ff_ode {
   int32_t walker_h_equal;
 } ff_ode;
 
-int ff_version(void);   /* 108; changes whenever a struct of this header changes layout (the Python binding checks it) */
+int ff_version(void);   /* 109; changes whenever a struct of this header changes layout (the Python binding checks it) */
 /* Releases what the library created lazily: the side stream and the two events per device of the routed local-energy pass
  * (created on the first such call on a device, shared by all host threads under a mutex).  Call when no call of this library is
  * in flight; the next routed call creates them again.  Everything else the library touches is caller-owned memory. */
@@ -137,8 +137,11 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * reference's solvers start cold, src/NeuralODE/nnModule.py:59-67): hs_out[b] = hval[b] * scale_out[cost[b]], scale a table of 32 factors
  * by cost class (scale_in; entries <= 0 read as 0.6) that FOLLOWS the passes: given the previous pass of the same batch size --
  * prev_cost (its classes), prev_hs (the steps it opened with, i.e. the previous call's hs_out), prev_he (its ff_ode.walker_h_out) --
- * a class of which more than 10 % of the walkers rejected their first step (prev_he < prev_hs) gets 0.93 x its factor; one with fewer
- * than 5 % gets 1.02 x IF its walkers showed that a plan one step shorter would pass (ABI 107): of those planned for k >= 3 equal steps
+ * a class of which more than shrink_at (0: 0.10; clamped to [0.02, 0.5]) of the walkers rejected their first step (prev_he < prev_hs) gets
+ * 0.93 x its factor -- the caller's choice by how many walkers its local-energy kernel advances in lockstep: a rejection costs the whole
+ * wave two more attempts, so the package passes 1 - 0.65^(1/G) within [0.06, 0.25] for G walkers per wave (0.10 at four, 0.25 for the
+ * one-walker-per-workgroup kernels; ABI 109) --; one with fewer
+ * than half of that gets 1.02 x IF its walkers showed that a plan one step shorter would pass (ABI 107): of those planned for k >= 3 equal steps
  * (at least 16), 70 % accepted a step >= interval / (k - 1) somewhere along the way (prev_he, the largest step the pass accepted;
  * without an interval: every walker votes, with a step >= 1.25 x the one it opened with); within [0.25, 1]; classes with fewer than 64
  * walkers keep theirs.  The updated table -- the one this call applies -- goes to
@@ -150,7 +153,7 @@ int ff_walker_order_mean(void* stream, int64_t B, const int32_t* cost, int32_t* 
  * as ff_ode.walker_h_init with walker_h_scale = walker_h_scale_loose = 1.  The error test of every step is untouched. */
 int ff_walker_schedule(void* stream, int64_t B, const int32_t* cost, int32_t* order, void* workspace, const double* hval, double* hmean,
                        const double* scale_in, double* scale_out, const int32_t* prev_cost, const double* prev_hs, const double* prev_he,
-                       const double* prev_counts, double interval, double* hs_out);
+                       const double* prev_counts, double interval, double* hs_out, double shrink_at);
 /* counts128[c] += walkers of cost class c that opened a local-energy pass with a step (hs > 0) and finished it (he > 0), counts128[32 + c]
  * += those whose first step was rejected (he < hs), counts128[64 + c] += those planned for three or more equal steps of `interval`,
  * counts128[96 + c] += those of them that accepted a step of the plan one shorter (ff_walker_schedule's growth condition; interval as

@@ -196,7 +196,7 @@ def walker_order(cost, hval=None):
     return order, hm[0]
 
 
-def walker_schedule(cost, hval, scale_in, prev=None, interval=0.0, counts=None):
+def walker_schedule(cost, hval, scale_in, prev=None, interval=0.0, counts=None, shrink_at=0.0):
     """ff_walker_schedule -> (order, mean(hval), hs, updated scale table)"""
     cost = _i(cost); hval = _d(hval); scale_in = _d(scale_in)
     order = np.empty_like(cost); hm = np.empty(1); hs = np.empty_like(hval); scale_out = np.full(32, np.nan)
@@ -204,7 +204,7 @@ def walker_schedule(cost, hval, scale_in, prev=None, interval=0.0, counts=None):
     ws = np.zeros((lib().ff_walker_order_workspace_bytes(C.c_int64(len(cost))) + 7) // 8)
     pc, ph, pe = (None, None, None) if prev is None else (_i(prev[0]), _d(prev[1]), _d(prev[2]))
     _ck(lib().ff_walker_schedule(None, C.c_int64(len(cost)), _p(cost), _p(order), _p(ws), _p(hval), _p(hm), _p(scale_in), _p(scale_out),
-                                 _p(pc), _p(ph), _p(pe), _p(_d(counts)) if counts is not None else None, C.c_double(interval), _p(hs)))
+                                 _p(pc), _p(ph), _p(pe), _p(_d(counts)) if counts is not None else None, C.c_double(interval), _p(hs), C.c_double(shrink_at)))
     return order, hm[0], hs, scale_out
 
 

@@ -851,7 +851,7 @@ def test_one_launch_estimator_and_schedule_with_mean():
         # with < 5 % grow by 1.02 if 70 % of their voters (without an interval: every walker) accepted a step of the plan one shorter
         # (without an interval: 1.25 x the opening step); within [0.25, 1]; classes with fewer than 64 walkers and walkers without a
         # step keep theirs
-        def rule(tab, cls, hs, he, interval):
+        def rule(tab, cls, hs, he, interval, shrink_at=0.10):
             want = tab.copy()
             ok = (he > 0) & (hs > 0)
             if interval > 0:
@@ -864,7 +864,7 @@ def test_one_launch_estimator_and_schedule_with_mean():
                 m = cls == c
                 n_c, r_c, v_c, y_c = int((m & ok).sum()), int((m & ok & (he < 0.999 * hs)).sum()), int((m & vote).sum()), int((m & yes).sum())
                 if n_c >= 64:
-                    f = 0.93 if r_c / n_c > 0.10 else (1.02 if (r_c / n_c < 0.05 and v_c >= 16 and y_c >= 0.7 * v_c) else 1.0)
+                    f = 0.93 if r_c / n_c > shrink_at else (1.02 if (r_c / n_c < 0.5 * shrink_at and v_c >= 16 and y_c >= 0.7 * v_c) else 1.0)
                     want[c] = min(1.0, max(0.25, tab[c] * f))
             return want
         tab = np.where(np.arange(32) <= 6, 0.9, 0.6)
@@ -906,6 +906,9 @@ def test_one_launch_estimator_and_schedule_with_mean():
         _, _, hs4, tab4 = S.walker_schedule(cost, h, tab, prev=(cost, hs3, he3), interval=1.0)
         want4 = rule(tab, cls, hs3, he3, 1.0)
         np.testing.assert_allclose(tab4, want4, rtol=1e-15)
+        # the caller's threshold (ff_walker_schedule's shrink_at; 0 = 0.10): 0.25, as for kernels that integrate one walker per wave
+        _, _, _, tab5 = S.walker_schedule(cost, h, tab1, prev=(cost, hs, he), shrink_at=0.25)
+        np.testing.assert_allclose(tab5, rule(tab, cls, hs, he, 0.0, 0.25), rtol=1e-15)
         cnts3 = S.scale_counts(cost, hs3, he3, interval=1.0)
         assert cnts3[64:96].sum() == ((k3 >= 3) & (hs3 > 0)).sum()
         _, _, hs4c, tab4c = S.walker_schedule(cost, h, tab, counts=cnts3, interval=1.0)
