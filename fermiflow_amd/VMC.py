@@ -126,6 +126,7 @@ def _add_generic_potentials(r, x, extra):
 # (ff_ode.after_main_event), so that it runs under the small reduction kernels with the SIMDs to itself; "adj" -- in front of the adjoint
 # call (rounds 2-4: beside the adjoint kernel, while the two still fitted one SIMD together); "est" -- in front of the estimator kernel.
 _PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "kernel")
+_ADJOINT_SCALE = float(os.environ.get("FERMIFLOW_ADJOINT_SCALE", "1.1"))      # x the flow pass's largest accepted step (probes)
 _ADJOINT_OPEN = os.environ.get("FERMIFLOW_ADJOINT_OPEN", "flow")      # "eloc": the adjoint opens with 1.25 x the local-energy pass's step (rounds 2-4)
 
 
@@ -301,7 +302,7 @@ class _Sweep:
             return {}
         if hg is None or _ADJOINT_OPEN == "eloc":
             return dict(walker_h_init=he, walker_h_scale=1.25)
-        return dict(walker_h_init=hg, walker_h_scale=1.1, walker_h_equal=True)
+        return dict(walker_h_init=hg, walker_h_scale=_ADJOINT_SCALE, walker_h_equal=True)
 
     def _reduce_with_counts(self, buf):
         """all-reduce of the estimator's sums with the first-step statistics of this pass riding along (one collective, not two)"""

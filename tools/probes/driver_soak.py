@@ -25,5 +25,5 @@ for it in range(1, N + 1):
         se, sa = m.profile["eloc_stats"][0], m.profile["adjoint_stats"][0]
         ok = all(torch.isfinite(p).all().item() for p in m.parameters())
         print(f"it {it:5d}: {dt:.3f} ms/iteration  E {m.E:.4f} +- {m.E_std / B ** 0.5:.4f}  eloc evals {se[0].item() / B:.2f} (failed {int(se[3])})  "
-              f"adjoint evals {sa[0].item() / B:.2f} (failed {int(sa[3])})  parameters finite {ok}  max|w1| {max(v.eta.fc1.weight.abs().max().item(), v.mu.fc1.weight.abs().max().item()):.2f}", flush=True)
+              f"adjoint evals {sa[0].item() / B:.2f} (rejected/walker {sa[2].item() / B:.3f}, failed {int(sa[3])})  parameters finite {ok}  max|w1| {max(v.eta.fc1.weight.abs().max().item(), v.mu.fc1.weight.abs().max().item()):.2f}", flush=True)
         t0 = time.perf_counter()
