@@ -1329,12 +1329,15 @@ FF_D int ff_ord_row(int c) { return FF_ORD_BINS - 1 - (c < 0 ? 0 : (c > FF_ORD_B
 // report ne / n3 = 0.00-0.05 at three steps and the table stays.  (Walkers planned for two steps cannot show such a step -- the
 // second one is capped by the rest of the interval -- and have nothing to gain short of a single step; they do not vote.)
 // Error control is untouched: every step passes the same test whatever it opened with.
+#ifndef FF_GROW_EVIDENCE
+#define FF_GROW_EVIDENCE 0.7      // (A/B knob)
+#endif
 FF_D double ff_scale_update(double cur, unsigned n, unsigned nr, unsigned n3, unsigned ne, double shrink_at) {
   if (!(cur > 0.0)) cur = 0.6;
   if (n >= 64u) {
     const double f = (double)nr / (double)n;
     if (f > shrink_at) cur *= 0.93;
-    else if (f < 0.5 * shrink_at && n3 >= 16u && (double)ne >= 0.7 * (double)n3) cur *= 1.02;
+    else if (f < 0.5 * shrink_at && n3 >= 16u && (double)ne >= FF_GROW_EVIDENCE * (double)n3) cur *= 1.02;
   }
   return fmin(1.0, fmax(0.25, cur));
 }
