@@ -289,6 +289,14 @@ def main():
     w_head = (tuple(t.detach().cpu().numpy().copy() for t in (_v.eta.fc1.weight, _v.eta.fc1.bias, _v.eta.fc2.weight)),
               tuple(t.detach().cpu().numpy().copy() for t in (_v.mu.fc1.weight, _v.mu.fc1.bias, _v.mu.fc2.weight)))
     beta_head = (model.F, model.F_std, model.S) if wl == "beta" else None
+    same = None
+    if rank == 0 and n_gpus == 1 and not args.no_extras and args.cpu_walkers > 0 and wl in ("gsvmc", "n12"):
+        # One untimed sweep on EXACTLY these weights (no Adam step behind it): its first walkers and their local energies are what the
+        # CPU baseline's oracle is given further down, so that E / E_std of both are estimates over the same sample
+        with torch.no_grad():
+            model(B_glob)
+        ns = args.cpu_walkers if wl == "gsvmc" else max(256, args.cpu_walkers // 8)
+        same = (model.x[:ns].cpu().numpy().copy(), model.Eloc[:ns].cpu().numpy().copy())
     model.profile = {}
     fence()
     t0s = time.perf_counter()
@@ -314,7 +322,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtl = tt.item()
         pl, model.profile = model.profile, None
-        long_leg = {"steps": kl, "ms_per_step": dtl / kl * 1e3, "value": B_glob * 100 * kl / dtl,
+        long_leg = {"steps": kl, "ms_per_step": dtl / kl * 1e3, "value": B_glob * 100 * kl / dtl, "E": model.E, "E_std": model.E_std,
                     "rhs_evals_per_walker": sum(int(st_[0].item()) for st_ in pl["eloc_stats"]) / kl / wpg,
                     "eloc_pass_ms": sum(a.elapsed_time(b) for a, b in pl["pass1"]) / kl,
                     "note": "the headline loop continued for 200 more steps (behind the stage-marker loop), same lr, same instrumentation; the synthetic "
@@ -360,6 +368,27 @@ def main():
                    "bar": 1e-5}
         for _ in range(2):
             step()      # (the warm-start state of the headline policy again, before the next leg)
+
+    # ---- configs[3] / configs[4]: the tolerance policy's largest E_loc error against a 1e-11 solve on this line too
+    #      (fp64 sensitivity matrices for the reference solve whatever --sens-bits the sweep runs at), two fresh batches
+    policy_err = None
+    if wl in ("n12", "c5") and not args.no_extras and world == 1:
+        nsub = min(wpg, 32768 if wl == "n12" else 16384)
+        errs = []
+        for sd in (31, 32):
+            torch.manual_seed(sd)
+            with torch.no_grad():
+                zr = model.basedist.sample(model.orbitals_up, model.orbitals_down, (nsub,))
+            model.forward_from(zr, batch=nsub)
+            x_, e_ = model.x, model.Eloc.clone()
+            tu_, td_ = model._tables(dev)
+            native.set_sens_precision(64)
+            tight = native.eloc(tu_, td_, nup, ndown, model.cnf.v_wrapper.v.net(), x_, 0.0, 1.0, 1e-11, 1e-13, args.Z, True)["eloc"]
+            native.set_sens_precision(sens_bits)
+            errs.append(((e_ - tight).abs() / tight.abs()).max().item())
+        policy_err = {"headline_policy_eloc_max_rel_err": max(errs), "headline_policy_eloc_max_rel_err_by_batch": errs, "walkers": nsub, "bar": 1e-5}
+        for _ in range(2):
+            step()
 
     # ---- second leg: the same measurement on a flow that has been trained for a while (the headline's weights are held in
     #      place by the tiny learning rate: its ODE step counts are the best case)
@@ -516,6 +545,24 @@ def main():
            "roofline": roofline}
     if long_leg is not None:
         out["long_window_leg"] = long_leg
+        # the same loop over a 200-step window, next to `value` (the K-step headline is a ~30 ms window on weights that
+        # have not moved yet; this is the rate the loop settles at)
+        out["value_200"] = long_leg["value"]
+        out["ms_per_step_200"] = long_leg["ms_per_step"]
+    # E_std is the standard deviation of an estimator with a log-divergent variance (1/r tails: one near-coalescence walker can double
+    # it): the legs' values side by side, their median and their maximum, instead of one unstable number
+    std_legs = {"headline": Estd_head}
+    if long_leg is not None:
+        std_legs["long_window"] = long_leg["E_std"]
+    if trained is not None:
+        std_legs["trained"] = trained["E_std"]
+    if driver is not None:
+        for k_ in ("iter_100", "iter_300"):
+            std_legs["driver_" + k_] = driver[k_]["E_std"]
+    vals_ = sorted(v_ for v_ in std_legs.values() if v_ == v_)
+    if vals_:
+        out["E_std_legs"] = {"median": vals_[len(vals_) // 2] if len(vals_) % 2 else 0.5 * (vals_[len(vals_) // 2 - 1] + vals_[len(vals_) // 2]),
+                             "max": vals_[-1], "by_leg": std_legs}
     if trained is not None:
         out["trained_leg"] = trained
     if driver is not None:
@@ -547,6 +594,8 @@ def main():
         out["comm"] = comm
     if ref_leg is not None:
         out["reference_semantics_leg"] = ref_leg
+    if policy_err is not None:
+        out["policy_error"] = policy_err
     if wl == "beta":
         out.update(F=beta_head[0], F_std=beta_head[1], S=beta_head[2])
 
@@ -688,6 +737,18 @@ def main():
                                    "sample": f"one full iteration (same stages, minus Adam) of {ncpu} walkers, "
                                              f"oracle/ff_oracle.c with OpenMP, {ct:.1f} s", "E": rr["E"], "E_std": rr["E_std"],
                                    "stage_seconds": rr["seconds"]}
+            if same is not None:
+                # the variance half of BASELINE.json's metric, like for like: the GPU sweep's first walkers x (headline weights) and their
+                # E_loc, against the oracle's E_loc of the SAME x at the same tolerances (src/VMC.py:57: mean and unbiased std)
+                import numpy as np
+                xs, es = same
+                t2 = time.perf_counter()
+                eo = O.eloc(xs, nup, ndown, onet, args.Z, rtol=1e-6, atol=1e-8)["eloc"]
+                out["cpu_baseline"]["same_walkers"] = {
+                    "n": int(xs.shape[0]), "what": "the first walkers of one GPU sweep on the headline's weights; the oracle's local energies of the same x "
+                                                   "(rtol 1e-6, atol 1e-8, scipy-RK45 restatement)",
+                    "E_gpu": float(es.mean()), "E_std_gpu": float(es.std(ddof=1)), "E_cpu": float(eo.mean()), "E_std_cpu": float(eo.std(ddof=1)),
+                    "max_rel_eloc_diff": float(np.max(np.abs(es - eo) / np.abs(eo))), "oracle_seconds": time.perf_counter() - t2}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

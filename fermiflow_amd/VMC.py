@@ -59,8 +59,12 @@ class _SweepScalar(torch.Tensor):
             return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
         params, flat = fast
         # The short cut never runs the autograd graph, so tensor hooks on the parameters (register_hook,
-        # register_post_accumulate_grad_hook: DDP / FSDP reducers, hook-based clipping) would not fire: with any hook present take the
-        # ordinary path.  Note that on the short cut the parameters' .grad are VIEWS of one flat buffer.
+        # register_post_accumulate_grad_hook: FSDP reducers, hook-based clipping) would not fire: with any such hook present take the
+        # ordinary path.  torch's DistributedDataParallel is NOT detectable this way -- its reducer hangs on the C++ AccumulateGrad node,
+        # which neither attribute shows -- and it is not the supported data-parallel mode: the sweeps all-reduce the estimator
+        # and the parameter gradient themselves (fermiflow_amd/dist.py), so every rank's .grad is already the global one.  A model that is
+        # wrapped in DDP anyway sets `model.fast_backward = False` (the sweep then returns a scalar without the short cut).
+        # Note that on the short cut the parameters' .grad are VIEWS of one flat buffer.
         if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
             return super().backward(gradient, retain_graph, create_graph, inputs=inputs)
         off = 0
@@ -75,9 +79,10 @@ class _SweepScalar(torch.Tensor):
                     p.grad.add_(view)
 
 
-def _sweep_scalar(value, flat, params):
+def _sweep_scalar(value, flat, params, fast=True):
     out = _ScalarWithParamGrads.apply(value, flat, *params).as_subclass(_SweepScalar)
-    out._ff_fast = (list(params), flat)
+    if fast:
+        out._ff_fast = (list(params), flat)
     return out
 
 
@@ -138,6 +143,7 @@ class _Sweep:
         # None, or a dict that receives per-stage torch.cuda.Event pairs + ODE stats.  {"stages": False}: only the event pair around the
         # local-energy pass and its statistics -- every stage marker is a hipEventRecord, ~8 us of pipeline bubble on this GPU
         self.profile = None
+        self.fast_backward = True    # _SweepScalar: `gradE.backward()` hands the gradient views to .grad without running the graph
         # ODE step-size warm start inside the sweep; FERMIFLOW_WARM_START=0 restores the cold start
         self.warm_start = os.environ.get("FERMIFLOW_WARM_START", "1") != "0"
         self._h_flow = None          # previous sweep's accepted flow steps: per walker (persistent walkers) or their mean
@@ -243,7 +249,11 @@ class _Sweep:
             if self._h_tab is None or self._h_tab.device != z.device:
                 tab = torch.full((2, 32), float(self._h_scale_eloc), dtype=torch.float64, device=z.device)
                 tab[:, :9] = self._h_scale_loose          # classes <= 8 open with 0.9 x the flow's step; the table takes it from there
-                self._h_tab, self._h_tab_cur, self._h_prev = tab, 0, None
+                # (a table rebuilt for another device starts cold: the statistics of the old one do not update it)
+                self._h_tab, self._h_tab_cur, self._h_prev, self._h_counts = tab, 0, None, None
+            if self._h_counts is not None and self._h_counts.device != z.device:
+                # a checkpoint loaded with map_location='cpu' (or rank 0's on another rank): the counts are a 64-word host-side sum, move them
+                self._h_counts = self._h_counts.to(z.device)
             cur = self._h_tab_cur
             if D._active():
                 # data-parallel: the table follows the statistics of the GLOBAL batch (counted per shard behind the pass, summed in the
@@ -612,7 +622,7 @@ class GSVMC(_Sweep, torch.nn.Module):
         if prof is not None:
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
-        return _sweep_scalar(est[2], gp, params)
+        return _sweep_scalar(est[2], gp, params, self.fast_backward)
 
 
 class BetaVMC(_Sweep, torch.nn.Module):
@@ -779,6 +789,6 @@ class BetaVMC(_Sweep, torch.nn.Module):
             prof.setdefault("events", []).append(ev)
         self.Eloc, self.x = Eloc, x
         pdev = self.log_state_weights.device
-        gradF_phi = _sweep_scalar(est[6].to(pdev), g_phi.to(pdev), [self.log_state_weights])
-        gradF_theta = _sweep_scalar(est[7], gp, params)
+        gradF_phi = _sweep_scalar(est[6].to(pdev), g_phi.to(pdev), [self.log_state_weights], self.fast_backward)
+        gradF_theta = _sweep_scalar(est[7], gp, params, self.fast_backward)
         return gradF_phi, gradF_theta

@@ -756,7 +756,6 @@ extern void ff_set_error(const char* msg);
 #define FF_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ff_set_error(hipGetErrorString(e_)); return FF_ELAUNCH; } } while (0)
 
 #include <stdlib.h>
-static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
 
 static int adj_G(int n, int d) { int M = n * d; return M > 0 && M <= FF_WAVE ? (FF_WAVE / M > 16 ? 16 : FF_WAVE / M) : 0; }   // = ff_geom<N,D>::G
 // Persistent grid: one wave per SIMD.  Every walker takes the same few steps here, so a static split is balanced, and
@@ -775,7 +774,7 @@ static int64_t adj_default_blocks() {
 
 static unsigned adj_grid(int64_t B, int G) {
   int64_t ngroups = (B + G - 1) / G;
-  const int64_t cap = ff_persist_blocks(adj_default_blocks());
+  const int64_t cap = adj_default_blocks();
   return (unsigned)(ngroups < cap ? ngroups : cap);
 }
 

@@ -1288,20 +1288,18 @@ extern int ff_slater_rows_launch(void* stream, int d, int64_t B, int nup, int nd
 #include <string.h>
 #include <mutex>
 #include <vector>
-// persistent single-wave workgroups; FF_PERSIST_BLOCKS env overrides (tuning experiments)
-static int64_t ff_persist_blocks(int64_t dflt) { const char* e = getenv("FF_PERSIST_BLOCKS"); return e ? atoll(e) : dflt; }
+static constexpr int64_t FF_GRID_CAP = 1 << 20;      // without a work queue: one workgroup per walker group, up to this many
 
 // With a radial table: the table kernel, then the direct-evaluation kernel as its (normally idle) fallback -- it returns
 // in its first instructions unless the table kernel left this launch's id in the event slot.  Without: direct only.
-// persistent grid of the queue mode: one wave per SIMD (FF_QUEUE_BLOCKS overrides, tuning)
+// persistent grid of the queue mode: one wave per SIMD
 static int64_t fwd_queue_blocks() {
   static int64_t n = 0;
   if (n == 0) {
-    const char* e = getenv("FF_QUEUE_BLOCKS");
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    n = e ? atoll(e) : 4 * (int64_t)cus;
+    n = 4 * (int64_t)cus;
   }
   return n;
 }
@@ -1426,7 +1424,7 @@ template <int N, int D, int MODE>
 static int launch_fwd(void* stream, const ff_fwd_args& a) {
   constexpr int G = ff_geom<N, D>::G;
   int64_t ngroups = (a.B + G - 1) / G;
-  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);   // without a queue: one workgroup per walker group
+  const int64_t cap = a.queue ? fwd_queue_blocks() : FF_GRID_CAP;   // without a queue: one workgroup per walker group
   unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   auto table = [&](void* st, const ff_fwd_args& aa) { FF_LAUNCH((ff_ode_fwd_kernel<N, D, MODE, true>), grid, FF_WAVE, st, aa); };
   int routed = FF_ROUTE_NONE;
@@ -1446,7 +1444,7 @@ template <int N, int D>
 static void launch_split(void* stream, const ff_fwd_args& a) {
   constexpr int G = FF_WAVE / (2 * N * D);
   int64_t ngroups = (a.B + G - 1) / G;
-  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const int64_t cap = a.queue ? fwd_queue_blocks() : FF_GRID_CAP;
   const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   if (a.evt) FF_LAUNCH((ff_eloc_split_kernel<N, D, true>), grid, FF_WAVE, stream, a);
   FF_LAUNCH((ff_eloc_split_kernel<N, D, false>), grid, FF_WAVE, stream, a);
@@ -1458,7 +1456,7 @@ template <int N, int D, int SPLIT>
 static void launch_rows(void* stream, const ff_fwd_args& a) {
   constexpr int G = FF_WAVE / (N * D * SPLIT) > 16 ? 16 : FF_WAVE / (N * D * SPLIT);
   int64_t ngroups = (a.B + G - 1) / G;
-  const int64_t cap = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const int64_t cap = a.queue ? fwd_queue_blocks() : FF_GRID_CAP;
   const unsigned grid = (unsigned)(ngroups < cap ? ngroups : cap);
   if (a.evt) FF_LAUNCH((ff_eloc_rows_kernel<N, D, SPLIT, true>), grid, FF_WAVE, stream, a);
   FF_LAUNCH((ff_eloc_rows_kernel<N, D, SPLIT, false>), grid, FF_WAVE, stream, a);
@@ -1471,7 +1469,7 @@ static void launch_rows(void* stream, const ff_fwd_args& a) {
 template <int N, int D>
 static int launch_mfma(void* stream, const ff_fwd_args& a) {
   const int64_t ngroups = (a.B + 3) / 4;
-  const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const int64_t cap = a.queue ? FF_MFMA_WPS * fwd_queue_blocks() : FF_GRID_CAP;
   auto table = [&](void* st, const ff_fwd_args& aa) {
     FF_LAUNCH((ff_eloc_mfma_kernel<N, D, true, FF_MFMA_WPS>), (unsigned)(ngroups < cap ? ngroups : cap), FF_WAVE, st, aa);
   };
@@ -1481,7 +1479,7 @@ static int launch_mfma(void* stream, const ff_fwd_args& a) {
   t_eloc_fb.fused = (a.fin.on & 1) && N % 2 == 0 && D == 2;      // (what the kernel's epilogue tests)
   t_eloc_fb.routed = routed == FF_ROUTE_DONE;
   t_eloc_fb.evt = a.evt; t_eloc_fb.evt_id = a.evt_id;
-  const int64_t cap1 = a.queue ? fwd_queue_blocks() : ff_persist_blocks(1 << 20);
+  const int64_t cap1 = a.queue ? fwd_queue_blocks() : FF_GRID_CAP;
   FF_LAUNCH((ff_eloc_mfma_kernel<N, D, false, 1>), (unsigned)(ngroups < cap1 ? ngroups : cap1), FF_WAVE, stream, a);
   return FF_OK;
 }
@@ -1513,11 +1511,11 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     return !e ? 0 : (!strcmp(e, "mfma") ? 1 : (!strcmp(e, "rows") ? 2 : (!strcmp(e, "columns") ? 3 : (!strcmp(e, "wide") ? 4 : 0))));
   }();
   // one walker per workgroup, both products on v_mfma_f64_16x16x4 (ff_wide.hip): measured faster than the row layout from
-  // FF_WIDE_ELOC_FROM particles on (tools/probes/wide_c5.py; 16 384 walkers: 11 particles 2.12 against 2.68 ms, 12 particles 2.25 against 2.91; 10 particles 2.04 against 1.88)
-  static const int wide_from = [] { const char* e = getenv("FF_WIDE_ELOC_FROM"); return e ? atoi(e) : 11; }();
+  // 11 particles on (tools/probes/wide_c5.py; 16 384 walkers: 11 particles 2.12 against 2.68 ms, 12 particles 2.25 against 2.91; 10 particles 2.04 against 1.88)
+  constexpr int wide_from = 11;
   if (MODE == 2 && d == 2 && (eloc_kind == 4 || (eloc_kind == 0 && n >= wide_from)) && ff_wide_supported(n, d))
     return wide();
-  static const int mfma_from = [] { const char* e = getenv("FF_MFMA_ELOC_FROM"); return e ? atoi(e) : 4; }();
+  constexpr int mfma_from = 4;      // (2-3 particles tie with the column sweep and keep it: DESIGN.md 3g)
   if (MODE == 2 && (eloc_kind == 1 || (eloc_kind == 0 && d == 2 && n >= mfma_from && n <= 6))) {
 #define FF_MF(N_, D_) if (n == N_ && d == D_) { const int s_ = launch_mfma<N_, D_>(stream, a); if (s_) return s_; FF_LAUNCH_CHECK(); return FF_OK; }
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)
@@ -1531,7 +1529,7 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
     FF_RW(2, 3, 1) FF_RW(3, 3, 1) FF_RW(4, 3, 1)      // three dimensions (small systems; finish: ff_eloc_finish3d)
 #undef FF_RW
   }
-  if (MODE == 2 && d == 2 && !getenv("FF_NO_SPLIT")) {
+  if (MODE == 2 && d == 2) {
 #define FF_SP(N_) if (n == N_) { launch_split<N_, 2>(stream, a); FF_LAUNCH_CHECK(); return FF_OK; }
     FF_SP(8) FF_SP(10) FF_SP(12)
 #undef FF_SP
@@ -1652,11 +1650,8 @@ static int eloc_sensitivities_impl(void* stream, int64_t B, int n, int d, const 
   a.heavy_tol = ode->heavy_tol > 0.0 ? ode->heavy_tol : FF_HEAVY_TOL_DEFAULT;
   a.sum_w = ode->sum_weight > 0.0 ? ode->sum_weight : FF_SUM_WEIGHT_DEFAULT;
   if (fin) a.fin = *fin;
-  static const bool use_queue = getenv("FF_NO_QUEUE") == nullptr;
-  if (use_queue) {
-    FF_LAUNCH(ff_queue_reset_kernel, 1, FF_WAVE, stream, w.queue);      // (a kernel of our own, not hipMemsetAsync: 1 us instead of a 5 us blit + 8 us of bubble)
-    a.queue = w.queue;
-  }
+  FF_LAUNCH(ff_queue_reset_kernel, 1, FF_WAVE, stream, w.queue);      // (a kernel of our own, not hipMemsetAsync: 1 us instead of a 5 us blit + 8 us of bubble)
+  a.queue = w.queue;
   return dispatch_fwd<2>(stream, n, d, a);
 }
 

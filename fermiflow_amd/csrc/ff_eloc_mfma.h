@@ -159,6 +159,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 
 #ifdef FF_STAMPS
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#ifdef FF_STAMPS_TRACE
+  unsigned long long stage_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stage_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #endif
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
     if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
@@ -433,6 +436,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       FF_STAMP(4);
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ consume (Dormand-Prince bookkeeping)
+#if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
+      const int s_prev = s;
+#endif
       if (s == -2) {
         ctl_t C; C.get(s_ctl[w]);
         __syncthreads();
@@ -542,6 +548,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         if (!any) break;
         s = (any & 2) ? 0 : 1;
       }
+#if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)      // consume ticks by stage (the price list of a per-walker stage index: DESIGN.md 3o)
+      { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stage_acc[s_prev + 2] += t_ - stamp_prev; stage_cnt[s_prev + 2]++; }
+#endif
       FF_STAMP(6);
       FF_SCHED_FENCE();
     }
@@ -793,6 +802,13 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   FF_STAMP(7);
   if (A.stats && lane == 0)
     for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
+#ifdef FF_STAMPS_TRACE
+  if (A.stats && lane == 0)
+    for (int q = 0; q < 9; q++) {
+      atomicAdd((unsigned long long*)(A.stats + 65600) + q, stage_acc[q]);
+      atomicAdd((unsigned long long*)(A.stats + 65600) + 9 + q, stage_cnt[q]);
+    }
+#endif
 #endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
   __syncthreads();

@@ -314,8 +314,9 @@ def walker_schedule(cost, hval, scale_in, scale_out, prev=None, interval=0.0, co
     pc, ph, pe = prev if prev is not None else (None, None, None)
     if prev is not None and not (pc.numel() == ph.numel() == pe.numel() == cost.numel()):
         raise ValueError("walker_schedule: the previous pass must have this call's batch size")
-    if counts is not None and not (counts.numel() == SCALE_COUNTS and counts.dtype == torch.float64 and counts.is_contiguous()):
-        raise ValueError(f"walker_schedule: counts must be the {SCALE_COUNTS} doubles of scale_counts")
+    if counts is not None and not (counts.numel() == SCALE_COUNTS and counts.dtype == torch.float64 and counts.is_contiguous()
+                                   and counts.is_cuda and counts.device == cost.device):
+        raise ValueError(f"walker_schedule: counts must be the {SCALE_COUNTS} doubles of scale_counts, contiguous, on the walkers' device")
     L.check(L.lib().ff_walker_schedule(L.stream(), L.i64(cost.numel()), L.ptr(cost), L.ptr(order), L.ptr(ws), L.ptr(hval), L.ptr(hmean),
                                        L.ptr(scale_in), L.ptr(scale_out), L.ptr(pc), L.ptr(ph), L.ptr(pe), L.ptr(counts), L.f64(abs(float(interval))), L.ptr(hs),
                                        L.f64(shrink_at)),

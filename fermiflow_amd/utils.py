@@ -46,7 +46,18 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: lr >= 0, eps >= 0, weight_decay >= 0, betas in [0, 1)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    @staticmethod
+    def _refuse_unsupported(groups, states=()):
+        for group in groups:
+            for key in ("amsgrad", "maximize", "capturable", "differentiable"):
+                if group.get(key):
+                    raise RuntimeError(f"FusedAdam does not implement {key}=True (a torch.optim.Adam state with it cannot be continued here)")
+        for st in states:
+            if "max_exp_avg_sq" in st:
+                raise RuntimeError("FusedAdam does not implement amsgrad (the loaded state carries max_exp_avg_sq)")
+
     def load_state_dict(self, state_dict):
+        self._refuse_unsupported(state_dict.get("param_groups", ()), state_dict.get("state", {}).values())
         super().load_state_dict(state_dict)
         for st in self.state.values():      # (torch's fused Adam keeps `step` on the device: reading it there would wait for the GPU every update)
             if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
@@ -59,15 +70,20 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._refuse_unsupported(self.param_groups)
+        for group in self.param_groups:      # every parameter is validated before any step count moves (an error leaves the state as it was)
+            for p in group["params"]:
+                g = p.grad
+                if g is not None and not (p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() and g.dtype == torch.float64 and g.is_cuda
+                                          and not g.is_sparse):
+                    raise RuntimeError("FusedAdam serves contiguous fp64 parameters on the GPU with dense fp64 gradients (make_adam picks "
+                                       "torch.optim.Adam for everything else)")
         for group in self.param_groups:
             ps, gs, ms, vs, steps = [], [], [], [], set()
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 g = p.grad
-                if not (p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() and g.dtype == torch.float64 and g.is_cuda and not g.is_sparse):
-                    raise RuntimeError("FusedAdam serves contiguous fp64 parameters on the GPU with dense fp64 gradients (make_adam picks "
-                                       "torch.optim.Adam for everything else)")
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)

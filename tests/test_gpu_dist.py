@@ -125,6 +125,47 @@ def test_rccl_single_rank_sweep_equals_plain_sweep():
     assert E2 == E and Es2 == Es and g2 == g and (grads2 == grads).all()
 
 
+def _run_rccl(rank, world, port, B, out):
+    """One rank per GPU over nccl (= RCCL): the production collective path of fermiflow_amd/dist.py."""
+    import torch.distributed as dist
+    import __graft_entry__ as G
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["FERMIFLOW_DIST_FORCE"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device(f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    model = G._model(dev, 3, 3, 2.0)
+    torch.manual_seed(123)
+    g = model(B)
+    g.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    out[rank] = (model.E, model.E_std, g.item(), grads, model.x[:4].cpu().numpy(), model.x.shape[0], dist.get_backend())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_equal_one_rank():
+    """test_two_ranks_equal_one_rank over RCCL, one GPU per rank -- the collective the 8-GPU bench uses, not
+    the gloo / CPU detour the one-GPU test box is limited to.  Skipped unless two devices are visible (RCCL refuses two ranks on one
+    GPU), so that the first multi-GPU box exercises it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL: one device per rank)")
+    B = 4096
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, B, one), nprocs=1, join=True)
+    mp.spawn(_run_rccl, args=(2, _free_port(), B, two), nprocs=2, join=True)
+    E, Es, g, grads, x0, n = one[0]
+    for r in (0, 1):
+        E2, Es2, g2, grads2, x02, n2, backend = two[r]
+        assert backend == "nccl" and n2 == B // 2
+        assert abs(E2 - E) < 1e-12 * abs(E) and abs(Es2 - Es) < 1e-11 * Es
+        assert abs(g2 - g) < 1e-10 * max(1.0, abs(g))
+        np.testing.assert_allclose(grads2, grads, rtol=0, atol=1e-10 * np.abs(grads).max())
+    assert (two[0][4] == x0).all()
+
+
 def _bench(args, env_extra=None, timeout=600):
     import json
     import subprocess

@@ -819,7 +819,7 @@ def _load_weight_set(model, W, tag):
             m.fc2.weight.copy_(torch.as_tensor(W[f"{tag}_{nm}_w2"]).reshape(1, -1))
 
 
-@pytest.mark.parametrize("tag", ["head", "trained", "driver", "driver1000"])
+@pytest.mark.parametrize("tag", ["head", "trained", "driver", "driver1000", "soak3000"])
 def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
     """VERDICT r04 next #1c.  The production sweep at BASELINE.json configs[1] -- one tolerance for every component, first steps by cost
     class from the learned table, routing of the heavy walkers; GSVMC.forward_from, several sweeps so that the table has settled --
@@ -830,7 +830,10 @@ def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
     Measured (tools/probes/policy_sweep.py): 8.1e-7 / 1.7e-6 / 4.4e-7 / 6.7e-6 -- and that is the error of a plain rtol = 1e-6 solve
     with a per-walker norm, which is what the sweep now is (the 10 x / class <= 8 policy of rounds 2-4: 4.3e-7 / 1.0e-5 / 4.0e-6 /
     1.3e-5; 5 x / class <= 6: 8.1e-7 / 1.0e-5 / 4.4e-7 / 2.7e-5).  Asserted: 3e-6 (driver1000: 1e-5, where the plain solve itself is at
-    6.7e-6), and never worse than the stand-alone one-tolerance call on the same walkers."""
+    6.7e-6), and never worse than the stand-alone one-tolerance call on the same walkers.
+    Round 6: "soak3000" -- the strongest flow the repo itself produces, init_zeros() + 3000 iterations of the
+    reference's loop at lr 1e-2 on 65 536 walkers (tools/probes/train_fixtures_r06.py; max|w1| = 0.77, 31 evaluations per walker).
+    Measured there: sweep 1.6e-6, plain call 3.0e-6 (profiles/r06_a_policy_error_shape_trained.txt); asserted 5e-6."""
     import os
     import __graft_entry__ as Gm
     from fermiflow_amd import native
@@ -861,8 +864,71 @@ def test_headline_policy_error_over_seeds_and_weight_sets(dev, tag, capsys):
         print(f"\n[policy error, {tag} weights] max rel. E_loc error vs a 1e-11 solve by seed: " + " ".join(f"{w:.1e}" for w in worst) +
               " | plain one-tolerance call: " + " ".join(f"{w:.1e}" for w in plain) + f"; RHS evaluations per walker {np.mean(evals):.1f}; " +
               "first-step factors by class 2..12: " + " ".join(f"{v:.2f}" for v in model._h_tab[model._h_tab_cur][2:13].tolist()))
-    assert max(worst) < (1e-5 if tag == "driver1000" else 3e-6), worst
+    assert max(worst) < {"driver1000": 1e-5, "soak3000": 5e-6}.get(tag, 3e-6), worst
     assert max(worst) <= max(1.5 * max(plain), 3e-6), (worst, plain)
+
+
+@pytest.mark.parametrize("shape", ["n12", "c5", "c5_f32"])
+def test_loosened_sensitivity_tolerance_on_shape_trained_flows(dev, shape, capsys):
+    """the sweeps of BASELINE.json configs[3] (6 + 6 particles, d = 2) and configs[4] (10 + 10, d = 3) control the
+    SENSITIVITY components of the walkers of flow cost class <= 8 at 10 x / 5 x the reference's rtol / atol
+    (fermiflow_amd/VMC.py _init_sweep; the reference has one tolerance: src/NeuralODE/nnModule.py:161-162).  Round 5 showed on config 2 that
+    such a factor can pass on the weights it was tuned on only, so here it is pinned on flows TRAINED AT THESE SHAPES with the reference's
+    loop -- init_zeros(), Adam, 1000 iterations (src/FermionHO2D.py:40-43,61-72; lr 1e-2 / 3: at 1e-2 both shapes leave the basin in
+    the second iteration; tests/golden/trained_weights.npz entries n12_1000 / c5_1000, written by tools/probes/train_fixtures_r06.py) --
+    AND on the benchmark's synthetic weights: the production sweep (forward_from, learned first steps settled) against a 1e-11 solve of the
+    same walkers with fp64 sensitivity matrices, 3 seeds x 32 768 (16 384) walkers.  "c5_f32": the fp32 sensitivity matrices configs[4] names.
+    Measured (profiles/r06_a_policy_error_shape_trained.txt): n12 4.8e-7 (the plain one-tolerance call: 3.6e-7; the largest errors sit in
+    classes 12-15, which keep one tolerance), c5 4.1e-7 (plain 9e-8); synthetic weights (round 5): 7.6e-7 / 1.2e-6.
+    Asserted: 3e-6 on the synthetic weights (config 2's bound), 1.5e-6 on the shape-trained ones -- 7 x under the 1e-5 bar -- and the
+    mean energy to 1e-8."""
+    import os
+    import __graft_entry__ as Gm
+    import fermiflow_amd as ff
+    from fermiflow_amd import native
+    nup, ndn, dim, B = (6, 6, 2, 32768) if shape == "n12" else (10, 10, 3, 16384)
+    bits = 32 if shape == "c5_f32" else 64
+    W = np.load(os.path.join(os.path.dirname(__file__), "golden", "trained_weights.npz"))
+    rows = []
+    try:
+        for tag in ("head", "n12_1000" if dim == 2 else "c5_1000"):
+            if dim == 2:
+                model = Gm._model(dev, nup, ndn, 2.0)
+            else:
+                gs = Gm._model(dev, 2, 2, 2.0)
+                model = ff.GSVMC(nup, ndn, ff.HO3D(), ff.FreeFermion(device=dev), gs.cnf, ff.CoulombPairPotential(2.0), sp_potential=ff.HO())
+                model.to(dev)
+            if tag != "head":
+                _load_weight_set(model, W, tag)
+            assert model.sens_tol == (10.0 if dim == 2 else 5.0) and model.sens_tol_class == 8      # the policy under test
+            tu, td = model._tables(dev)
+            worst, plain = [], []
+            for seed in range(600, 603):
+                torch.manual_seed(seed)
+                with torch.no_grad():
+                    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+                native.set_sens_precision(bits)
+                for _ in range(3 if seed == 600 else 2):
+                    model.forward_from(z)
+                e = model.Eloc.clone()
+                net = model.cnf.v_wrapper.v.net()
+                native.set_sens_precision(64)
+                tight = native.eloc(tu, td, nup, ndn, net, model.x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+                one = native.eloc(tu, td, nup, ndn, net, model.x, 0.0, 1.0, 1e-6, 1e-8, 2.0, True)["eloc"]
+                loose = model.walker_cost <= 8
+                assert 0.5 < loose.double().mean().item() <= 1.0
+                rel = (e - tight).abs() / tight.abs()
+                worst.append(rel.max().item())
+                plain.append(((one - tight).abs() / tight.abs()).max().item())
+                assert abs(e.mean().item() / tight.mean().item() - 1) < 1e-8
+            rows.append((tag, worst, plain))
+            assert max(worst) < (3e-6 if tag == "head" else 1.5e-6), (tag, worst, plain)
+    finally:
+        native.set_sens_precision(64)
+    with capsys.disabled():
+        for tag, worst, plain in rows:
+            print(f"\n[loosened sensitivity tolerance, {shape}, {tag} weights] max rel. E_loc error vs a 1e-11 solve by seed: " +
+                  " ".join(f"{w:.1e}" for w in worst) + " | plain one-tolerance call: " + " ".join(f"{w:.1e}" for w in plain))
 
 
 def test_first_step_table_settles_on_a_trained_flow(dev, capsys):

@@ -72,16 +72,22 @@ sa = st[8:26].view(torch.int64)[:9].double()
 if sa.sum() > 0:   # 0 stage input, 1 publish, 2 radius, 3 component, 4 consume, 5 consume of stage 6 (deposit), per wave-eval
     res["adjoint_stamps_ticks"] = [round(v) for v in (sa / (st[0].item() / 5.0)).tolist()]
 st8 = r["stats"][8:26].view(torch.int64)[:9].double()
+GW = 4.0 if 4 <= n <= 6 else float(max(1, 64 // (2 * n)))      # walkers per wave of the local-energy kernel (matrix-core kernel: four)
 if st8.sum() > 0:
     res["stamps_pct"] = [round(v, 1) for v in (100 * st8 / st8.sum()).tolist()]
-    res["stamps_ticks"] = [round(v) for v in (st8 / (r["stats"][0].item() / 5.0)).tolist()]
+    res["stamps_ticks"] = [round(v) for v in (st8 / (r["stats"][0].item() / GW)).tolist()]
     res["core_clock_GHz"] = r["stats"][26].item() / max(1, r["stats"][27].item()) * 0.1
-    res["stamp_ticks_per_wave_eval"] = st8.sum().item() / (r["stats"][0].item() / 5.0)   # G = 5 walkers per wave at n = 6   # 0 coef, 1 publish, 2 radius, 3 transpose(after sweep), 4 -, 5 consume, 6 form in[], 7 sweep
+    res["stamp_ticks_per_wave_eval"] = st8.sum().item() / (r["stats"][0].item() / GW)   # 0 coef, 1 publish, 2 radius, 3 transpose(after sweep), 4 -, 5 consume, 6 form in[], 7 sweep
 if r["stats"].numel() > 32:   # per-workgroup trace of the local-energy kernel (FF_STAMPS_TRACE build)
     import numpy as np
     nb = min(16384, (r["stats"].numel() - 32) // 4)
     t = r["stats"][32:32 + 4 * nb].view(nb, 4).cpu().numpy().astype(np.int64)
     t = t[t[:, 1] != 0]
+if r["stats"].numel() >= 65600 + 36:      # consume-phase ticks by Dormand-Prince stage (-2 .. 6), per wave-evaluation in that stage
+    sa = r["stats"][65600:65636].view(torch.int64).double()
+    res["consume_ticks_by_stage(-2..6)"] = [round(float(a / max(1.0, float(c)))) for a, c in zip(sa[:9], sa[9:])]
+    res["consume_evals_by_stage(-2..6)"] = [int(c) for c in sa[9:]]
+if r["stats"].numel() > 32 and len(t):
     t0 = t[:, 0].min()
     st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0      # microseconds
     dur = en - st
@@ -95,9 +101,6 @@ if r["stats"].numel() > 32:   # per-workgroup trace of the local-energy kernel (
     res["trace"]["per_xcc_blocks"] = np.bincount(xcc, minlength=8).tolist()
     res["trace"]["per_xcc_mean_dur"] = [round(float(dur[xcc == k].mean()), 1) if (xcc == k).any() else 0 for k in range(8)]
     np.save(os.path.join(ROOT, "gpurun_out", "trace.npy"), t)
-    if r["stats"].numel() >= 65600 + 36:
-        sa = r["stats"][65600:65636].view(torch.int64).double()
-        res["consume_ticks_by_stage(-2..6)"] = [round(float(a / max(1.0, float(c)))) for a, c in zip(sa[:9], sa[9:])]
 res["E"] = r["eloc"].mean().item()
 res["gp_norm"] = gp.norm().item()
 print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))
