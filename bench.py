@@ -76,10 +76,10 @@ def self_launch(n):
 def eloc_kernel_name(n, d=2):
     """The local-energy kernel the dispatcher picks (csrc/ff_cnf_fwd.hip, dispatch_fwd; csrc/ff_wide.hip beyond 12 / 4 particles)."""
     kind = os.environ.get("FF_ELOC_KERNEL", "auto")
-    if os.environ.get("FF_WIDE") == "1" or kind == "wide" or (d == 2 and n >= int(os.environ.get("FF_WIDE_ELOC_FROM", "11")) and kind == "auto") \
+    if os.environ.get("FF_WIDE") == "1" or kind == "wide" or (d == 2 and n >= 11 and kind == "auto") \
             or (d == 2 and n > 12) or (d == 3 and n > 4):
         return "wide", f"ff_wide_eloc_kernel<{d}, {(n * d + 4 + 15) // 16}, true>"
-    if d == 2 and 2 <= n <= 6 and (kind == "mfma" or (kind == "auto" and n >= int(os.environ.get("FF_MFMA_ELOC_FROM", "4")))):
+    if d == 2 and 2 <= n <= 6 and (kind == "mfma" or (kind == "auto" and n >= 4)):
         return "mfma", f"ff_eloc_mfma_kernel<{n}, 2, true, 2>"
     split = {7: 2, 8: 2, 9: 3, 10: 3, 11: 2, 12: 2}.get(n, 1)
     if kind == "rows" or n in (1, 7, 9, 11) or (kind in ("auto", "mfma") and n >= 9):

@@ -127,12 +127,9 @@ def _add_generic_potentials(r, x, extra):
     return r
 
 
-# Where the sampler's side stream is released (FERMIFLOW_PREFETCH_GO): "kernel" (default since round 5) -- behind the adjoint's main kernel
-# (ff_ode.after_main_event), so that it runs under the small reduction kernels with the SIMDs to itself; "adj" -- in front of the adjoint
-# call (rounds 2-4: beside the adjoint kernel, while the two still fitted one SIMD together); "est" -- in front of the estimator kernel.
-_PREFETCH_GO = os.environ.get("FERMIFLOW_PREFETCH_GO", "kernel")
-_ADJOINT_SCALE = float(os.environ.get("FERMIFLOW_ADJOINT_SCALE", "1.1"))      # x the flow pass's largest accepted step (probes)
-_ADJOINT_OPEN = os.environ.get("FERMIFLOW_ADJOINT_OPEN", "flow")      # "eloc": the adjoint opens with 1.25 x the local-energy pass's step (rounds 2-4)
+# The adjoint opens with this factor x the largest step the walker's flow pass accepted (_adjoint_open; probed in round 5: 1.25 equal,
+# 1.4 worse over a 3000-iteration run)
+_ADJOINT_SCALE = 1.1
 
 
 class _Sweep:
@@ -162,8 +159,8 @@ class _Sweep:
         # -- it passed on the weights it was tuned on only: as the flow strengthens the sensitivities grow and any factor f is f times the
         # error of the plain solve in the worst walkers.  So the sweeps now keep ONE tolerance for every component (sens_tol = 1: never
         # looser than the reference's own control, src/NeuralODE/nnModule.py:161-162); what the cost classes still decide is the step a
-        # walker opens with (_h_tab below) and the routing of the heavy walkers.  FERMIFLOW_SENS_TOL=10 FERMIFLOW_SENS_TOL_CLASS=8 is the
-        # old policy.
+        # walker opens with (_h_tab below) and the routing of the heavy walkers.  model.sens_tol = 10, model.sens_tol_class = 8 is the
+        # old policy (FERMIFLOW_SENS_TOL sets the factor for every shape; 1 = the reference's control everywhere).
         # Beyond 12 coordinates the plain solve is 5-20 x more accurate in E_loc (larger |E_loc|, more terms to average over: max error
         # 1e-7 .. 3.7e-7 at 6 + 6 particles and 9e-8 .. 1.9e-7 at configs[4] on synthetic, trained and driver-trained flows), and one
         # tolerance costs 30-40 % more evaluations there (a third step for every walker).  Those systems keep a factor for the walkers of
@@ -171,7 +168,7 @@ class _Sweep:
         # driver-trained flows), 5 beyond (configs[4]: 1.2e-6 / 2.6e-7; 10 x: 2.4e-6 / 7.7e-7) -- tools/probes/policy_sweep.py.
         M = n * dim
         self.sens_tol = float(os.environ.get("FERMIFLOW_SENS_TOL", "1" if M <= 12 else ("10" if M <= 24 else "5")))
-        self.sens_tol_class = int(os.environ.get("FERMIFLOW_SENS_TOL_CLASS", "6" if M <= 12 else "8"))
+        self.sens_tol_class = 6 if M <= 12 else 8
         self._h_scale_loose = 0.9
         # First step of the local-energy pass = (largest step the flow pass accepted) x a factor BY COST CLASS that follows the passes
         # (ff_walker_schedule: more than _h_shrink_at of a class rejected their first step -> x 0.93; fewer than 5 % AND 70 % of its walkers with
@@ -192,7 +189,7 @@ class _Sweep:
             G = min(16, 64 // (2 * n)) if n <= 3 else (4 if n <= 6 else (2 if n <= 8 else 1))
         else:
             G = max(1, 64 // (3 * n)) if n <= 4 else 1
-        self._h_shrink_at = float(os.environ.get("FERMIFLOW_SHRINK_AT", min(0.25, max(0.06, 1.0 - 0.65 ** (1.0 / G)))))
+        self._h_shrink_at = min(0.25, max(0.06, 1.0 - 0.65 ** (1.0 / G)))
         self._h_tab = None           # [2, 32] device table (double-buffered), row _h_tab_cur is current
         self._h_tab_cur = 0
         self._h_prev = None          # (cost, hs, he) of the previous local-energy pass
@@ -204,8 +201,8 @@ class _Sweep:
         self.heavy_class = int(os.environ.get("FERMIFLOW_HEAVY_CLASS", "0"))
         # ff_ode.compact_finish (None: native.eloc decides by the size of the full workspace; FERMIFLOW_COMPACT=1/0 forces it)
         self.compact_finish = {"1": True, "0": False}.get(os.environ.get("FERMIFLOW_COMPACT", ""), None)
-        self.heavy_tol = float(os.environ.get("FERMIFLOW_HEAVY_TOL", "0"))
-        self.sum_weight = float(os.environ.get("FERMIFLOW_SUM_WEIGHT", "0"))
+        self.heavy_tol = 0.0         # 0: the library's defaults (ff_ode.heavy_tol 0.3, ff_ode.sum_weight 4); attributes, for probes
+        self.sum_weight = 0.0
 
     def _mark(self, ev, name):
         if self.profile is not None and self.profile.get("stages", True):
@@ -305,12 +302,11 @@ class _Sweep:
         by 1.4 x.  The adjoint follows the flow's own trajectory with a linear costate: it opens with 1.1 x the largest step the
         walker's FLOW pass accepted, rounded down to equal steps of the interval (config 2, 200 iterations into the benchmark's
         training: 15.9 -> 14.2 evaluations per walker, no rejections; 12 particles: 13.7 -> 13.1, rejected first steps 4 % -> 0.06 %;
-        configs[4]: 20.7 -> 18.9, 19 % -> 3 %; 1.3 x: 36 % rejected there -- tools/probes/adjoint_open.py).
-        FERMIFLOW_ADJOINT_OPEN=eloc keeps the old rule."""
+        configs[4]: 20.7 -> 18.9, 19 % -> 3 %; 1.3 x: 36 % rejected there -- tools/probes/adjoint_open.py)."""
         hg = getattr(self, "_hg_last", None)
         if not self.warm_start or he is None:
             return {}
-        if hg is None or _ADJOINT_OPEN == "eloc":
+        if hg is None:
             return dict(walker_h_init=he, walker_h_scale=1.25)
         return dict(walker_h_init=hg, walker_h_scale=_ADJOINT_SCALE, walker_h_equal=True)
 
@@ -432,13 +428,14 @@ class GSVMC(_Sweep, torch.nn.Module):
         # Measured (round 4, with the determinant-ratio samplers): it pays at 6 particles (1.67 -> 1.61 ms per iteration: the adjoint
         # and the sampler fit one SIMD together) and costs at 12 and beyond (6.65 against 6.45 ms at 12 particles, 145 against 139 ms
         # at configs[4]: both kernels fill the SIMDs on their own and only slow each other down) -- default on up to 8 particles.
-        self.prefetch_walkers = os.environ.get("FERMIFLOW_PREFETCH", "1" if nup + ndown <= 8 else "0") != "0"
+        _pf = int(os.environ.get("FERMIFLOW_PREFETCH", "2" if nup + ndown <= 8 else "0"))
+        self.prefetch_walkers = _pf != 0
         # Round 5: TWO iterations ahead, released behind the adjoint kernel (ff_ode.after_main_event).  The two-wave adjoint fills the
         # register files, so a sampler released beside it ran in its tail anyway -- 0.05 ms of interference at its start and 0.05 ms of
         # the next iteration waiting for the walkers.  Released when the adjoint kernel ends, the sampler runs under the small
         # latency-bound kernels behind it (table reduction, contraction, Adam, next radial table: ~150 us of mostly idle SIMDs), and
-        # with a batch in hand nobody ever waits for it.  FERMIFLOW_PREFETCH_DEPTH=1 keeps one batch ahead.
-        self.prefetch_depth = max(1, int(os.environ.get("FERMIFLOW_PREFETCH_DEPTH", "2")))
+        # with a batch in hand nobody ever waits for it.  FERMIFLOW_PREFETCH=<n> keeps n batches ahead (0: off).
+        self.prefetch_depth = max(1, _pf)
         self._z_queue = []           # entries (walkers, event on the side stream, nloc, CPU generator state after their seed was drawn, seed)
         self._resume_seeds, self._resume_rng = [], None
         self._side = None
@@ -545,14 +542,10 @@ class GSVMC(_Sweep, torch.nn.Module):
         """Walkers of the iterations ahead on the side stream, until prefetch_depth batches are in hand: released when `go` fires -- the
         event the adjoint call records behind its main kernel (ff_ode.after_main_event)."""
         if self._side is None:
-            # (FERMIFLOW_PREFETCH_PRIORITY: stream priority of the sampler's stream, lower number = served first; default 0)
-            self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
+            self._side = torch.cuda.Stream()
         from .base_dist import _draw_seed
         with torch.cuda.stream(self._side):
             self._side.wait_event(go)
-            delay = float(os.environ.get("FERMIFLOW_PREFETCH_DELAY_US", "0"))
-            if delay > 0:
-                native.stream_delay(delay)
             while len(self._z_queue) < self.prefetch_depth:
                 seed = _draw_seed()
                 z = self.basedist.sample(self.orbitals_up, self.orbitals_down, (nloc,), seed=seed)
@@ -586,10 +579,6 @@ class GSVMC(_Sweep, torch.nn.Module):
             # from E on the device (ff_cnf_adjoint_energy) -- nothing here waits for the host
             prev = self._dev.get("E")
             shift = prev.reshape(1) if prev is not None else torch.zeros(1, dtype=Eloc.dtype, device=Eloc.device)
-            go_early = None
-            if prefetch and _PREFETCH_GO == "est":
-                go_early = torch.cuda.Event()
-                go_early.record()
             if not D._active():
                 _, est = native.energy_estimate(Eloc, r["logp"], shift, batch)       # one launch: sums and finish (nothing to all-reduce)
             else:
@@ -598,17 +587,13 @@ class GSVMC(_Sweep, torch.nn.Module):
                 est = native.energy_finish(sums, shift, batch)    # [E, sum (e - E)^2, mean(logp (e - E))]
             self._dev["E"], self._dev["E_ss"], self._n_global = est[0], est[1], batch
             self._mark(ev, "estimator")
-            go = go_early
-            after = None
-            if prefetch and go is None:
+            go, after = None, None
+            if prefetch:      # the sampler's side stream is released by the library right behind the adjoint's main kernel (ff_ode.after_main_event)
                 go = torch.cuda.Event()
-                if _PREFETCH_GO == "adj":
-                    go.record()
-                else:      # default: recorded by the library right behind the adjoint's main kernel
-                    if self._side is None:
-                        self._side = torch.cuda.Stream(priority=int(os.environ.get("FERMIFLOW_PREFETCH_PRIORITY", "0")))
-                    go.record(self._side)      # (creates the handle; the library re-records it on the main stream)
-                    after = go
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                go.record(self._side)      # (creates the handle; the library re-records it on the main stream)
+                after = go
             adj = native.cnf_adjoint(net, r["z"], r["glogp0"], None, t0, t1, self.cnf.rtol, self.cnf.atol,
                                      need_gx=False, energy=(Eloc, est, 1.0 / batch),   # (uniform cost: no schedule)
                                      after_main_event=after, want_stats=prof is not None, **self._adjoint_open(he))

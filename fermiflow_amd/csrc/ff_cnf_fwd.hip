@@ -165,7 +165,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 
   __shared__ long long s_next;
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
-    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
       __syncthreads();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();
@@ -177,7 +177,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     const int64_t b = ff_opt_load(A.order, inb, bq, A.y_in, (int32_t)bq);   // the walker this lane group integrates
     // (routing by cost class, launch_routed below: with heavy_mode = 2 the walkers of class >= heavy_class belong to another launch)
     // (only where this kernel is the local-energy pass's default, up to 3 particles: the larger instantiations sit at the edge of the
-    // register allocator's bug of DESIGN.md 10 and are left exactly as they were)
+    // register allocator's bug of docs/LOG.md (round 2) and are left exactly as they were)
     const bool valid = inb && !(MODE == 2 && N <= 3 && A.heavy_mode == 2 && ff_opt_load(A.wclass, inb, b, A.y_in, (int32_t)0) >= A.heavy_class);
     // Stage storage, 5 vectors instead of the textbook 7 (y, k0..k5): c0..c2 hold k0..k2 up to stage 3; once k3 is
     // known the remaining stage inputs and the error accumulator are formed and overwrite them:
@@ -727,7 +727,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 
   __shared__ long long s_next;
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
-    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
       __syncthreads();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();
@@ -1515,7 +1515,10 @@ static int dispatch_fwd(void* stream, int n, int d, const ff_fwd_args& a_in) {
   constexpr int wide_from = 11;
   if (MODE == 2 && d == 2 && (eloc_kind == 4 || (eloc_kind == 0 && n >= wide_from)) && ff_wide_supported(n, d))
     return wide();
-  constexpr int mfma_from = 4;      // (2-3 particles tie with the column sweep and keep it: DESIGN.md 3g)
+#ifndef FF_MFMA_FROM
+#define FF_MFMA_FROM 4      // (2-3 particles tie with the column sweep and keep it: DESIGN.md 3g; the host simulator builds with 99)
+#endif
+  constexpr int mfma_from = FF_MFMA_FROM;
   if (MODE == 2 && (eloc_kind == 1 || (eloc_kind == 0 && d == 2 && n >= mfma_from && n <= 6))) {
 #define FF_MF(N_, D_) if (n == N_ && d == D_) { const int s_ = launch_mfma<N_, D_>(stream, a); if (s_) return s_; FF_LAUNCH_CHECK(); return FF_OK; }
     FF_MF(6, 2) FF_MF(2, 2) FF_MF(3, 2) FF_MF(4, 2) FF_MF(5, 2)

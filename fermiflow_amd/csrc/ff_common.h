@@ -188,11 +188,7 @@ FF_D double ff_sigmoid_sel(double a, const double* __restrict__ tab) {
 // --- NV sigmoids side by side.  Written step by step over the NV lanes-of-work with scheduling fences in between:
 //     under the register pressure of the local-energy kernel hipcc otherwise runs the NV dependency chains one
 //     after the other, and a single resident wave per SIMD then stalls on every fp64 latency.
-#ifndef FF_NO_SCHED_FENCE
 #define FF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define FF_SCHED_FENCE() do {} while (0)      // (A/B knob)
-#endif
 // wave priority for the instruction arbiter (0..3): the small kernels of the critical path raise theirs, because they run beside the
 // prefetched Metropolis kernel.  Round 4 measured this as zero-sum (the adjoint stage 0.576 -> 0.532 ms, the wait for the walkers 0.040
 // -> 0.070: somebody waited for the sampler either way) and left it off.  Since round 5 the sampler works two iterations ahead and
@@ -291,7 +287,7 @@ FF_D void ff_sigmoid_n(const double* a_in, double* sg, const double* __restrict_
 // Optional per-walker inputs (ff_ode.walker_order / walker_h_init / walker_class) are read WITHOUT a branch: a lane that
 // has no entry reads element 0 of `safe`, an array of the launch that always exists, and discards it.  This is not a
 // micro-optimisation: ROCm 7.2's register allocator was caught placing VGPR->AGPR copies in front of the exec restore at the
-// join of exactly these `if (p) v = p[b];` blocks (tools/check_agpr_spills.py) -- with a null pointer nobody
+// join of exactly these `if (p) v = p[b];` blocks (tools/check_agpr_spills.py, docs/LOG.md round 2) -- with a null pointer nobody
 // takes the branch, the copy executes with exec = 0 and the value it should have parked is garbage from then on.
 template <class T>
 FF_D T ff_opt_load(const T* p, bool cond, long long idx, const void* safe, T dflt) {

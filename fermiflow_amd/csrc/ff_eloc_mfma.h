@@ -164,7 +164,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #endif
 #endif
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
-    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
       __syncthreads();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();

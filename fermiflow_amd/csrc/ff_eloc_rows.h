@@ -132,7 +132,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
   unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
-    if (A.queue) {   // persistent grid: next group from the launch's work counter (heavy walkers sit at the front)
+    if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
       __syncthreads();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();

@@ -159,7 +159,7 @@ FF_D double ff_pow02(double x, float e) {
 // second one to grow by 1.4 x, which the step-size control only grants after an error below 0.11 of the tolerance (flow and adjoint
 // kernels; the local-energy pass gets its opening steps rounded by ff_walker_schedule).
 // (Selects, not a per-lane branch: a divergent join in a walker prologue is where ROCm 7.2's register allocator misplaces its AGPR
-// copies -- DESIGN.md 10 -- and `if (h > 0 && h < interval)` written as a branch did break ff_wide_adjtab_kernel<3, 4, .> at 20 particles:
+// copies -- docs/LOG.md, round 2 -- and `if (h > 0 && h < interval)` written as a branch did break ff_wide_adjtab_kernel<3, 4, .> at 20 particles:
 // every walker failed, with walker_h_equal = 0.  The flag itself is uniform.)
 FF_D double ff_open_step(double h, double ta, double tb, int equal) {
   if (equal) {

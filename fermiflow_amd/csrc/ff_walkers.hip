@@ -1385,6 +1385,10 @@ __global__ void __launch_bounds__(FF_ORD_THREADS) ff_order_count_kernel(int64_t 
       if (hs0 > 0.0 && he0 > 0.0) {       // (a failed or cold-started walker says nothing about the scale)
         const int row = ff_ord_row(prev_cost[j0 + k]);
         atomicAdd(&pn[row], 1u);
+        // "first step rejected" is INFERRED: he0 is the largest step accepted anywhere in the pass, so a walker whose first step was
+        // rejected and whose later steps grew back to hs0 counts as accepted -- the shrink rule under-counts rejections.
+        // Performance only (the per-step error test is untouched), and the thresholds of ff_scale_update were set against THIS count:
+        // left as it is with the controller frozen; an explicit flag from the kernels is the clean form.
         if (he0 < 0.999 * hs0) atomicAdd(&pr[row], 1u);
         const unsigned v = ff_scale_votes(hs0, he0, interval);
         if (v & 1u) atomicAdd(&p3[row], 1u);

@@ -415,7 +415,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 
   bool degrees_known = false;      // (fused finish: the orbitals' Hermite degrees are in LDS)
   for (int64_t bq = bq_first;; bq += gridDim.x) {
-    if (A.queue) {   // persistent grid: next walker from the launch's work counter (heavy walkers sit at the front)
+    if (A.queue) {   // persistent grid: next walker from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
       __syncthreads();
       if (tid == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
       __syncthreads();

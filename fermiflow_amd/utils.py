@@ -104,13 +104,9 @@ class FusedAdam(torch.optim.Optimizer):
 
 def make_adam(params, lr):
     """torch.optim.Adam as the reference's drivers build it (src/FermionHO2D.py:61, lr = 1e-2) -- as FusedAdam (one launch of the
-    library's own kernel) when every parameter is an fp64 tensor on the GPU, torch.optim.Adam otherwise.  FERMIFLOW_FUSED_ADAM=torch
-    takes PyTorch's fused implementation instead (rounds 2-4: two multi-tensor launches, 24 us each for 300 numbers),
-    FERMIFLOW_FUSED_ADAM=0 the default one (seven launches)."""
-    import os
+    library's own kernel; PyTorch's fused implementation: two multi-tensor launches of 24 us each for 300 numbers, the default one seven)
+    when every parameter is a contiguous fp64 tensor on the GPU, torch.optim.Adam otherwise."""
     params = list(params)
-    mode = os.environ.get("FERMIFLOW_FUSED_ADAM", "1")
-    on_gpu = len(params) > 0 and all(p.is_cuda for p in params)
-    if mode == "1" and on_gpu and all(p.dtype == torch.float64 and p.is_contiguous() for p in params):
+    if len(params) > 0 and all(p.is_cuda and p.dtype == torch.float64 and p.is_contiguous() for p in params):
         return FusedAdam(params, lr=lr)
-    return torch.optim.Adam(params, lr=lr, fused=True) if (mode != "0" and on_gpu) else torch.optim.Adam(params, lr=lr)
+    return torch.optim.Adam(params, lr=lr)

@@ -67,9 +67,12 @@ typedef struct ff_ode {
    * passes a point at which the field is merely C^1 (a vanishing radius).  walker_class (in, B): a cost class per walker --
    * walker_cost of the flow pass along the same trajectory.  Walkers with class <= sens_tol_class control those components at
    * sens_tol x (rtol, atol) -- their own coordinates keep rtol/atol -- and open with walker_h_init x walker_h_scale_loose
-   * (0: walker_h_scale); the others keep one tolerance for everything.  The sweeps pass sens_tol = 5, class 6, scale 0.9
-   * (rounds 2-4: 10, 8, 1.0 -- 1.3e-5 relative E_loc error on trained flows, past the 1e-5 bar): 19.5 -> 13.6 evaluations per
-   * walker at 6 particles on the benchmark's weights; max E_loc error 1.6e-6 on those and on trained ones. */
+   * (0: walker_h_scale); the others keep one tolerance for everything.  The package's sweeps pass sens_tol = 1 (off: the
+   * reference's one tolerance, src/NeuralODE/nnModule.py:161-162) up to 12 coordinates -- rounds 2-4 ran 10 x for class <= 8
+   * there and measured 1.3e-5 relative E_loc error on trained flows, past the 1e-5 bar --, sens_tol = 10 with class <= 8 up
+   * to 24 coordinates and 5 with class <= 8 beyond (max E_loc error 4.8e-7 / 4.1e-7 on flows trained at those shapes, pinned
+   * by tests/test_gpu_parity.py::test_loosened_sensitivity_tolerance_on_shape_trained_flows), and, with ff_walker_schedule's
+   * hs_out as walker_h_init, walker_h_scale = walker_h_scale_loose = 1. */
   const int32_t* walker_class;
   double sens_tol;
   double walker_h_scale_loose;

@@ -35,8 +35,8 @@ def lib():
     if _LIB is None:
         # Which local-energy kernel "auto" picks is a measured-on-MI355X choice; under the simulator the matrix-core kernel is the
         # slowest by far (every ds_bpermute / DPP exchange is a barrier of 64 host threads), so the simulator's default stays the
-        # column sweep and the tests that are ABOUT the matrix-core kernel select it (FF_ELOC_KERNEL=mfma in a subprocess).
-        os.environ.setdefault("FF_MFMA_ELOC_FROM", "99")
+        # column sweep (tests/hostsim/Makefile: -DFF_MFMA_FROM=99) and the tests that are ABOUT the matrix-core kernel select it
+        # (FF_ELOC_KERNEL=mfma in a subprocess).
         alt = os.environ.get("FF_HOSTSIM_LIB")     # e.g. a build of the same sources under the address / UB sanitizers
         if not alt:
             build()

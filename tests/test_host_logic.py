@@ -146,7 +146,7 @@ def test_no_agpr_copy_in_front_of_an_exec_restore():
     """Static check of the BUILT library (tools/check_agpr_spills.py): ROCm 7.2's register allocator can place a VGPR->AGPR
     copy in front of the `s_or_b64 exec` of a join block, where it runs under the mask of the branch that just ended --
     with exec = 0 when no lane took it (an optional ff_ode array that is NULL).  That was an aperture violation at run time
-    for ff_ode_fwd_kernel<2,2,2>; the kernels read optional inputs without a branch since, and this test keeps
+    for ff_ode_fwd_kernel<2,2,2> (docs/LOG.md, round 2); the kernels read optional inputs without a branch since, and this test keeps
     the pattern from coming back unnoticed with the next change of register pressure."""
     import importlib.util, os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

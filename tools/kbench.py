@@ -33,7 +33,7 @@ def timeit(fn):
     return e0.elapsed_time(e1) / a.reps, out
 
 
-res = {"tag": a.tag, "B": a.B, "blocks": os.environ.get("FF_PERSIST_BLOCKS", "default")}
+res = {"tag": a.tag, "B": a.B}
 res["mcmc_ms"], _ = timeit(lambda: native.mcmc_sample(tu, td, a.nup, a.ndown, a.B, 100, 0.1, 1, dev))
 steps = torch.empty(a.B, dtype=torch.int32, device=dev)
 sched = not os.environ.get("FF_NO_SCHED")
