@@ -610,6 +610,14 @@ class GSVMC(_Sweep, torch.nn.Module):
         return _sweep_scalar(est[2], gp, params, self.fast_backward)
 
 
+def draw_states_reference(logits, batch):
+    """The reference's state draw (src/VMC.py:90-96): `Categorical(logits=log_state_weights).sample((batch,))` on torch's default (CPU)
+    generator in the reference's fp64, then sorted -- the list `Counter(sorted(state_indices.tolist()))` counts.  Returns int64 on the CPU."""
+    from torch.distributions.categorical import Categorical
+    idx = Categorical(logits=logits.detach().to("cpu", torch.float64)).sample((int(batch),))
+    return torch.sort(idx).values
+
+
 class BetaVMC(_Sweep, torch.nn.Module):
     def __init__(self, beta, nup, ndown, deltaE, boltzmann, orbitals, basedist, cnf, pair_potential, sp_potential=None):
         super(BetaVMC, self).__init__()
@@ -647,10 +655,22 @@ class BetaVMC(_Sweep, torch.nn.Module):
 
     _coll = None
 
+    # How the many-body states of a batch are drawn: "order_statistics" (default; below) or "reference" -- the reference's own draw,
+    # Categorical(logits).sample((batch,)) on torch's CPU generator, sorted (src/VMC.py:90-96): after the same torch.manual_seed the state
+    # list IS the reference's, so a seeded BetaVMC.forward can be compared with it end to end (VERDICT r05 missing #3).  A host round trip
+    # per sweep: opt-in.
+    state_draw = "order_statistics"
+
     def _draw_states(self, batch):
         """Many-body state of every walker of the GLOBAL batch, sorted as the reference does (src/VMC.py:94-96), on the
         device; rank 0 draws and broadcasts so that every rank cuts its shard from the same list."""
         logits = self.log_state_weights.detach()
+        if self.state_draw == "reference":
+            idx = draw_states_reference(logits, batch).to(logits.device)
+            D.broadcast_(idx)
+            return idx
+        if self.state_draw != "order_statistics":
+            raise ValueError(f"BetaVMC.state_draw must be 'order_statistics' or 'reference', not {self.state_draw!r}")
         # sorted(Categorical(logits).sample((batch,))) without the sort: the order statistics of `batch` uniforms are the
         # normalised partial sums of batch + 1 exponentials, and the inverse CDF is monotone -- so pushing the (already sorted)
         # uniforms through it gives the sorted state list directly (one scan instead of multinomial + radix/merge sort)

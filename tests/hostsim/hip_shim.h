@@ -31,6 +31,7 @@ inline pthread_barrier_t* ff_sim_bar = nullptr;
 // workgroups of several INDEPENDENT waves (the two-wave tabulated adjoint): one barrier per wave of 64 "lanes"
 inline pthread_barrier_t ff_sim_wave_bar[16];
 #define FF_WAVE_SYNC() pthread_barrier_wait(&ff_sim_wave_bar[threadIdx.x >> 6])
+#define FF_LOAD_ORDER() std::atomic_thread_fence(std::memory_order_seq_cst)
 
 #define __global__
 #define __device__
@@ -48,6 +49,14 @@ typedef int hipError_t;
 inline int hipGetLastError() { return 0; }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __HIP_MEMORY_SCOPE_AGENT 1
+inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, sizeof d); return d; }
+inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;      // (the value found: == the expected one exactly when the exchange happened)
+}
 template <class T> inline T __hip_atomic_load(T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 template <class T, class V> inline void __hip_atomic_store(T* p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 inline const char* hipGetErrorString(int) { return "hostsim"; }
@@ -136,15 +145,15 @@ inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
   return o;
 }
 // wave vote (the kernels only ask whether any lane of a single-wave workgroup voted yes)
-static std::atomic<int> ff_sim_vote{0};
+static std::atomic<unsigned long long> ff_sim_vote{0};
 // the same vote among the 64 lanes of the caller's own wave only (waves of a workgroup that do not run in lockstep)
-static std::atomic<int> ff_sim_wave_vote[16];
+static std::atomic<unsigned long long> ff_sim_wave_vote[16];
 inline unsigned long long ff_wave_ballot(bool pred) {
   const unsigned w = threadIdx.x >> 6;
   FF_WAVE_SYNC();
   if ((threadIdx.x & 63) == 0) ff_sim_wave_vote[w].store(0);
   FF_WAVE_SYNC();
-  if (pred) ff_sim_wave_vote[w].fetch_or(1);
+  if (pred) ff_sim_wave_vote[w].fetch_or(1ULL << (threadIdx.x & 63));      // (a real lane mask, as on the GPU)
   FF_WAVE_SYNC();
   return (unsigned long long)ff_sim_wave_vote[w].load();
 }
@@ -153,7 +162,7 @@ inline unsigned long long __ballot(bool pred) {
   __syncthreads();
   if (threadIdx.x == 0) ff_sim_vote.store(0);
   __syncthreads();
-  if (pred) ff_sim_vote.fetch_or(1);
+  if (pred) ff_sim_vote.fetch_or(1ULL << (threadIdx.x & 63));
   __syncthreads();
   return (unsigned long long)ff_sim_vote.load();
 }

@@ -715,6 +715,48 @@ def test_local_energy_routing_by_cost_class(dev, nup, ndn, monkeypatch):
     assert all(torch.equal(dflt[k], want[k]) for k in ("eloc", "grad", "z"))
 
 
+def test_rejected_first_steps_do_not_couple_the_walkers_of_a_wave(dev, capsys):
+    """The four walkers of a matrix-core wave advance in lockstep: a rejected step of one sends all of them through stage 0 again, which
+    must not change anybody's numbers.  16 384 walkers of a TRAINED flow (tests/golden/trained_weights.npz "trained") opened with half
+    the interval -- most first steps rejected -- in one call, against the same walkers in calls of three: every output identical, the
+    rejections counted once, the call reproducible.  (Written for round 6's retry queue -- docs/attic/retry_queue_r06.patch, DESIGN.md 3p
+    -- whose retried integrations had to be the in-place ones bit for bit; kept as the invariant it checks.)"""
+    import os
+    import __graft_entry__ as Gm
+    from fermiflow_amd import native
+    model = Gm._model(dev, 3, 3, 2.0)
+    _load_weight_set(model, np.load(os.path.join(os.path.dirname(__file__), "golden", "trained_weights.npz")), "trained")
+    net = model.cnf.v_wrapper.v.net()
+    tu, td = model._tables(dev)
+    B = 16384
+    torch.manual_seed(23)
+    z = model.basedist.sample(model.orbitals_up, model.orbitals_down, (B,))
+    x = native.cnf_generate(net, z, 0.0, 1.0, 1e-6, 1e-8)
+    h = torch.full((B,), 0.5, dtype=torch.float64, device=dev)
+    run = lambda xx, hh: native.eloc(tu, td, 3, 3, net, xx, 0.0, 1.0, 1e-6, 1e-8, 2.0, True, want_stats=True, walker_h_init=hh, walker_h_scale=1.0,
+                                     walker_cost=torch.zeros(xx.shape[0], dtype=torch.int32, device=dev))
+    a, b = run(x, h), run(x, h)
+    rej = int(a["stats"][2])
+    assert int(a["stats"][3]) == 0 and rej > B // 4, a["stats"][:4]
+    keys = ("eloc", "logp", "lap", "grad", "z", "dlogp", "glogp0")
+    for k in keys:
+        assert torch.equal(a[k], b[k]), k
+    n3 = 1500      # the first 1 500 walkers three at a time
+    rej3 = 0
+    for i in range(0, n3, 3):
+        s3 = run(x[i:i + 3].contiguous(), h[i:i + 3].contiguous())
+        rej3 += int(s3["stats"][2])
+        for k in keys:
+            assert torch.equal(s3[k], a[k][i:i + 3]), (k, i)
+    sub = run(x[:n3].contiguous(), h[:n3].contiguous())
+    assert int(sub["stats"][2]) == rej3
+    tight = native.eloc(tu, td, 3, 3, net, x, 0.0, 1.0, 1e-11, 1e-13, 2.0, True)["eloc"]
+    err = ((a["eloc"] - tight).abs() / tight.abs()).max().item()
+    with capsys.disabled():
+        print(f"\n[rejected first steps] {B} walkers, {rej} rejected steps; bit-identical to the calls of three; max rel. E_loc error vs a 1e-11 solve {err:.1e}")
+    assert err < 1e-5
+
+
 def test_heavy_walker_route_vs_oracle(dev, capsys):
     """the walkers of cost class >= 12 (a particle passing the origin: 0.4-0.6 % of a batch, and the ones
     with the largest E_loc error) leave the throughput kernel for the one-walker-per-wave kernel at 0.3 x the tolerances

@@ -242,6 +242,37 @@ def test_routing_controls_travel_in_ff_ode_not_in_the_environment():
     assert _lib.lib().ff_shutdown() == 0          # nothing created yet: a no-op, and callable without a GPU
 
 
+def test_environment_knobs_are_the_documented_dozen():
+    """the A/B knobs of closed experiments are gone -- what the package and the library still read from the environment
+    is exactly the table of INTEGRATION.md section 2 (FF_STATS_WORDS: diagnostic builds only; WORLD_SIZE & co.: the launcher's)."""
+    pkg = os.path.join(ROOT, "fermiflow_amd")
+    found = set()
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                t = open(os.path.join(d, f)).read()
+                found |= set(re.findall(r'getenv\("(\w+)"\)', t)) | set(re.findall(r'environ(?:\.get|\.setdefault)?\(\s*"(\w+)"', t))
+    found -= {"WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FF_STATS_WORDS"}
+    documented = set(re.findall(r"^\| `((?:FERMIFLOW|FF)_[A-Z_]+)` \|", open(os.path.join(ROOT, "INTEGRATION.md")).read(), flags=re.M))
+    assert found == documented and len(found) == 12, (sorted(found - documented), sorted(documented - found))
+
+
+def test_reference_state_draw_reproduces_the_reference(golden):
+    """VERDICT r05 missing #3: BetaVMC.state_draw = "reference" draws the many-body states as the reference does (src/VMC.py:90-96) -- after
+    the same torch.manual_seed the Counter of sorted state indices is the one the reference's seeded forward produced (g6_betavmc.npz:
+    keys / counts of three cases, captured by tests/golden/make_golden.py)."""
+    from collections import Counter
+    from fermiflow_amd.VMC import draw_states_reference
+    G = golden["g6_betavmc"]
+    for tag in ("boltz", "hot", "rand"):
+        nup, B, seed = (int(v) for v in G[f"{tag}_cfg"])
+        torch.manual_seed(seed)
+        idx = draw_states_reference(torch.tensor(G[f"{tag}_logits"]), B)
+        assert idx.dtype == torch.int64 and idx.shape == (B,) and bool((idx[1:] >= idx[:-1]).all())
+        got = Counter(idx.tolist())
+        assert list(got.keys()) == [int(k) for k in G[f"{tag}_keys"]] and list(got.values()) == [int(c) for c in G[f"{tag}_counts"]], tag
+
+
 def test_adjoint_workspace_serves_either_kernel_family():
     """ff_cnf_adjoint_workspace_bytes no longer depends on the mutable kernel family -- the size is the larger of the two
     layouts, so a family switch between the query and the call cannot overrun the caller's buffer."""

@@ -416,6 +416,41 @@ def test_matrix_core_kernel_every_block_count(nup, ndn, B):
         np.testing.assert_allclose(r[2], lap, rtol=1e-6, atol=1e-6)
 
 
+def test_rejected_first_steps_do_not_couple_the_walkers_of_a_wave():
+    """The four walkers of a matrix-core wave advance in lockstep (csrc/ff_eloc_mfma.h): when one of them rejects a step, all pass through
+    stage 0 again -- which must not change anybody's numbers.  Nine walkers of 3 + 3 particles opened with the WHOLE interval as first
+    step (rejected for most of them) in one call against the same nine, one call each: every output identical, rejections and attempted
+    steps counted once; also with an explicit order and as a batch of five; and against the oracle.  (Written for round 6's retry queue
+    -- docs/attic/retry_queue_r06.patch, DESIGN.md 3p -- whose retried integrations had to be the in-place ones bit for bit; kept as the
+    invariant it checks.)"""
+    import subprocess, sys, json, os
+    code = ("import numpy as np, json; from tests.hostsim import simlib as S; from tests.common import net_arrays; from oracle import oracle as O;"
+            "G=np.load('tests/golden/g5_gsvmc.npz'); eta,mu=net_arrays(G,'z2_nt_'); x=G['z2_nt_x'][:9]; net=S.Net(eta,mu,table=True);"
+            "ref=O.eloc(x,3,3,O.Net(eta,mu),2.0,rtol=1e-11,atol=1e-13); keys=('eloc','logp','lap','grad','z','dlogp','glogp0')\n"
+            "def run(xx, order=None):\n"
+            "    h=np.ones(len(xx)); steps=np.zeros(len(xx),dtype=np.int32); S.warm(h_init=h, h_scale=1.0)\n"
+            "    try:\n"
+            "        r=S.eloc(xx,3,3,net,2.0,rtol=1e-7,atol=1e-9,steps=steps,order=order)\n"
+            "    finally:\n"
+            "        S.warm()\n"
+            "    return [[r[k].tolist() for k in keys], r['stats'].tolist(), steps.tolist()]\n"
+            "batch=run(x); ordered=run(x, order=np.array([8,3,5,0,7,1,6,2,4],dtype=np.int32)); five=run(x[:5]); singles=[run(x[i:i+1]) for i in range(9)]\n"
+            "print(json.dumps([batch, ordered, five, singles, ref['eloc'].tolist()]))")
+    env = dict(os.environ, FF_ELOC_KERNEL="mfma")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    batch, ordered, five, singles, el = json.loads(out.decode().strip().splitlines()[-1])
+    assert batch[1][3] == 0 and batch[1][2] >= 3, batch[1]                        # no failure; at least three first steps were rejected
+    for k in range(7):
+        for i in range(9):
+            assert batch[0][k][i] == singles[i][0][k][0], (k, i)                  # bit for bit the in-place retry
+            assert ordered[0][k][i] == batch[0][k][i], (k, i)
+        for i in range(5):
+            assert five[0][k][i] == batch[0][k][i], (k, i)
+    assert batch[1][2] == sum(sg[1][2] for sg in singles)                        # rejected steps: counted once per walker
+    assert batch[2] == [sg[2][0] for sg in singles]                              # attempted steps per walker (walker_cost)
+    np.testing.assert_allclose(batch[0][0], el, rtol=2e-6)
+
+
 def test_local_energy_routing_by_cost_class():
     """launch_mfma (csrc/ff_cnf_fwd.hip): with cost classes the walkers of class >= ff_ode.heavy_class (default 12 below 12 coordinates) are integrated by the
     one-walker-per-wave kernel (csrc/ff_wide.hip), the others by the four-walkers-per-wave matrix-core kernel.  Every walker is
