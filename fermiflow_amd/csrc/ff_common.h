@@ -104,6 +104,9 @@ FF_D double ff_swap2(double v) {
 
 // value of v on lane src (any lane of the wave; two ds_bpermute_b32: the LDS crossbar, no LDS memory)
 FF_D double ff_lane_read(double v, int src) {
+#ifdef FF_DIAG_NO_BPERMUTE      // (timing diagnostic: no LDS crossbar round trip; the numbers are then wrong)
+  return v;
+#endif
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
   return __hiloint2double(hi, lo);

@@ -13,7 +13,9 @@
 #include "ff_common.h"
 
 #define FF_TAB_RMAX 32.0
+#ifndef FF_TAB_ROW
 #define FF_TAB_ROW 10                       // doubles per node (9 used; 80-byte rows keep 16-byte alignment)
+#endif
 #define FF_TAB_MAXLOG 9                     // finest grid: h = 2^-9
 #define FF_TAB_NMAX (32 * (1 << FF_TAB_MAXLOG) + 1)
 #define FF_TAB_HDR 16                       // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used,
@@ -96,7 +98,10 @@ __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __res
   }
   w = sm[0];
   // (w h/2)^6/720 <~ 1e-15  <=>  w h <= 0.06
-  int lg = 6;
+#ifndef FF_TAB_MINLOG
+#define FF_TAB_MINLOG 6
+#endif
+  int lg = FF_TAB_MINLOG;
   while (lg < FF_TAB_MAXLOG && w * ldexp(1.0, -lg) > 0.06) lg++;
   const bool bad = !(w * ldexp(1.0, -lg) <= 0.06);
   const double hstep = ldexp(1.0, -lg);
@@ -144,7 +149,8 @@ __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __res
       double* row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + j) * FF_TAB_ROW;
 #pragma unroll
       for (int n = 0; n < 9; n++) row[n] = acc[n];
-      row[9] = 0.0;
+#pragma unroll
+      for (int n = 9; n < FF_TAB_ROW; n++) row[n] = 0.0;
     }
   }
 }
@@ -158,7 +164,11 @@ FF_D bool ff_table_fetch(const double* __restrict__ tab, double inv_h, double h,
   if (!(r < FF_TAB_RMAX)) return false;
   const double jf = rint(r * inv_h);
   dr = fma(-jf, h, r);
+#ifdef FF_DIAG_TAB_ROW0      // (timing diagnostic: every lane reads ONE row -- what the table's cache misses cost; the numbers are then wrong)
+  const double* __restrict__ row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + 100) * FF_TAB_ROW;
+#else
   const double* __restrict__ row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + (int)jf) * FF_TAB_ROW;
+#endif
 #pragma unroll
   for (int e = 0; e < NH + 5; e++) T[e] = row[e];
   return true;

@@ -1,5 +1,5 @@
-# the round's evidence set: bench lines of all four workloads, kernel tables, per-kernel counters  ->  gpurun_out/<tag>_*
-tag=${1:-r05x}
+# round 6 evidence set: bench lines of all four workloads, kernel tables, per-kernel counters  ->  gpurun_out/<tag>_*
+tag=${1:-r06z}
 set -x
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python bench.py --workload beta --steps 20 --warmup 5 > gpurun_out/${tag}_bench_beta.json 2>/dev/null
@@ -7,6 +7,7 @@ python bench.py --workload n12 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_n
 python bench.py --workload c5 --steps 5 --warmup 2 > gpurun_out/${tag}_bench_c5.json 2>/dev/null
 bash tools/prof_stats.sh ${tag} > /dev/null 2>&1
 bash tools/prof_stats.sh ${tag}_beta --workload beta > /dev/null 2>&1
+bash tools/prof_stats.sh ${tag}_n12 --workload n12 > /dev/null 2>&1
 bash tools/prof_stats.sh ${tag}_c5 --workload c5 --steps 3 --warmup 1 > /dev/null 2>&1
 python tools/pmc_kernels.py gpurun_out/${tag}_kernels_pmc.json > gpurun_out/${tag}_pmc.log 2>&1
 # the long window (the flow trains: three steps per walker where two did), the learned first-step table and the adjoint over it, kernel timeline of its last iterations
