@@ -41,11 +41,6 @@ struct ff_adj_args {
   double* gx_out;       // (B, M)  gradient wrt x = z(t1); may be NULL
   double* rows;         // (gridDim.x * G, 3He+3Hm) per-(workgroup, group-slot) parameter-gradient partials (direct kernel)
   double* trows;        // (gridDim.x, 2, FF_DEP_NLDS, FF_DEP_ROW) private coefficient tables, then Wtot (tabulated kernel)
-  // (gridDim.x, 4) which of the 256 rows of a private table its workgroup wrote this call (bit row & 63 of word row >> 6): a radius
-  // deposits about its nearest node, and three quarters of the nodes lie beyond every radius of the batch -- those rows are neither
-  // flushed nor read back (round 6: HBM bytes of the launch 51.6 -> 39.8 MB at config 2 -- about half of a table's rows are touched by
-  // the ~200 walkers of a workgroup --, time unchanged; profiles/r06_n_kernels_pmc.json).  NULL: every row is current (ff_adj_wide.h).
-  unsigned long long* tmask;
   double* off_table;    // one double, zeroed per call: set to 1 when a radius falls off the deposit table
   int32_t* stats;
   const double* h_init;    // optional (B): first step size to try for every walker (ff_ode.walker_h_init), times h_scale
@@ -604,24 +599,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
     if (lane == 0) __hip_atomic_store(&s_done[wv], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();      // (the one workgroup barrier: every wave has made its last deposit)
-  // flush the workgroup-private coefficient table: the rows something was deposited on, and the mask that says which
+  // flush the workgroup-private coefficient table
   {
-    double* tab = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
-    constexpr int NROW = 2 * FF_DEP_NLDS;
-    static_assert(NROW % FF_WAVE == 0 && NROW / FF_WAVE <= 4, "row mask: four 64-bit words per table");
-    for (int rw = threadIdx.x; rw < NROW; rw += FF_WAVE * WPW) {      // (wave-uniform trip count: every lane of a wave votes)
-      const double* src = &s_W[0][0][0] + (size_t)rw * FF_DEP_LROW;
-      double v[FF_DEP_ROW];
-      bool nz = false;
-#pragma unroll
-      for (int k = 0; k < FF_DEP_ROW; k++) { v[k] = src[k]; nz = nz || (v[k] != 0.0); }      // (NaN -- a failed walker's poison -- counts)
-      if (nz || !A.tmask) {
-#pragma unroll
-        for (int k = 0; k < FF_DEP_ROW; k++) tab[(size_t)rw * FF_DEP_ROW + k] = v[k];
-      }
-      const unsigned long long m = ff_wave_ballot(nz);
-      if (A.tmask && lane == 0) A.tmask[(size_t)blockIdx.x * 4 + (rw >> 6)] = m;
-    }
+    double* row = A.trows + (size_t)blockIdx.x * 2 * FF_DEP_NLDS * FF_DEP_ROW;
+    for (int e = threadIdx.x; e < 2 * FF_DEP_NLDS * FF_DEP_ROW; e += FF_WAVE * WPW) row[e] = (&s_W[0][0][0])[(e / FF_DEP_ROW) * FF_DEP_LROW + e % FF_DEP_ROW];
   }
   __syncthreads();
   if (A.stats && threadIdx.x == 0 && (s_st[0] || s_st[3])) {
@@ -646,8 +627,7 @@ extern int ff_wide_supported(int n, int d);
 // tabulated kernel's private deposit tables (only if the tabulated kernel served the call)
 __global__ void __launch_bounds__(FF_DEPR_EX * FF_DEPR_TY)
 ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows, int P, const double* __restrict__ prow,
-                     double* __restrict__ out, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot,
-                     const unsigned long long* __restrict__ tmask) {
+                     double* __restrict__ out, int nblocks, const double* __restrict__ rows, double* __restrict__ wtot) {
   FF_SETPRIO();
   const double* rtab = net.radial_table;
   const bool tab_served = rtab && rtab[3] == 0.0 && rtab[4] == 0.0 && *off_table == 0.0;
@@ -679,21 +659,14 @@ ff_adj_reduce_kernel(ff_net net, const double* __restrict__ off_table, int nrows
   // the prefetched Metropolis kernel, which owns most of the issue slots -- what decides its time is how soon its waves get placed.)
   double sp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (e < NE) {
-    // a table's row is read only if its workgroup wrote it this call (ff_adj_args::tmask; an unwritten row holds an earlier call's
-    // numbers) -- what is skipped is a row of zeros, so the sums are the ones the unmasked reduction forms, bit for bit
-    const int rw = e / FF_DEP_ROW, mw = rw >> 6, mb = rw & 63;
-    auto term = [&](int bb) -> double {
-      if (tmask && !((tmask[(size_t)bb * 4 + mw] >> mb) & 1ULL)) return 0.0;
-      return rows[(size_t)bb * NE + e];
-    };
     int b = ty;
     for (; b + 7 * FF_DEPR_TY < nblocks; b += 8 * FF_DEPR_TY) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) sp[u] += term(b + u * FF_DEPR_TY);
+      for (int u = 0; u < 8; u++) sp[u] += rows[(size_t)(b + u * FF_DEPR_TY) * NE + e];
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
-      if (b + u * FF_DEPR_TY < nblocks) sp[u] += term(b + u * FF_DEPR_TY);
+      if (b + u * FF_DEPR_TY < nblocks) sp[u] += rows[(size_t)(b + u * FF_DEPR_TY) * NE + e];
   }
   sm[ty][tx] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
   __syncthreads();
@@ -861,8 +834,7 @@ static size_t adj_ws_doubles(bool wide, int64_t B, int n, int d, int He, int Hm)
   if (wide) return ff_wide_supported(n, d) ? adj_direct_doubles(B, 1, He, Hm) + adj_table_doubles(B, 1) + 1 + (size_t)B : 0;   // (+ B: opening steps, ff_ode.walker_h_equal)
   const bool narrow = (d == 2 && n >= 1 && n <= 12) || (d == 3 && n >= 2 && n <= 4);
   const int G = adj_G(n, d);
-  // (+ four mask words per private table behind the off-table flag: ff_adj_args::tmask)
-  return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d) * FF_ADJ_WPW) + 1 + 4 * (size_t)adj_grid(B, adj_tab_G(n, d) * FF_ADJ_WPW) : 0;
+  return (narrow && G) ? adj_direct_doubles(B, G, He, Hm) + adj_table_doubles(B, adj_tab_G(n, d) * FF_ADJ_WPW) + 1 : 0;
 }
 
 // The larger of the two families' layouts: which family a call uses is decided when it runs (ff_set_kernel_family / FF_WIDE may
@@ -918,7 +890,6 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     if (Gq == 0) { ff_set_error("ff_cnf_adjoint: n*d > 64"); return FF_EUNSUPPORTED; }
     a.trows = a.rows + adj_direct_doubles(B, Gq, net->He, net->Hm);
     a.off_table = a.trows + adj_table_doubles(B, wide ? 1 : adj_tab_G(n, d) * FF_ADJ_WPW);
-    a.tmask = wide ? nullptr : reinterpret_cast<unsigned long long*>(a.off_table + 1);
   }
   if (wide) {      // (those kernels accumulate in their global rows and tables)
     if (hipMemsetAsync(workspace, 0, sizeof(double) * adj_ws_doubles(wide, B, n, d, net->He, net->Hm), (hipStream_t)stream) != hipSuccess) return FF_ELAUNCH;
@@ -967,8 +938,7 @@ static int adjoint_impl(void* stream, int64_t B, int n, int d, const ff_net* net
     double* wtot = a.trows + (size_t)ntab * 2 * FF_DEP_NLDS * FF_DEP_ROW;
     const unsigned ndep = net->radial_table ? (unsigned)((2 * FF_DEP_NLDS * FF_DEP_ROW + FF_DEPR_EX - 1) / FF_DEPR_EX) : 0u;
     FF_LAUNCH(ff_adj_reduce_kernel, (unsigned)P + ndep, FF_DEPR_EX * FF_DEPR_TY, stream, *net, (const double*)a.off_table, nblk * G, P,
-              (const double*)a.rows, grad_params, ntab, (const double*)(net->radial_table ? a.trows : nullptr), wtot,
-              (const unsigned long long*)a.tmask);
+              (const double*)a.rows, grad_params, ntab, (const double*)(net->radial_table ? a.trows : nullptr), wtot);
     FF_LAUNCH_CHECK();
   }
   if (net->radial_table) {
