@@ -1119,6 +1119,39 @@ def test_fused_adam_equals_torch_adam(dev):
     with pytest.raises(RuntimeError):
         FusedAdam([q], lr=1e-2).step()
     assert isinstance(make_adam([q], lr=1e-2), torch.optim.Adam)
+    # an amsgrad / maximize state is refused (not run as plain Adam), and a refused step moves no step count
+    oam = torch.optim.Adam(ma.parameters(), lr=1e-2, amsgrad=True)
+    oam.step()
+    with pytest.raises(RuntimeError):
+        FusedAdam(ma.parameters(), lr=1e-2).load_state_dict(oam.state_dict())
+    good = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64, device=dev)); good.grad = torch.ones_like(good)
+    mixed = FusedAdam([good, q], lr=1e-2)
+    with pytest.raises(RuntimeError):
+        mixed.step()
+    assert len(mixed.state[good]) == 0      # validated before anything was counted
+
+
+def test_sweep_scalar_backward_short_cut_equals_autograd(dev):
+    """The scalar a sweep returns hands its pre-computed gradient to .grad directly when the training loop calls `.backward()` on it
+    (VMC._SweepScalar); `model.fast_backward = False` -- what a model wrapped in DistributedDataParallel sets -- takes the
+    ordinary autograd path: the same gradients, and a schedule state on another device follows the walkers (_h_counts)."""
+    import __graft_entry__ as Gm
+    grads = []
+    for fast in (True, False):
+        model = Gm._model(dev, 3, 3, 2.0)
+        model.fast_backward = fast
+        torch.manual_seed(9)
+        g = model(4096)
+        assert hasattr(g, "_ff_fast") == fast
+        g.backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    from fermiflow_amd import native
+    cost = torch.zeros(64, dtype=torch.int32, device=dev); hg = torch.full((64,), 0.5, dtype=torch.float64, device=dev)
+    tab = torch.ones(2, 32, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):      # counts on the host: refused, not handed to a kernel as a device pointer
+        native.walker_schedule(cost, hg, tab[0], tab[1], None, interval=1.0, counts=torch.zeros(native.SCALE_COUNTS, dtype=torch.float64), shrink_at=0.1)
 
 
 def test_walker_prefetch_changes_nothing_but_the_schedule(dev):

@@ -273,6 +273,26 @@ def test_reference_state_draw_reproduces_the_reference(golden):
         assert list(got.keys()) == [int(k) for k in G[f"{tag}_keys"]] and list(got.values()) == [int(c) for c in G[f"{tag}_counts"]], tag
 
 
+def test_fused_adam_refuses_what_it_does_not_implement():
+    """FusedAdam.load_state_dict copies torch.optim.Adam's param_groups -- a state saved with amsgrad or maximize must not be
+    continued as plain Adam (no GPU needed: the refusal happens before any launch)."""
+    from fermiflow_amd.utils import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))
+    for kw in ({"amsgrad": True}, {"maximize": True}):
+        ref = torch.optim.Adam([p], lr=1e-2, **kw)
+        p.grad = torch.ones_like(p)
+        ref.step()
+        with pytest.raises(RuntimeError):
+            FusedAdam([p], lr=1e-2).load_state_dict(ref.state_dict())
+    ok = torch.optim.Adam([p], lr=1e-2)
+    ok.step()
+    opt = FusedAdam([p], lr=1e-2)
+    opt.load_state_dict(ok.state_dict())
+    with pytest.raises(RuntimeError):      # a CPU parameter: refused by step(), and its step count stays where the state dict left it
+        opt.step()
+    assert float(opt.state[p]["step"]) == 1.0
+
+
 def test_adjoint_workspace_serves_either_kernel_family():
     """ff_cnf_adjoint_workspace_bytes no longer depends on the mutable kernel family -- the size is the larger of the two
     layouts, so a family switch between the query and the call cannot overrun the caller's buffer."""
