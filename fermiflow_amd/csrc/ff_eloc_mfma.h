@@ -241,8 +241,14 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       const double g1 = fma(hs, a1, s == 5 ? 1.0 : 0.0), g2 = fma(hs, a2, s == 6 ? 1.0 : 0.0);
       if (s == -1) g0 = s_ctl[w].h0v * s_ctl[w].S.dir;      // (cold start only: the probe evaluation of Hairer's rule)
       auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y.get(v)))); };
+      // The J blocks of y live in LDS columns, and stages 4-6 take their input from c0 / c1 / c2 alone: those stages skip the nine LDS
+      // reads (twice per evaluation) -- the kernel is bound by the LDS, not by what it issues.  (From stage 5 on c0
+      // carries the error accumulator, times g0 = 0 here: finite for every walker that is still integrating.  A run-time select among
+      // c0 / c1 / c2 instead would put all three arrays into scratch: 336 B per lane.)
+      const bool use_y = s <= 3;
+      auto form_noy = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], g0 * c0[v])); };
       double out[NV];
-      const double zin = form(0), kin = form(IK);
+      const double zin = use_y ? form(0) : form_noy(0), kin = use_y ? form(IK) : form_noy(IK);
       FF_STAMP(0);
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ publish z, kbar
@@ -279,8 +285,13 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       // ------------------------------------------------------------------ S = J J^T on the matrix cores
       {
         double Jt[NB];      // the blocks transposed in place: lane (r, c) <-> (c, r)
+        if (use_y) {
 #pragma unroll
-        for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form(1 + e), tl);
+          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form(1 + e), tl);
+        } else {
+#pragma unroll
+          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form_noy(1 + e), tl);
+        }
         double* Sw = s_A[w];
 #pragma unroll
         for (int I = 0; I < MB; I++) {
@@ -290,7 +301,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
             for (int K = 0; K < MB; K++) acc = ff_mfma4(Jt[I * MB + K], Jt[Kc * MB + K], acc);
             Sw[(4 * I + r) * AS + 4 * Kc + c] = acc;
-            if (Kc != I) Sw[(4 * Kc + c) * AS + 4 * I + r] = acc;
+            // (the mirrored half of an off-diagonal block is read by nobody in the right-hand side: W needs S_aa, S_bb -- inside the
+            // diagonal blocks, D divides 4 -- and S_ab with a < b, the upper triangle; the finish forms its own S, both halves)
+            if (Kc != I && 4 % D != 0) Sw[(4 * Kc + c) * AS + 4 * I + r] = acc;
           }
         }
       }
@@ -328,13 +341,24 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           // W = S_aa + S_bb - S_ab - S_ba (S_aa for a one-body radius);  w1 = W rho, q = rho^T W rho / r^2
           const double* Sg = s_A[w];
           double w1[D], dk[D], qq = 0.0, tr = 0.0, rdk = 0.0;
+          // (W is symmetric -- S is, element for element: both halves of a block pair are one accumulator, and the two lanes of a
+          // diagonal block form the same products in the same order -- so only c2i >= cc is read: 12 LDS reads per pair instead of 16)
+          double Ws[D][D];
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+#pragma unroll
+            for (int c2i = cc; c2i < D; c2i++) {
+              double ww = Sg[(a * D + cc) * AS + a * D + c2i];
+              if (pair) ww += (Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i]) - Sg[(a * D + c2i) * AS + bb * D + cc];
+              Ws[cc][c2i] = ww; Ws[c2i][cc] = ww;
+            }
+          }
 #pragma unroll
           for (int cc = 0; cc < D; cc++) {
             double t = 0.0;
 #pragma unroll
             for (int c2i = 0; c2i < D; c2i++) {
-              double ww = Sg[(a * D + cc) * AS + a * D + c2i];
-              if (pair) ww += (Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i]) - Sg[(a * D + c2i) * AS + bb * D + cc];
+              const double ww = Ws[cc][c2i];
               t = fma(ww, rho[c2i], t);
               if (c2i == cc) tr += ww;
             }
@@ -377,7 +401,14 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           FF_OPAQUE(pk);
           const double* rec = &s_rec[pk >> 1];
           const int smask = (int)((unsigned)pk << 31);                                        // the sign of this partner's odd terms, as a sign bit
-          const double f0 = rec[QF0], ru = rec[rc], fc = rec[QF1] * ru;
+          // (rho is read once, both components, and the lane's own one selected: rec[rc] beside rec[0 .. D) was a seventh LDS read per partner)
+          double rh[D];
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) rh[cc] = rec[cc];
+          double ru = rh[0];
+#pragma unroll
+          for (int cc = 1; cc < D; cc++) ru = (rc == cc) ? rh[cc] : ru;
+          const double f0 = rec[QF0], fc = rec[QF1] * ru;
           const double rcv = __hiloint2double(__double2hiint(ru) ^ smask, __double2loint(ru));
           const double pw = rec[QPW + rc];
           vi = fma(f0, rcv, vi);
@@ -386,7 +417,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           double* ablk = arow + k * D;       // (k == own particle: overwritten by the diagonal block below)
 #pragma unroll
           for (int cc = 0; cc < D; cc++) {
-            const double Bcc = fma(fc, rec[cc], f0 * dsel[cc]);               // B = eta I + (eta'/r) rho rho^T, row rc
+            const double Bcc = fma(fc, rh[cc], f0 * dsel[cc]);               // B = eta I + (eta'/r) rho rho^T, row rc
             Ad[cc] += Bcc;
             ablk[cc] = -Bcc;
           }
@@ -401,8 +432,13 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       // ------------------------------------------------------------------ J' = A J on the matrix cores, (grad Delta)' = -J^T g
       {
         double Jin[NB];
+        if (use_y) {
 #pragma unroll
-        for (int e = 0; e < NB; e++) Jin[e] = form(1 + e);
+          for (int e = 0; e < NB; e++) Jin[e] = form(1 + e);
+        } else {
+#pragma unroll
+          for (int e = 0; e < NB; e++) Jin[e] = form_noy(1 + e);
+        }
         const double* Aw = s_A[w];
 #pragma unroll
         for (int I = 0; I < MB; I++) {
@@ -417,21 +453,35 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             out[1 + I * MB + Kc] = acc;
           }
         }
-        // component 4K + c of g^T J: sum over the rows 4I + r -- over I on the lane, over r across the walker's four quads; the
-        // lane keeps the component of its own coordinate p = 4r + c
-        double dd = 0.0;
+        // Component 4K + c of g^T J is a sum over the rows 4I + r: over I on the lane, over r across the walker's four quads; the lane
+        // keeps the component of its own coordinate p = 4r + c.
+        // Four sums over the walker's four quads (r), each wanted by ONE quad: components K = 0, 1, 2 by the lanes r = K, and the two
+        // scalars -- Delta' = -div v and (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar), summed over the quad by DPP first -- by the
+        // spare lanes p = 12, 13 (r = 3, c = 0, 1) that integrate them.  A reduce-scatter: two values across lane ^ 32, one across
+        // lane ^ 16 -- three exchanges through the LDS crossbar where three all-reduces + two walker sums took ten (round 6: the kernel
+        // is bound by the LDS).
+        double tt[4];
 #pragma unroll
-        for (int K = 0; K < MB; K++) {
+        for (int K = 0; K < 3; K++) {
           double t = 0.0;
+          if (K < MB) {
 #pragma unroll
-          for (int I = 0; I < MB; I++) t = fma(s_gd[w][4 * I + r], Jin[I * MB + K], t);
-          t += ff_lane_read(t, ln ^ 16);
-          t += ff_lane_read(t, ln ^ 32);
-          dd = (r == K) ? t : dd;
+            for (int I = 0; I < MB; I++) t = fma(s_gd[w][4 * I + r], Jin[I * MB + K], t);
+          }
+          tt[K] = t;
         }
-        // Delta' = -div v and (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar): summed over the walker's lanes, integrated by two spare ones
-        const double dtot = walker_sum(dsum), qtot = walker_sum(fma(gdi, kin, qsum));
-        out[0] = owner ? vi : (p == PDL ? -dtot : (p == PLP ? -qtot : 0.0));
+        {
+          double ds4 = dsum, qs4 = fma(gdi, kin, qsum);
+          ds4 += ff_swap1(ds4); ds4 += ff_swap2(ds4);
+          qs4 += ff_swap1(qs4); qs4 += ff_swap2(qs4);
+          tt[3] = c == 0 ? ds4 : qs4;
+        }
+        const bool lo2 = r < 2, ev = (r & 1) == 0;
+        const double ka = (lo2 ? tt[0] : tt[2]) + ff_lane_read(lo2 ? tt[2] : tt[0], ln ^ 32);      // index 0 (r < 2) or 2
+        const double kb2 = (lo2 ? tt[1] : tt[3]) + ff_lane_read(lo2 ? tt[3] : tt[1], ln ^ 32);     // index 1 or 3
+        const double res = (ev ? ka : kb2) + ff_lane_read(ev ? kb2 : ka, ln ^ 16);                  // the total of index r
+        const double dd = r < 3 ? res : 0.0;
+        out[0] = owner ? vi : ((p == PDL || p == PLP) ? -res : 0.0);
         out[IK] = wk;                         // (row lanes beyond M read the zero record: all their sums vanish)
         out[IDD] = -dd;
       }
@@ -515,14 +565,14 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         for (int v = 0; v < NV; v++) {
           c1[v] = fma(hs * FF_A54, out[v], c1[v]);
           c2[v] = fma(hs * FF_B4, out[v], c2[v]);
-          c3.set(v, fma(hs * FF_E4, out[v], c3.get(v)));
-        }
+          c0[v] = fma(hs * FF_E4, out[v], c3.get(v));      // c0 -- the input of this stage -- is free now: the error accumulator lives there
+        }                                                   // through stages 5 and 6 (its LDS columns: one write at stage 3, one read here)
         s = 5;
       } else if (s == 5) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c2[v] = fma(hs * FF_B5, out[v], c2[v]);
-          c3.set(v, fma(hs * FF_E5, out[v], c3.get(v)));
+          c0[v] = fma(hs * FF_E5, out[v], c0[v]);
         }
         s = 6;
       } else {
@@ -531,7 +581,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         double pe = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double e = fma(hs * FF_E6, out[v], c3.get(v)), yv = y.get(v);
+          const double e = fma(hs * FF_E6, out[v], c0[v]), yv = y.get(v);
           const double t = e * wgt(v) * ff_rcp(fma(fmax(fabs(yv), fabs(c2[v])), rtol, atol));   // c2 = the candidate y_new
           pe = fma(t, t, pe);
         }
