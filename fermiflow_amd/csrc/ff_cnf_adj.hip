@@ -426,13 +426,13 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           // own rows: +x to particle a from partner bb, -x to particle bb from partner a
           const double f0 = hd[0], f1 = hd[1], f2 = hd[2];
           const double F1 = f1 * (al * ri), gq = (pair ? 2.0 : 1.0) * fma(f2, r, (1.0 + D) * f1) * ri;
+          // ONE entry per radius, in the row of its first particle (a < bb): the lanes of particle bb read it there with the other sign
+          // (round 6: six LDS stores per pair where the mirrored entry took twelve -- this kernel, too, lives on the LDS)
           double* Ta = &s_T[qg][a][bb * 3 * D];
-          double* Tb = &s_T[qg][bb][a * 3 * D];
 #pragma unroll
           for (int c = 0; c < D; c++) {
             const double pv = f0 * rho[c], pw = fma(F1, rho[c], f0 * dl[c]), pg = gq * rho[c];
             Ta[c] = pv; Ta[D + c] = pw; Ta[2 * D + c] = pg;
-            if (pair) { Tb[c] = -pv; Tb[D + c] = -pw; Tb[2 * D + c] = -pg; }
           }
         }
       }
@@ -443,12 +443,14 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       double out[NV];
       {
         double vi = 0.0, dvk = 0.0, gdi = 0.0;
-        const double* T = &s_T[gg][ai][ci];
 #pragma unroll
         for (int j = 0; j < N; j++) {
           const bool use = has_mu || j != ai;
-          const double tv = T[j * 3 * D], tw = T[j * 3 * D + D], tg = T[j * 3 * D + 2 * D];
-          vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
+          const bool lower = j < ai;      // the pair (j, ai) sits in row j, slot ai, written from particle j's side: the other sign
+          const double* T = lower ? &s_T[gg][j][ai * 3 * D + ci] : &s_T[gg][ai][j * 3 * D + ci];
+          const double sg = lower ? -1.0 : 1.0;
+          const double tv = T[0], tw = T[D], tg = T[2 * D];
+          vi = fma(sg, use ? tv : 0.0, vi); dvk = fma(sg, use ? tw : 0.0, dvk); gdi = fma(sg, use ? tg : 0.0, gdi);
         }
         out[0] = vi;
         out[1] = fma(s_ad[gg], gdi, -dvk);

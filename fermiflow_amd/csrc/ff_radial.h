@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __res
     if (live && part == 0) {
       double* row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + j) * FF_TAB_ROW;
 #pragma unroll
-      for (int n = 0; n < 9; n++) row[n] = acc[n];
+      for (int n = 0; n < 9 && n < FF_TAB_ROW; n++) row[n] = acc[n];
 #pragma unroll
       for (int n = 9; n < FF_TAB_ROW; n++) row[n] = 0.0;
     }
@@ -169,21 +169,24 @@ FF_D bool ff_table_fetch(const double* __restrict__ tab, double inv_h, double h,
 #else
   const double* __restrict__ row = tab + FF_TAB_HDR + ((size_t)t * FF_TAB_NMAX + (int)jf) * FF_TAB_ROW;
 #endif
+  constexpr int NT = NH + 5 < FF_TAB_ROW ? NH + 5 : FF_TAB_ROW;      // (a row holds FF_TAB_ROW derivatives: the highest heads expand to fewer orders)
 #pragma unroll
-  for (int e = 0; e < NH + 5; e++) T[e] = row[e];
+  for (int e = 0; e < NT; e++) T[e] = row[e];
   return true;
 }
 
 template <int NH>
 FF_D void ff_table_eval(const double* T, double dr, double* hd) {
-  const double d2 = dr * 0.5, d3 = dr * (1.0 / 3.0), d4 = dr * 0.25, d5 = dr * 0.2;
+  constexpr int NT = NH + 5 < FF_TAB_ROW ? NH + 5 : FF_TAB_ROW;
+  const double dk[5] = {dr, dr * 0.5, dr * (1.0 / 3.0), dr * 0.25, dr * 0.2};
 #pragma unroll
   for (int m = 0; m < NH; m++) {
-    double v = fma(T[m + 5], d5, T[m + 4]);
-    v = fma(v, d4, T[m + 3]);
-    v = fma(v, d3, T[m + 2]);
-    v = fma(v, d2, T[m + 1]);
-    hd[m] = fma(v, dr, T[m]);
+    const int top = m + 5 < NT ? m + 5 : NT - 1;      // (compile-time after unrolling)
+    double v = T[top];
+#pragma unroll
+    for (int k = 4; k >= 0; k--)
+      if (m + k < top) v = fma(v, dk[k], T[m + k]);
+    hd[m] = v;
   }
 }
 
