@@ -246,6 +246,7 @@ template <class TE, int NV, int NTHR, bool IN_LDS>
 struct ff_wide_vec;
 template <class TE, int NV, int NTHR>
 struct ff_wide_vec<TE, NV, NTHR, false> {
+  static constexpr bool in_lds = false;
   TE r[NV];
   FF_D ff_wide_vec(TE*, int) {}
   FF_D TE& operator[](int v) { return r[v]; }
@@ -253,6 +254,7 @@ struct ff_wide_vec<TE, NV, NTHR, false> {
 };
 template <class TE, int NV, int NTHR>
 struct ff_wide_vec<TE, NV, NTHR, true> {
+  static constexpr bool in_lds = true;
   TE* col;
   FF_D ff_wide_vec(TE* base, int tid) : col(base + tid) {}
   FF_D TE& operator[](int v) { return col[v * NTHR]; }
@@ -479,8 +481,13 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       // it is the B operand of J' = A J)
       auto formJ = [&](int v) -> TJ { return ff_t_fma(g2J, c2J[v], ff_t_fma(g1J, c1J[v], ff_t_fma(g0J, c0J[v], gyJ * yJ[v]))); };
       TJ Jin[NVJ];
+      if (!Y_LDS || s <= 3) {
 #pragma unroll
-      for (int v = 0; v < NVJ; v++) Jin[v] = formJ(v);
+        for (int v = 0; v < NVJ; v++) Jin[v] = formJ(v);
+      } else {      // stages 4-6 take their input from c0 / c1 / c2 alone: no LDS read of y's J part (from stage 5 on c0 holds the error accumulator, times 0)
+#pragma unroll
+        for (int v = 0; v < NVJ; v++) Jin[v] = ff_t_fma(g2J, c2J[v], ff_t_fma(g1J, c1J[v], g0J * c0J[v]));
+      }
       const double kb_in = form(IK);
       if (own) { s_z[rp] = form(IZ); s_kb[rp] = kb_in; }
 #pragma unroll
