@@ -317,11 +317,11 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
 
     auto group_sum = [&](double part) -> double {
       if (ingrp) s_err[g][i] = part;
-      FF_WAVE_SYNC();
+      FF_WAVE_ORDER();
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < M; j++) t += s_err[gg][j];
-      FF_WAVE_SYNC();
+      FF_WAVE_ORDER();
       return t;
     };
 
@@ -373,9 +373,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
       }
       FF_STAMP(0);
-      FF_WAVE_SYNC();
+      FF_WAVE_ORDER();
       if (ingrp) { s_z[g][i] = in[0]; s_kb[g][i] = in[1]; }
-      FF_WAVE_SYNC();
+      FF_WAVE_ORDER();
       FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase (lane <-> radius)
       ff_rec cur[NSLOT];
@@ -436,7 +436,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           }
         }
       }
-      FF_WAVE_SYNC();
+      FF_WAVE_ORDER();
       nev++;
       FF_STAMP(2);
       // ------------------------------------------------------------------ component phase: sum the own rows
@@ -546,7 +546,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
         // step size of every walker whose step was accepted (0 otherwise), for the lanes that hold its radii
         if (ingrp && i == 0) s_hw[g] = acc ? h : 0.0;
-        FF_WAVE_SYNC();
+        FF_WAVE_ORDER();
 #ifndef FF_ADJ_NOTICKET      // (timing experiments only: without the turns the sum order, hence the last bits, depend on timing)
         if constexpr (WPW > 1) {      // this wave's turn at the shared table (A0 B0 A1 B1 ...; a finished partner waives its turns)
           while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn &&
@@ -589,7 +589,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
-    FF_WAVE_SYNC();
+    FF_WAVE_ORDER();
   }
 #ifdef FF_STAMPS
   if (A.stats && lane == 0)

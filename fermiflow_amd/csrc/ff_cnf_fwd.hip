@@ -123,7 +123,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
     for (int a = 0; a < N; a++) { if (P + a < R) { s_pa[P + a] = a; s_pb[P + a] = -1; } }
   }
-  __syncthreads();
+  FF_WG1_SYNC();
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? (P + N) : P;
@@ -166,9 +166,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
   __shared__ long long s_next;
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
     if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
-      __syncthreads();
+      FF_WG1_SYNC();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
-      __syncthreads();
+      FF_WG1_SYNC();
       grp = s_next;
     }
     if (grp >= ngroups) break;
@@ -213,11 +213,11 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
     // group-wide sum of a per-lane partial (all lanes of a walker get the identical result)
     auto group_sum = [&](double part) -> double {
       if (ingrp) s_err[g][i] = part;
-      __syncthreads();
+      FF_WG1_SYNC();
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < M; j++) t += s_err[gg][j];
-      __syncthreads();
+      FF_WG1_SYNC();
       return t;
     };
     const double sens_w = loose ? A.sens_w : 1.0;
@@ -252,7 +252,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       };
       FF_STAMP(0);
       // ------------------------------------------------------------------ publish
-      __syncthreads();
+      FF_WG1_SYNC();
       {
         double pub[NV];
         form(pub, 0, MODE == 2 ? M + 2 : 1, MODE == 2 ? M + 1 : 1);   // slots 0 and (MODE 2) M+1 only
@@ -261,7 +261,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           if constexpr (MODE == 2) s_kb[g][i] = pub[M + 1];
         }
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(1);
       // ------------------------------------------------------------------ radius phase
       // (two halves: every radius of the wave is formed and -- table kernels -- its table row requested before the
@@ -343,7 +343,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           }
         }
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       nev++;
       FF_STAMP(2);
       // ------------------------------------------------------------------ right-hand side
@@ -370,7 +370,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
             vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
           }
         }
-        __syncthreads();
+        FF_WG1_SYNC();
         double du[M], qv[M];
 #pragma unroll
         for (int k = 0; k < M; k++) { du[k] = 0.0; qv[k] = 0.0; }
@@ -438,7 +438,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #pragma unroll
           for (int k = 0; k < M; k++) s_qt[(g * M + i) * QTW + k] = qv[k];
         }
-        __syncthreads();
+        FF_WG1_SYNC();
 #pragma unroll
         for (int j = 0; j < M; j++) sumq += s_qt[(gg * M + j) * QTW + i];
         FF_STAMP(3);
@@ -575,7 +575,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       for (int qk = 0; qk < NQ; qk++) {
         if (rq_id[qk] >= 0) s_rmin[rq_id[qk] & 15][rq_id[qk] >> 12] = rmin_q[qk];
       }
-      __syncthreads();
+      FF_WG1_SYNC();
     }
     if (valid) {
       // a walker whose integration failed (NaN error norm, max_steps) must not pass for a result: its outputs are NaN,
@@ -605,7 +605,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
       }
     }
-    __syncthreads();
+    FF_WG1_SYNC();
   }
 #ifdef FF_STAMPS
   if (A.stats && lane == 0)
@@ -632,7 +632,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
 #endif
 #endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  __syncthreads();
+  FF_WG1_SYNC();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
     atomicAdd(&A.stats[0], s_st[0]);
     atomicMax(&A.stats[1], s_st[1]);
@@ -704,7 +704,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       for (int b = a + 1; b < N; b++) { s_pa[p] = a; s_pb[p] = b; p++; }
     for (int a = 0; a < N; a++) { s_pa[P + a] = a; s_pb[P + a] = -1; }
   }
-  __syncthreads();
+  FF_WG1_SYNC();
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? R : P;
@@ -728,9 +728,9 @@ ff_eloc_split_kernel(ff_fwd_args A) {
   __shared__ long long s_next;
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
     if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
-      __syncthreads();
+      FF_WG1_SYNC();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
-      __syncthreads();
+      FF_WG1_SYNC();
       grp = s_next;
     }
     if (grp >= ngroups) break;
@@ -760,11 +760,11 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 
     auto group_sum = [&](double part) -> double {
       if (ingrp) s_err[g][idx] = part;
-      __syncthreads();
+      FF_WG1_SYNC();
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < L; j++) t += s_err[gg][j];
-      __syncthreads();
+      FF_WG1_SYNC();
       return t;
     };
     // slots 0 and MH+1 exist on owner lanes only; sensitivity components: their own tolerance (ff_ode.sens_tol)
@@ -789,13 +789,13 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 #pragma unroll
       for (int v = 0; v < NV; v++) in[v] = fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v])));
       // ------------------------------------------------------------------ publish z, kbar (owners) and the u halves
-      __syncthreads();
+      FF_WG1_SYNC();
       if (ingrp) {
         if (owner) { s_z[g][i] = in[0]; s_kb[g][i] = in[MH + 1]; }
 #pragma unroll
         for (int k = 0; k < MH; k++) s_u[g][i][h * MH + k] = in[1 + k];
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       // ------------------------------------------------------------------ radius phase (lane <-> radius)
       double rq_rho[NQ][D], rq_dk[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
       bool rq_ok[NQ];
@@ -862,7 +862,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
           if (pair) { Tb[c] = -pv; Tb[D + c] = -pw; Tb[2 * D + c] = -pg; }
         }
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       nev++;
       // ------------------------------------------------------------------ own rows (owner lanes), then the jet sweep
       double ddiv = 0.0, qdiv = 0.0, divv = 0.0, vi = 0.0, dvk = 0.0, gdi = 0.0;
@@ -875,7 +875,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
           vi += use ? tv : 0.0; dvk += use ? tw : 0.0; gdi += use ? tg : 0.0;
         }
       }
-      __syncthreads();   // s_qt is reused by the transposition below
+      FF_WG1_SYNC();   // s_qt is reused by the transposition below
       double du[MH], qv[MH];
 #pragma unroll
       for (int k = 0; k < MH; k++) { du[k] = 0.0; qv[k] = 0.0; }
@@ -943,7 +943,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
 #pragma unroll
         for (int k = 0; k < MH; k++) s_qt[g * QTS + (i * 2 + h) * (MH + 1) + k] = qv[k];
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       double sumq = 0.0;
       if (owner) {
         const int lc = i - h * MH;
@@ -1050,13 +1050,13 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     const double dpart = y[MH + 2], delpart = y[MH + 3], lpart = y[MH + 4];
     const double delta = group_sum(delpart) * (1.0 / M);    // every direction's two lanes cover all pairs once
     if (ingrp) s_err[g][idx] = dpart;
-    __syncthreads();
+    FF_WG1_SYNC();
     const double dD_i = s_err[gg][i] + s_err[gg][M + i];
-    __syncthreads();
+    FF_WG1_SYNC();
     if (ingrp) s_err[g][idx] = lpart;
-    __syncthreads();
+    FF_WG1_SYNC();
     const double L_i = s_err[gg][i] + s_err[gg][M + i];
-    __syncthreads();
+    FF_WG1_SYNC();
     if (valid) {
       const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN results (see ff_ode_fwd_kernel)
       if (owner) { A.y_out[b * M + i] = y[0] + bad; A.kbar[b * M + i] = y[MH + 1]; }
@@ -1070,10 +1070,10 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (S.fail) atomicMax(&s_st[3], 1); }
       }
     }
-    __syncthreads();
+    FF_WG1_SYNC();
   }
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  __syncthreads();
+  FF_WG1_SYNC();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
     atomicAdd(&A.stats[0], s_st[0]);
     atomicMax(&A.stats[1], s_st[1]);

@@ -40,6 +40,30 @@
 #define FF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #endif
+// Barrier of a SINGLE-WAVE workgroup.  The LDS serves the operations of one wave in program order -- a store followed by a load of the
+// same word from another lane of that wave needs no wait in between (the load's own s_waitcnt in front of its first use is all the
+// hardware asks for) --, so what remains of __syncthreads() is the promise that the compiler keeps the operations in order: a
+// wavefront-scope fence (no instruction) and a wave barrier (no instruction).  __syncthreads() itself costs s_waitcnt lgkmcnt(0) --
+// the wave parks until its last STORE has completed -- at every one of the ten phase boundaries of an evaluation.
+// -DFF_WG1_FULL_SYNC restores __syncthreads() (A/B).
+// FF_WAVE_ORDER(): the same promise among the lanes of one wave of a multi-wave workgroup whose waves run independently (where
+// FF_WAVE_SYNC() also waits for completion: needed only where ANOTHER wave is told that this wave's operations have landed).
+#ifndef FF_WAVE_ORDER
+#ifdef FF_WG1_FULL_SYNC
+#define FF_WAVE_ORDER() FF_WAVE_SYNC()
+#else
+#define FF_WAVE_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } while (0)
+#endif
+#endif
+#ifndef FF_WG1_SYNC
+#ifdef FF_WG1_FULL_SYNC
+#define FF_WG1_SYNC() __syncthreads()
+#else
+#define FF_WG1_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } while (0)
+#endif
+#endif
 #ifndef FF_HAVE_WAVE_BALLOT
 #define ff_wave_ballot(pred) __ballot(pred)      // (on the GPU a ballot IS per wave; the host simulator's needs to know which wave)
 #endif

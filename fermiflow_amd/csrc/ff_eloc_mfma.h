@@ -80,7 +80,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   // record of a radius: [0,D) rho  [D] eta  [D+1] eta'/r  [D+2] c phi'/r  [D+3, 2D+3) this radius' term of A kbar + the second-order source
   constexpr int RW = (2 * D + 3) | 1;     // odd: the row lanes of a wave read up to 4 N records at a time, one bank group each
   constexpr int QF0 = D, QF1 = D + 1, QGQ = D + 2, QPW = D + 3;
-  __shared__ double s_rec[(G * R + 1) * RW];   // + one record that stays zero
+  __shared__ double s_rec[(G * P + 1) * RW];   // one record per PAIR radius + one that stays zero
   __shared__ double s_cv[2 * NB][FF_WAVE];   // the J blocks of y and of the error accumulator of the Dormand-Prince step, lane-private columns
   __shared__ int s_any;
   __shared__ int s_st[4];
@@ -109,46 +109,45 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   if (lane < 4) s_st[lane] = 0;
   for (int e = lane; e < G * MP * AS; e += FF_WAVE) (&s_A[0][0])[e] = 0.0;   // padding stays zero
   for (int e = lane; e < G * MP; e += FF_WAVE) { (&s_z[0][0])[e] = 0.0; (&s_kb[0][0])[e] = 0.0; }
-  for (int e = lane; e < (G * R + 1) * RW; e += FF_WAVE) s_rec[e] = 0.0;
-  __syncthreads();
+  for (int e = lane; e < (G * P + 1) * RW; e += FF_WAVE) s_rec[e] = 0.0;
+  FF_WG1_SYNC();
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
-  const int nrad = has_mu ? R : P;
   const double tab_inv_h = TAB ? rtab[0] : 0.0, tab_h = TAB ? rtab[1] : 0.0;
   const double rtol = A.rtol, atol = A.atol;
   double (*s_gd)[MP] = s_z;
   constexpr double NT = (double)M * M + 4.0 * M + 2.0;   // z, J, kbar, grad Delta, Delta, lap Delta
   const int64_t ngroups = (A.B + G - 1) / G;
-  // radii this lane evaluates for its own walker (slot qk: radius i16 + 16 qk): a | b (15: none) << 4 | record offset << 8
-  constexpr int NQ = (R + 15) / 16;
-  constexpr bool SPLIT1B = P <= 16 && R > 16;
+  // Pair radii this lane evaluates for its own walker (slot qk: pair i16 + 16 qk): a | b << 4 | record offset << 8.  The ONE-BODY
+  // radius of a particle is evaluated by that particle's own row lanes (both of them, redundantly) and applied from registers: no
+  // record, no second radius slot at six particles -- per wave-evaluation seven LDS stores and six loads less on a kernel that is
+  // bound by its LDS operations.
+  constexpr int NQ = (P + 15) / 16;
   const int i16 = 4 * r + c;
   int rq_id[NQ];
 #pragma unroll
   for (int qk = 0; qk < NQ; qk++) {
-    // SPLIT1B (the pairs fill one slot and the one-body radii do not fit beside them: 6 particles): slot 0 holds pairs only, slot 1
-    // one-body radii only -- which a radius is becomes a compile-time property of the slot and each slot's code loses the other's half
-    const int pr = SPLIT1B ? (qk == 0 ? (i16 < P ? i16 : R) : (i16 < N ? P + i16 : R)) : i16 + 16 * qk;
-    int a = 0, bb = 15;
+    const int pr = i16 + 16 * qk;
+    int a = 0, bb = 1;
     if (pr < P) {
       int q = pr;
       while (q >= N - 1 - a) { q -= N - 1 - a; a++; }
       bb = a + 1 + q;
-    } else {
-      a = pr - P;
     }
-    rq_id[qk] = pr < nrad ? (a | (bb << 4) | (((w * R + pr) * RW) << 8)) : -1;
+    rq_id[qk] = pr < P ? (a | (bb << 4) | (((w * P + pr) * RW) << 8)) : -1;
   }
-  // row lanes: partner slot k = particle k (k == own particle: the one-body radius).  Packed: record offset << 1 | (k < own).
-  // An absent term reads the all-zero record behind the last one and "writes" -0.0 where the diagonal block is stored afterwards.
+  // row lanes: partner slot j = particle k(j) = j + (j >= own particle), j < N - 1.  Packed: (k < own) | record offset << 1 |
+  // byte offset of block k in the lane's row of A << 13.  A lane without a coordinate reads the all-zero record behind the last one.
   const int ra = owner ? p / D : 0, rc = owner ? p % D : 0;
-  int prec[N];
+  constexpr int NPART = N - 1 > 0 ? N - 1 : 1;
+  int prec[NPART];
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    const bool ok = owner && (k != ra || has_mu);
+  for (int j = 0; j < NPART; j++) {
+    const int k = j + (j >= ra ? 1 : 0);
+    const bool ok = owner && j < N - 1;
     const int lo = k < ra ? k : ra, hi = k < ra ? ra : k;
-    const int pr = k == ra ? P + ra : lo * (2 * N - lo - 1) / 2 + (hi - lo - 1);
-    prec[k] = ((ok ? (w * R + pr) : G * R) * RW) << 1 | ((ok && k < ra) ? 1 : 0);
+    const int pr = lo * (2 * N - lo - 1) / 2 + (hi - lo - 1);
+    prec[j] = ((ok ? (w * P + pr) : G * P) * RW) << 1 | ((ok && k < ra) ? 1 : 0) | ((ok ? k * D * 8 : 0) << 13);
   }
 
   // sum over the 16 lanes of a walker (identical on all of them): quad by DPP, the four quads through the LDS crossbar
@@ -168,9 +167,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #endif
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
     if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
-      __syncthreads();
+      FF_WG1_SYNC();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
-      __syncthreads();
+      FF_WG1_SYNC();
       grp = s_next;
     }
     if (grp >= ngroups) break;
@@ -212,9 +211,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       // tolerance of the sensitivity components relative to the coordinates' (ff_ode.sens_tol): weight in the error norm
       C.sens_w = loose ? A.sens_w : 1.0;
       C.hmax_acc = 0.0; C.h0v = 0.0; C.d1v = 0.0;
-      __syncthreads();
+      FF_WG1_SYNC();
       s_ctl[w].get(C);
-      __syncthreads();
+      FF_WG1_SYNC();
     }
     int s = -2, nev = 0;
     double hs_keep = 0.0;      // = s_ctl[w].S.h of the attempt under way
@@ -252,11 +251,12 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       FF_STAMP(0);
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ publish z, kbar
-      __syncthreads();
+      FF_WG1_SYNC();
       if (owner) { s_z[w][p] = zin; s_kb[w][p] = kin; }
-      __syncthreads();
-      // ------------------------------------------------------------------ radius lanes (radii of the lane's own walker), first
-      // half: the radii, their table rows requested -- the fetch runs under the S product
+      FF_WG1_SYNC();
+      // ------------------------------------------------------------------ radius lanes (pair radii of the lane's own walker) and
+      // row lanes (the one-body radius of the lane's own particle), first half: the radii, their table rows requested -- the fetch
+      // runs under the S product
       double rq_rho[NQ][D], rq_r[NQ], rq_ri[NQ], rq_T[NQ][TAB ? NH + 5 : 1], rq_dr[NQ];
       bool rq_ok[NQ];
 #pragma unroll
@@ -264,13 +264,11 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         int id = rq_id[qk];
         FF_OPAQUE(id);
         const bool act = id >= 0;
-        const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
-        const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
-        const int bb = pair ? bb0 : a;
+        const int a = act ? (id & 15) : 0, bb = act ? ((id >> 4) & 15) : 1;
         double r2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < D; cc++) {
-          rq_rho[qk][cc] = s_z[w][a * D + cc] - (pair ? s_z[w][bb * D + cc] : 0.0);
+          rq_rho[qk][cc] = s_z[w][a * D + cc] - s_z[w][bb * D + cc];
           r2 = fma(rq_rho[qk][cc], rq_rho[qk][cc], r2);
         }
         if (!act) r2 = 1.0;
@@ -278,8 +276,25 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         rq_dr[qk] = 0.0;
         rq_ok[qk] = true;
         if constexpr (TAB) {
-          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, pair ? 0 : 1, rq_r[qk], rq_T[qk], rq_dr[qk]);
+          rq_ok[qk] = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, 0, rq_r[qk], rq_T[qk], rq_dr[qk]);
           if (act && !rq_ok[qk]) off_table = true;
+        }
+      }
+      const bool ob_act = owner && has_mu;
+      double ob_rho[D], ob_r, ob_ri, ob_T[TAB ? NH + 5 : 1], ob_dr = 0.0;
+      bool ob_ok = true;
+      {
+        double r2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < D; cc++) {
+          ob_rho[cc] = s_z[w][ra * D + cc];
+          r2 = fma(ob_rho[cc], ob_rho[cc], r2);
+        }
+        if (!ob_act) r2 = 1.0;
+        ff_sqrt_rcp(r2, ob_r, ob_ri);
+        if constexpr (TAB) {
+          ob_ok = ff_table_fetch<NH>(rtab, tab_inv_h, tab_h, 1, ob_r, ob_T, ob_dr);
+          if (ob_act && !ob_ok) off_table = true;
         }
       }
       // ------------------------------------------------------------------ S = J J^T on the matrix cores
@@ -307,20 +322,18 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           }
         }
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(1);
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ radius lanes, second half: heads, contraction of the
-      // second-order terms with S, one record per radius
+      // second-order terms with S, one record per pair radius; the row lanes keep their one-body radius' terms in registers
       double dsum = 0.0, qsum = 0.0;
 #pragma unroll
       for (int qk = 0; qk < NQ; qk++) {
         int id = rq_id[qk];
         FF_OPAQUE(id);
         const bool act = id >= 0;
-        const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
-        const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
-        const int bb = pair ? bb0 : a;
+        const int a = act ? (id & 15) : 0, bb = act ? ((id >> 4) & 15) : 1;
         const double* rho = rq_rho[qk];
         const double rr = rq_r[qk], ri = rq_ri[qk];
         double hd[NH];
@@ -331,14 +344,13 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             for (int m = 0; m < NH; m++) hd[m] = 0.0;
           }
         } else {
-          ff_heads<NH, true>(s_w[pair ? 0 : 1], s_e2, pair ? He : Hm, rr, hd);
+          ff_heads<NH, true>(s_w[0], s_e2, He, rr, hd);
         }
         if (act) {
-          const double cf = pair ? 2.0 : 1.0;
           const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
-          const double Ac = cf * fma(f2, rr, (1.0 + D) * f1), Bc = cf * fma(f3, rr, (2.0 + D) * f2);
+          const double Ac = 2.0 * fma(f2, rr, (1.0 + D) * f1), Bc = 2.0 * fma(f3, rr, (2.0 + D) * f2);
           const double f1ri = f1 * ri, gq = Ac * ri;
-          // W = S_aa + S_bb - S_ab - S_ba (S_aa for a one-body radius);  w1 = W rho, q = rho^T W rho / r^2
+          // W = S_aa + S_bb - S_ab - S_ba;  w1 = W rho, q = rho^T W rho / r^2
           const double* Sg = s_A[w];
           double w1[D], dk[D], qq = 0.0, tr = 0.0, rdk = 0.0;
           // (W is symmetric -- S is, element for element: both halves of a block pair are one accumulator, and the two lanes of a
@@ -349,7 +361,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
             for (int c2i = cc; c2i < D; c2i++) {
               double ww = Sg[(a * D + cc) * AS + a * D + c2i];
-              if (pair) ww += (Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i]) - Sg[(a * D + c2i) * AS + bb * D + cc];
+              ww += (Sg[(bb * D + cc) * AS + bb * D + c2i] - Sg[(a * D + cc) * AS + bb * D + c2i]) - Sg[(a * D + c2i) * AS + bb * D + cc];
               Ws[cc][c2i] = ww; Ws[c2i][cc] = ww;
             }
           }
@@ -364,7 +376,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             }
             w1[cc] = t;
             qq = fma(rho[cc], t, qq);
-            dk[cc] = s_kb[w][a * D + cc] - (pair ? s_kb[w][bb * D + cc] : 0.0);
+            dk[cc] = s_kb[w][a * D + cc] - s_kb[w][bb * D + cc];
             rdk = fma(rho[cc], dk[cc], rdk);
           }
           qq *= ri * ri;
@@ -377,11 +389,67 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             rec[QPW + cc] = fma(F2, rho[cc], fma(F1x2, w1[cc], f0 * dk[cc]));    // D_v[kbar] + the second-order source, this radius
           }
           rec[QF0] = f0; rec[QF1] = f1ri; rec[QGQ] = gq;
-          dsum = fma(cf, fma(f1, rr, D * f0), dsum);       // this radius' share of div v
+          dsum = fma(2.0, fma(f1, rr, D * f0), dsum);      // this radius' share of div v
           qsum += fma(Bc, qq, gq * tq);                    // ... and of the Laplacian source
         }
       }
-      __syncthreads();      // records complete; S has been read: A takes its place
+      // the one-body radius of the lane's particle: mu(|z_a|) z_a with W = S_aa; both lanes of the particle hold the same numbers, the
+      // lane of component 0 counts the radius' share of div v and of the Laplacian source
+      double ob_f0 = 0.0, ob_fc = 0.0, ob_gq = 0.0, ob_pw = 0.0;
+      {
+        double hd[NH];
+        if constexpr (TAB) {
+          if (ob_ok) ff_table_eval<NH>(ob_T, ob_dr, hd);
+          else {
+#pragma unroll
+            for (int m = 0; m < NH; m++) hd[m] = 0.0;
+          }
+        } else {
+          ff_heads<NH, true>(s_w[1], s_e2, Hm, ob_r, hd);
+        }
+        if (ob_act) {
+          const double f0 = hd[0], f1 = hd[1], f2 = hd[2], f3 = hd[3];
+          const double Ac = fma(f2, ob_r, (1.0 + D) * f1), Bc = fma(f3, ob_r, (2.0 + D) * f2);
+          const double f1ri = f1 * ob_ri, gq = Ac * ob_ri;
+          const double* Sg = s_A[w];
+          double Ws[D][D];
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+#pragma unroll
+            for (int c2i = cc; c2i < D; c2i++) {
+              const double ww = Sg[(ra * D + cc) * AS + ra * D + c2i];
+              Ws[cc][c2i] = ww; Ws[c2i][cc] = ww;
+            }
+          }
+          double w1[D], dk[D], qq = 0.0, tr = 0.0, rdk = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) {
+            double t = 0.0;
+#pragma unroll
+            for (int c2i = 0; c2i < D; c2i++) {
+              const double ww = Ws[cc][c2i];
+              t = fma(ww, ob_rho[c2i], t);
+              if (c2i == cc) tr += ww;
+            }
+            w1[cc] = t;
+            qq = fma(ob_rho[cc], t, qq);
+            dk[cc] = s_kb[w][ra * D + cc];
+            rdk = fma(ob_rho[cc], dk[cc], rdk);
+          }
+          qq *= ob_ri * ob_ri;
+          const double tq = tr - qq;
+          const double F2 = fma(f2, qq, fma(f1ri, tq, f1ri * rdk)), F1x2 = 2.0 * f1ri;
+          double pw = fma(F2, ob_rho[0], fma(F1x2, w1[0], f0 * dk[0]));
+#pragma unroll
+          for (int cc = 1; cc < D; cc++) pw = (rc == cc) ? fma(F2, ob_rho[cc], fma(F1x2, w1[cc], f0 * dk[cc])) : pw;
+          ob_f0 = f0; ob_fc = f1ri; ob_gq = gq; ob_pw = pw;
+          if (rc == 0) {
+            dsum += fma(f1, ob_r, D * f0);
+            qsum += fma(Bc, qq, gq * tq);
+          }
+        }
+      }
+      FF_WG1_SYNC();      // records complete; S has been read: A takes its place
       nev++;
       FF_STAMP(2);
       FF_SCHED_FENCE();
@@ -389,17 +457,26 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       double vi = 0.0, wk = 0.0, gdi = 0.0;
       {
         double Ad[D];
-#pragma unroll
-        for (int cc = 0; cc < D; cc++) Ad[cc] = 0.0;
         double* arow = owner ? &s_A[w][p * AS] : s_dump;
         double dsel[D];      // row rc of the identity
 #pragma unroll
         for (int cc = 0; cc < D; cc++) dsel[cc] = rc == cc ? 1.0 : 0.0;
+        {   // the one-body radius, from the lane's registers
+          double ru = ob_rho[0];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-          int pk = prec[k];
+          for (int cc = 1; cc < D; cc++) ru = (rc == cc) ? ob_rho[cc] : ru;
+          const double fc = ob_fc * ru;
+          vi = ob_f0 * ru;
+          wk = ob_pw;
+          gdi = ob_gq * ru;
+#pragma unroll
+          for (int cc = 0; cc < D; cc++) Ad[cc] = fma(fc, ob_rho[cc], ob_f0 * dsel[cc]);
+        }
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) {
+          int pk = prec[j];
           FF_OPAQUE(pk);
-          const double* rec = &s_rec[pk >> 1];
+          const double* rec = &s_rec[(pk >> 1) & 0xfff];
           const int smask = (int)((unsigned)pk << 31);                                        // the sign of this partner's odd terms, as a sign bit
           // (rho is read once, both components, and the lane's own one selected: rec[rc] beside rec[0 .. D) was a seventh LDS read per partner)
           double rh[D];
@@ -414,7 +491,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           vi = fma(f0, rcv, vi);
           wk += __hiloint2double(__double2hiint(pw) ^ smask, __double2loint(pw));
           gdi = fma(rec[QGQ], rcv, gdi);
-          double* ablk = arow + k * D;       // (k == own particle: overwritten by the diagonal block below)
+          double* ablk = (double*)((char*)arow + (pk >> 13));       // block k(j) of the lane's row
 #pragma unroll
           for (int cc = 0; cc < D; cc++) {
             const double Bcc = fma(fc, rh[cc], f0 * dsel[cc]);               // B = eta I + (eta'/r) rho rho^T, row rc
@@ -426,7 +503,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         for (int cc = 0; cc < D; cc++) arow[ra * D + cc] = Ad[cc];
         (owner ? &s_gd[w][p] : &s_dump[MP])[0] = gdi;
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(3);
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ J' = A J on the matrix cores, (grad Delta)' = -J^T g
@@ -493,7 +570,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #endif
       if (s == -2) {
         ctl_t C; C.get(s_ctl[w]);
-        __syncthreads();
+        FF_WG1_SYNC();
         const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
         auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
 #pragma unroll
@@ -517,10 +594,10 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         }
         hs_keep = C.S.h;
         s_ctl[w].get(C);
-        __syncthreads();
+        FF_WG1_SYNC();
       } else if (s == -1) {
         ctl_t C; C.get(s_ctl[w]);
-        __syncthreads();
+        FF_WG1_SYNC();
         const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
         auto wgt = [&](int v) -> double { return v == 0 ? w0 : sens_w; };
         double p2 = 0.0;
@@ -536,7 +613,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         C.S.plan();
         hs_keep = C.S.h;
         s_ctl[w].get(C);
-        __syncthreads();
+        FF_WG1_SYNC();
         s = 1;
       } else if (s == 0) {
 #pragma unroll
@@ -587,7 +664,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         }
         const double err = sqrt(walker_sum(pe) * (1.0 / NT));
         ctl_t C; C.get(s_ctl[w]);
-        __syncthreads();
+        FF_WG1_SYNC();
         const bool was_active = !C.S.done;
         const bool acc = C.S.decide(err, A.max_steps);
         if (acc) C.hmax_acc = fmax(C.hmax_acc, fabs(hs));
@@ -598,7 +675,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         C.S.plan();
         hs_keep = C.S.h;
         s_ctl[w].get(C);
-        __syncthreads();
+        FF_WG1_SYNC();
         const int any = ff_wave_or(&s_any, lane, C.S.done ? 0 : ((was_active && !acc) ? 3 : 1));
         if (!any) break;
         s = (any & 2) ? 0 : 1;
@@ -650,7 +727,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         }
         const double y0 = y.get(0);                      // z_p (owner lanes), Delta (p = PDL), lap Delta (p = PLP)
         if (owner) s_z[w][p] = y0;
-        __syncthreads();
+        FF_WG1_SYNC();
         // Particle lanes: lane i16 = 4r + c < N of a walker owns particle i16 (spin i16 / NSF): its row of the Slater matrix, of the
         // gradient tables T_c[a][b] = sum_j d_c phi_j(r_a) Dinv[j][b] and its same-particle Hessian sums S3; the rows
         // meet in LDS (the record area is free here), every lane inverts its spin's matrix itself (adjugate, <= 3 x 3).
@@ -697,7 +774,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
           for (int j = 0; j < NSF; j++) fD[al * NSF + j] = ph[j];
         }
-        __syncthreads();
+        FF_WG1_SYNC();
         double lp0 = 0.0, trhs = 0.0;
         double Tx[NSF], Ty[NSF], S3[3] = {0.0, 0.0, 0.0};
         {
@@ -732,7 +809,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #pragma unroll
           for (int bb2 = 0; bb2 < NSF; bb2++) { fT[al * NSF + bb2] = Tx[bb2]; fT[NSF * NSF + al * NSF + bb2] = Ty[bb2]; }
         }
-        __syncthreads();
+        FF_WG1_SYNC();
         if (pl) {     // this particle's share of tr(H0 S): same-particle block with S3, cross blocks -T_ac (x) T_ca
           const double* Sm = s_A[w];
           const int ia = 2 * i16;
@@ -745,7 +822,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           }
           trhs = 2.0 * q;
         }
-        __syncthreads();
+        FF_WG1_SYNC();
         // grad_x logp: component p of J^T g0 (rows 4I + r on the lane, r across the walker's quads), minus grad Delta
         double dd = 0.0;
 #pragma unroll
@@ -764,31 +841,28 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         const double g2 = walker_sum(gradp * gradp);
         // V(x) = sum_{i<j} Z / r_ij + (1/2) sum_i r_i^2 on the radius lanes (src/potentials.py:13, 23-47)
         const double xp = ff_opt_load(A.y_in, valid && owner, b * M + p, A.y_in, 0.25 * (p + 1) + 0.125 * ((p * 7) % 5));
-        __syncthreads();
+        FF_WG1_SYNC();
         if (owner) s_z[w][p] = xp;
-        __syncthreads();
+        FF_WG1_SYNC();
         double vl = 0.0;
 #pragma unroll
         for (int qk = 0; qk < NQ; qk++) {
           int id = rq_id[qk];
           FF_OPAQUE(id);
           const bool act = id >= 0;
-          const int a = act ? (id & 15) : 0, bb0 = act ? ((id >> 4) & 15) : 15;
-          const bool pair = SPLIT1B ? qk == 0 : bb0 != 15;
-          const int bb = pair ? bb0 : a;
+          const int a = act ? (id & 15) : 0, bb = act ? ((id >> 4) & 15) : 1;
           double r2 = 0.0;
 #pragma unroll
           for (int cc = 0; cc < D; cc++) {
-            const double d = s_z[w][a * D + cc] - (pair ? s_z[w][bb * D + cc] : 0.0);
+            const double d = s_z[w][a * D + cc] - s_z[w][bb * D + cc];
             r2 = fma(d, d, r2);
           }
           double rr, ri;
           ff_sqrt_rcp(r2, rr, ri);
-          const double term = pair ? A.fin.Z * ri : (A.fin.use_ho ? 0.5 * r2 : 0.0);
-          vl += act ? term : 0.0;
+          vl += act ? A.fin.Z * ri : 0.0;
         }
-        // (without mu the one-body radii have no slot: the trap term is then taken by the coordinate lanes)
-        if (!has_mu && A.fin.use_ho && owner) vl = fma(0.5 * xp, xp, vl);
+        // (the trap term is taken by the coordinate lanes)
+        if (A.fin.use_ho && owner) vl = fma(0.5 * xp, xp, vl);
         const double Vv = walker_sum(vl);
         if (valid) {
           ctl_t C; C.get(s_ctl[w]);
@@ -851,7 +925,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       }
      }
     }
-    __syncthreads();
+    FF_WG1_SYNC();
   }
 #ifdef FF_STAMPS
   FF_STAMP(7);
@@ -866,7 +940,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
 #endif
 #endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  __syncthreads();
+  FF_WG1_SYNC();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
     atomicAdd(&A.stats[0], s_st[0]);
     atomicMax(&A.stats[1], s_st[1]);

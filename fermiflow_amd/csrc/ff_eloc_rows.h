@@ -101,7 +101,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
   // padding columns of the J rows, the gd slots and the records of absent radii start (and stay) at zero
   for (int e = lane; e < G * JWS; e += FF_WAVE) s_J[e] = 0.0;
   for (int e = lane; e < G * R * RW; e += FF_WAVE) s_rec[e] = 0.0;
-  __syncthreads();
+  FF_WG1_SYNC();
   const int He = A.net.He, Hm = A.net.Hm;
   const bool has_mu = Hm > 0;
   const int nrad = has_mu ? R : P;
@@ -133,9 +133,9 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
 #endif
   for (int64_t grp = blockIdx.x;; grp += gridDim.x) {
     if (A.queue) {   // persistent grid: next group from the launch's work counter (the order is by schedule key: cost class + 4 x planned steps, costliest first)
-      __syncthreads();
+      FF_WG1_SYNC();
       if (lane == 0) s_next = (long long)atomicAdd(A.queue + (TAB ? 0 : 1), 1ULL);
-      __syncthreads();
+      FF_WG1_SYNC();
       grp = s_next;
     }
     if (grp >= ngroups) break;
@@ -167,11 +167,11 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
 
     auto group_sum = [&](double part) -> double {
       if (ingrp) s_err[g][idx] = part;
-      __syncthreads();
+      FF_WG1_SYNC();
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < L; j++) t += s_err[gg][j];
-      __syncthreads();
+      FF_WG1_SYNC();
       return t;
     };
 
@@ -199,14 +199,14 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
       double out[NV];
       FF_STAMP(0);
       // ------------------------------------------------------------------ publish z, kbar (owners) and the row chunks
-      __syncthreads();
+      FF_WG1_SYNC();
       if (ingrp) {
         if (owner) { s_z[l_g][l_p] = form(0); s_kb[l_g][l_p] = form(IK); }
         double* row = &s_J[l_g * JWS + l_p * JROW + l_col0];
 #pragma unroll
         for (int k = 0; k < MC; k++) row[k] = form(1 + k);
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(1);
       // ------------------------------------------------------------------ R1: radius lanes
       {
@@ -270,7 +270,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
           rec[QDS] = cf * fma(f1, r, D * f0);                 // this radius' share of div v
         }
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       nev++;
       FF_STAMP(2);
       // ------------------------------------------------------------------ row sweep: dJ = A J, S = J J^T, own-row sums
@@ -324,7 +324,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
         }
       }
       if (ingrp && owner) s_J[l_g * JWS + l_p * JROW + MCOLS] = gdi;   // read by the grad-Delta sweep, two barriers from here
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(3);
       // ------------------------------------------------------------------ R2: radius lanes contract their terms with S
 #pragma unroll
@@ -371,7 +371,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
         for (int c = 0; c < D; c++) rec[QPW + c] = fma(F2, rho[c], F1x2 * w1[c]);
         rec[QQD] = fma(Bc, qq, gq * tq);
       }
-      __syncthreads();
+      FF_WG1_SYNC();
       FF_STAMP(4);
       // ------------------------------------------------------------------ second-order sources, grad-Delta sweep
       double qs = 0.0, shq = 0.0, shd = 0.0;
@@ -493,11 +493,11 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
     double dD_p = y[IDD];
     if constexpr (SPLIT > 1) {
       if (ingrp) s_err[g][idx] = y[IDD];
-      __syncthreads();
+      FF_WG1_SYNC();
       dD_p = 0.0;
 #pragma unroll
       for (int hh = 0; hh < SPLIT; hh++) dD_p += s_err[gg][hh * M + p];
-      __syncthreads();
+      FF_WG1_SYNC();
     }
     if (valid) {
       const bool failed = S.fail != 0;
@@ -519,7 +519,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
         if (A.stats) { atomicAdd(&s_st[0], nev); atomicMax(&s_st[1], S.nacc); atomicAdd(&s_st[2], S.nrej); if (failed) atomicMax(&s_st[3], 1); }
       }
     }
-    __syncthreads();
+    FF_WG1_SYNC();
   }
 #ifdef FF_STAMPS
   FF_STAMP(7);
@@ -527,7 +527,7 @@ ff_eloc_rows_kernel(ff_fwd_args A) {
     for (int q = 0; q < 9; q++) atomicAdd((unsigned long long*)(A.stats + 8) + q, stamp_acc[q]);
 #endif
   if constexpr (TAB) { if (off_table) *A.evt = A.evt_id; }
-  __syncthreads();
+  FF_WG1_SYNC();
   if (A.stats && lane == 0 && (s_st[0] || s_st[3])) {
     atomicAdd(&A.stats[0], s_st[0]);
     atomicMax(&A.stats[1], s_st[1]);
