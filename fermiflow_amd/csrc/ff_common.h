@@ -140,6 +140,15 @@ FF_D double ff_lane_read(double v, int src) {
 // Lane l = 16 k + 4 blk + i supplies A_blk[i][k]; lane 16 k + 4 blk + j supplies B_blk[k][j]; lane 16 i + 4 blk + j holds
 // C/D_blk[i][j] (measured on gfx950: tools/probes/mfma_f64.hip) -- the block is (l / 4) % 4, NOT l / 16.
 FF_D double ff_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// element (c, r) of the lane's 4 x 4 block delivered to lane (r, c) (l = 16 r + 4 blk + c; tl = 16 c + 4 blk + r): the value fed as the
+// A operand is read as A_blk[c][r], so the product with the identity (idn = 1 on the lanes r == c) comes back transposed
+FF_D double ff_block_transpose(double v, double idn, int tl) {
+#ifdef FF_TRANSPOSE_BPERMUTE      // (A/B: two ds_bpermute_b32 through the LDS crossbar)
+  return ff_lane_read(v, tl);
+#else
+  return ff_mfma4(v, idn, 0.0);
+#endif
+}
 
 // v_mfma_f64_16x16x4_f64: D (16x16) = A (16x4) B (4x16) + C per wave.  Lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16];
 // register v of lane l holds C/D[4 v + l / 16][l % 16] (measured on gfx950: tools/probes/mfma_f64.hip, wide_probe.hip).

@@ -150,13 +150,14 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     prec[j] = ((ok ? (w * P + pr) : G * P) * RW) << 1 | ((ok && k < ra) ? 1 : 0) | ((ok ? k * D * 8 : 0) << 13);
   }
 
-  // sum over the 16 lanes of a walker (identical on all of them): quad by DPP, the four quads through the LDS crossbar
+  // sum over the 16 lanes of a walker (identical on all of them): quad by DPP, the four quads by the matrix cores -- with ones as the A
+  // operand a 4 x 4 x 4 product returns the column sums of B, sum_k B_blk[k][j], on every lane (i, j) of the block: the sum over the
+  // walker's four quads r = k, in the fixed order k = 0 .. 3 (the LDS crossbar took two exchanges = four ds_bpermute for it)
+  auto quads_sum = [&](double part) -> double { return ff_mfma4(1.0, part, 0.0); };
   auto walker_sum = [&](double part) -> double {
     part += ff_swap1(part);
     part += ff_swap2(part);
-    part += ff_lane_read(part, lane ^ 16);
-    part += ff_lane_read(part, lane ^ 32);
-    return part;
+    return quads_sum(part);
   };
 
 #ifdef FF_STAMPS
@@ -299,13 +300,18 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       }
       // ------------------------------------------------------------------ S = J J^T on the matrix cores
       {
-        double Jt[NB];      // the blocks transposed in place: lane (r, c) <-> (c, r)
+        // The blocks transposed in place, lane (r, c) <-> (c, r) -- by the matrix cores: a lane's element fed as the A operand IS the
+        // transposed block (A_blk[i][k] is supplied by lane (k, i)), so one product with the identity returns it in the C/D layout,
+        // exactly (one non-zero product per sum).  Nine matrix instructions on a pipe that is 10 % busy instead of eighteen ds_bpermute
+        // on the LDS crossbar this kernel is bound by.
+        double Jt[NB];
+        const double idn = r == c ? 1.0 : 0.0;
         if (use_y) {
 #pragma unroll
-          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form(1 + e), tl);
+          for (int e = 0; e < NB; e++) Jt[e] = ff_block_transpose(form(1 + e), idn, tl);
         } else {
 #pragma unroll
-          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(form_noy(1 + e), tl);
+          for (int e = 0; e < NB; e++) Jt[e] = ff_block_transpose(form_noy(1 + e), idn, tl);
         }
         double* Sw = s_A[w];
 #pragma unroll
@@ -530,34 +536,31 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
             out[1 + I * MB + Kc] = acc;
           }
         }
-        // Component 4K + c of g^T J is a sum over the rows 4I + r: over I on the lane, over r across the walker's four quads; the lane
-        // keeps the component of its own coordinate p = 4r + c.
-        // Four sums over the walker's four quads (r), each wanted by ONE quad: components K = 0, 1, 2 by the lanes r = K, and the two
-        // scalars -- Delta' = -div v and (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar), summed over the quad by DPP first -- by the
-        // spare lanes p = 12, 13 (r = 3, c = 0, 1) that integrate them.  A reduce-scatter: two values across lane ^ 32, one across
-        // lane ^ 16 -- three exchanges through the LDS crossbar where three all-reduces + two walker sums took ten (round 6: the kernel
-        // is bound by the LDS).
-        double tt[4];
+        // Component 4K + c of g^T J is a sum over the rows 4I + r -- itself a product on the matrix cores: with A_blk[i][k] = g[4I + k] for
+        // every i (lane (r, c) supplies g[4I + r]: the value it reads from LDS anyway) and B = block (I, K) of J, the sum over I of the
+        // products is (g^T J)[4K + j] on every lane (i, j); the lane keeps the component of its own coordinate p = 4r + c, i.e. K = r.
+        // MB^2 matrix instructions instead of MB^2 fp64 FMAs and a reduce-scatter through the LDS crossbar (round 6: three exchanges).
+        // The two scalars -- Delta' = -div v and (lap Delta)' = -(sum_i D2div[u_i, u_i] + g . kbar) -- are summed over the quad by DPP
+        // and over the walker's four quads by one product with ones: column 0 carries the first, the other columns the second; the
+        // spare lanes p = 12, 13 (r = 3, c = 0, 1) integrate them.
+        double gdr[MB];
 #pragma unroll
-        for (int K = 0; K < 3; K++) {
+        for (int I = 0; I < MB; I++) gdr[I] = s_gd[w][4 * I + r];
+        double dd = 0.0;
+#pragma unroll
+        for (int K = 0; K < MB; K++) {
           double t = 0.0;
-          if (K < MB) {
 #pragma unroll
-            for (int I = 0; I < MB; I++) t = fma(s_gd[w][4 * I + r], Jin[I * MB + K], t);
-          }
-          tt[K] = t;
+          for (int I = 0; I < MB; I++) t = ff_mfma4(gdr[I], Jin[I * MB + K], t);
+          dd = (r == K) ? t : dd;
         }
+        double res;
         {
           double ds4 = dsum, qs4 = fma(gdi, kin, qsum);
           ds4 += ff_swap1(ds4); ds4 += ff_swap2(ds4);
           qs4 += ff_swap1(qs4); qs4 += ff_swap2(qs4);
-          tt[3] = c == 0 ? ds4 : qs4;
+          res = quads_sum(c == 0 ? ds4 : qs4);
         }
-        const bool lo2 = r < 2, ev = (r & 1) == 0;
-        const double ka = (lo2 ? tt[0] : tt[2]) + ff_lane_read(lo2 ? tt[2] : tt[0], ln ^ 32);      // index 0 (r < 2) or 2
-        const double kb2 = (lo2 ? tt[1] : tt[3]) + ff_lane_read(lo2 ? tt[3] : tt[1], ln ^ 32);     // index 1 or 3
-        const double res = (ev ? ka : kb2) + ff_lane_read(ev ? kb2 : ka, ln ^ 16);                  // the total of index r
-        const double dd = r < 3 ? res : 0.0;
         out[0] = owner ? vi : ((p == PDL || p == PLP) ? -res : 0.0);
         out[IK] = wk;                         // (row lanes beyond M read the zero record: all their sums vanish)
         out[IDD] = -dd;
@@ -710,8 +713,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         walker_of(w, b, valid);
         {   // S = J J^T of the final J -> s_A[w]
           double Jt[NB];
+          const double idn = r == c ? 1.0 : 0.0;
 #pragma unroll
-          for (int e = 0; e < NB; e++) Jt[e] = ff_lane_read(y.get(1 + e), tl);
+          for (int e = 0; e < NB; e++) Jt[e] = ff_block_transpose(y.get(1 + e), idn, tl);
           double* Sw = s_A[w];
 #pragma unroll
           for (int I = 0; I < MB; I++) {
@@ -829,9 +833,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         for (int K = 0; K < MB; K++) {
           double t = 0.0;
 #pragma unroll
-          for (int I = 0; I < MB; I++) t = fma(s_kb[w][4 * I + r], y.get(1 + I * MB + K), t);
-          t += ff_lane_read(t, ln ^ 16);
-          t += ff_lane_read(t, ln ^ 32);
+          for (int I = 0; I < MB; I++) t = ff_mfma4(s_kb[w][4 * I + r], y.get(1 + I * MB + K), t);      // (as (grad Delta)' in the right-hand side)
           dd = (r == K) ? t : dd;
         }
         const double g0p = owner ? s_kb[w][p] : 0.0;
