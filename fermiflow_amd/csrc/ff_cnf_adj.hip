@@ -131,11 +131,17 @@ struct ff_rec { double dr, ca, cb; int j; };
 
 // add one coefficient row to node j of net t: LDS table for the near nodes, global overflow table beyond
 // (one branch and one address computation per row, not per coefficient)
-FF_D void ff_row_add(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, int j, const double* c) {
+// nrow (wave-uniform: header slot 5 of the radial table, ff_radial.h): the coefficients the weights of this launch need -- 6, 8, 10 or all
+// 12; an LDS floating-point atomic is served at less than one lane per clock and CU, so the rows are no longer than they have to be
+FF_D void ff_row_add(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, int j, const double* c, int nrow) {
   if (j < FF_DEP_NLDS) {
     double* row = &sW[t][j][0];
 #pragma unroll
-    for (int k = 0; k < FF_DEP_ROW; k++) atomicAdd(row + k, c[k]);
+    for (int k = 0; k < 6; k++) atomicAdd(row + k, c[k]);
+#pragma unroll
+    for (int k0 = 6; k0 < FF_DEP_ROW; k0 += 2) {
+      if (nrow > k0) { atomicAdd(row + k0, c[k0]); atomicAdd(row + k0 + 1, c[k0 + 1]); }
+    }
   } else {
     // (hipcc otherwise sinks the two atomic loops into one over a select of an LDS and a global pointer -- a flat pointer
     // whose aperture test it then fails to encode: "Illegal instruction detected" in the one-walker-per-wave kernels)
@@ -147,7 +153,7 @@ FF_D void ff_row_add(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict_
   }
 }
 
-FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& rc, double w) {
+FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& rc, double w, int nrow) {
   if (w == 0.0) return;
   double pk = 1.0, pm = 0.0, c[FF_DEP_ROW];   // dr^k/k!, dr^(k-1)/(k-1)!
 #pragma unroll
@@ -156,7 +162,7 @@ FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict_
     pm = pk;
     pk = pk * rc.dr * (1.0 / (k + 1));
   }
-  ff_row_add(sW, ovf, t, rc.j, c);
+  ff_row_add(sW, ovf, t, rc.j, c, nrow);
 }
 
 // The five records of one accepted step (stages 0, 2, 3, 4, 5 with the b-weights of the tableau).  Within a step the radius moves a
@@ -168,7 +174,7 @@ FF_D void ff_deposit(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict_
 // Truncation: the expansion is of order 11 in w1 dr with |dr| <= 1.5 h_d here, and the table is declared usable only while
 // max|w1| h_d <= 0.4 (ff_radial.h: 0.6 while |dr| <= h_d / 2 ... h_d) -- (0.6)^12 / 12! as before.
 FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict__ ovf, int t, const ff_rec& q0, const ff_rec& q2,
-                      const ff_rec& q3, const ff_rec& q4, const ff_rec& q5, double hw) {
+                      const ff_rec& q3, const ff_rec& q4, const ff_rec& q5, double hw, int nrow) {
   if (hw == 0.0) return;
   const ff_rec* rc[5] = {&q0, &q2, &q3, &q4, &q5};
   const double bw[5] = {hw * FF_B0, hw * FF_B2, hw * FF_B3, hw * FF_B4, hw * FF_B5};
@@ -194,10 +200,10 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
         pk = pk * dr * (1.0 / (k + 1));
       }
     } else {
-      ff_deposit(sW, ovf, t, *rc[e], bw[e]);
+      ff_deposit(sW, ovf, t, *rc[e], bw[e], nrow);
     }
   }
-  ff_row_add(sW, ovf, t, jC, acc);
+  ff_row_add(sW, ovf, t, jC, acc, nrow);
 }
 
 #ifndef FF_ADJ_WPS
@@ -237,6 +243,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
 #endif
   const double* __restrict__ rtab = A.net.radial_table;
   if (!(rtab && rtab[3] == 0.0 && rtab[4] == 0.0)) return;   // the direct-evaluation kernel serves this call
+  const int dep_nrow = FF_UNIFORM(rtab[5] >= 6.0 && rtab[5] <= (double)FF_DEP_ROW ? (int)rtab[5] : FF_DEP_ROW);   // coefficients per deposit row
 
   __shared__ double s_z_[WPW][G][M], s_kb_[WPW][G][M], s_err_[WPW][G][M], s_ad_[WPW][G], s_hw_[WPW][G];
   // T[g][a][j][3][D]: what partner j (j = a: the one-body term) contributes to particle a's rows of v, Dv^T[lambda] and
@@ -562,7 +569,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
             const int t = ((rq_id[sl] >> 8) & 15) != 15 ? 0 : 1;
             const double hw = s_hw[qg];
 #ifndef FF_ADJ_NODEP      // (timing experiments only: the parameter gradient is then wrong)
-            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw);
+            ff_deposit5(s_W, ovf, t, r0[sl], r2[sl], r3[sl], r4[sl], r5[sl], hw, dep_nrow);
 #endif
             if (hw != 0.0) r0[sl] = r6[sl];   // FSAL: the record of k6 opens that walker's next step
           }

@@ -20,6 +20,7 @@
 #define FF_TAB_NMAX (32 * (1 << FF_TAB_MAXLOG) + 1)
 #define FF_TAB_HDR 16                       // [0] 1/h, [1] h, [2] nodes, [3] 1.0 if the table must not be used,
                                             // [4] 1.0 if the adjoint's deposit grid must not be used,
+                                            // [5] coefficients per deposit row these weights need (6, 8, 10 or 12),
                                             // [8..15] event slots written by the kernels that read the table: a launch
                                             // that met a radius beyond the table leaves its id in slot (id mod 8)
 #define FF_TAB_EVT0 8
@@ -112,7 +113,18 @@ __global__ void __launch_bounds__(128) ff_table_kernel(ff_net net, double* __res
     tab[2] = (double)nodes;
     tab[3] = bad ? 1.0 : 0.0;
     tab[4] = (w * (1.0 / FF_DEP_INVH) <= 0.4) ? 0.0 : 1.0;   // 1.0: the coarse deposit grid is not accurate enough
-    for (int q = 5; q < FF_TAB_HDR; q++) tab[q] = 0.0;
+    // [5]: coefficients of a deposit row these weights need.  A deposit is expanded up to 1.5 h_d from its node; the remainder of n
+    // coefficients, (1.5 w h_d)^n / n!, is held to what the full row leaves at the validity bound above: 0.6^12 / 12! = 4.5e-12.
+    {
+      const double xd = 1.5 * w * (1.0 / FF_DEP_INVH);
+      double nrow = (double)FF_DEP_ROW, rem = xd * xd * xd * xd * (1.0 / 24.0);      // xd^4 / 4!
+      for (int n = 6; n < FF_DEP_ROW; n += 2) {
+        rem *= xd * xd / (double)(n * (n - 1));
+        if (rem <= 4.5e-12) { nrow = (double)n; break; }
+      }
+      tab[5] = nrow;
+    }
+    for (int q = 6; q < FF_TAB_HDR; q++) tab[q] = 0.0;
   }
   if (bad) return;
   // f^(0..8)(r_j) = sum_h w2 w1^n sigma^(n)(w1 r_j + b1): quad q of the launch takes the nodes q, q + (quads of the launch), ... of
