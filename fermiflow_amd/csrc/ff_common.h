@@ -68,6 +68,11 @@
 #define ff_wave_ballot(pred) __ballot(pred)      // (on the GPU a ballot IS per wave; the host simulator's needs to know which wave)
 #endif
 
+// the lane's index within its wave, recomputed where it is needed (two instructions) instead of kept in a register across a loop --
+// in a single-wave workgroup this IS threadIdx.x, which lives in an input register the allocator can only spill
+#ifndef FF_LANE_SELF
+#define FF_LANE_SELF() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#endif
 // a value the program knows to be wave-uniform -> scalar register (lets loops on it be scalar loops)
 #define FF_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 

@@ -40,6 +40,8 @@
 //   weight 1: max 2.9e-6, p99.9 1.6e-7, launch 0.79 ms | 4: 2.1e-6, 5.5e-8, 0.89 ms | 16: 2.1e-6, 1.3e-8, 1.05 ms
 //   (column kernel: 2.1e-7, 1.7e-8, 1.03 ms; the bar is 1e-5)
 // The weight is ff_ode.sum_weight (A.sum_w; the entry point substitutes the default, 4, for 0).
+#define FF_STAGE_DYN 99      // ff_eloc_mfma_kernel's evaluate(): the stage is the run-time value (the evaluations in front of a step)
+template <int V> struct ff_stage_c { static constexpr int value = V; };
 template <int NB, int NS>
 struct ff_jsplit_vec {
   double* col;
@@ -219,10 +221,20 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     int s = -2, nev = 0;
     double hs_keep = 0.0;      // = s_ctl[w].S.h of the attempt under way
 
-#pragma unroll 1
-    for (;;) {
+    // One evaluation of the right-hand side and what the Dormand-Prince step does with it.  The six stages of a step are SIX
+    // instantiations of this body (SG = 1 .. 6: the stage is a compile-time constant; straight-line code between them), the rare
+    // evaluations in front of a step -- the first one of a walker group (-2), the probe of Hairer's rule (-1), k0 again after a rejected
+    // step (0) -- share a seventh (SG = FF_STAGE_DYN: the stage is the run-time value s).  With ONE body and a run-time stage (rounds
+    // 3-6) every evaluation ended in a merge of nine branches and a loop back-edge, and the compiler moved the whole Dormand-Prince
+    // state -- 42 doubles per lane -- through two sets of registers on the way: 84 v_mov_b64 per evaluation, a tenth of the kernel's
+    // vector instructions; a stage known at compile time also knows which of c0 / c1 / c2 enter its input.
+    // Returns true when every walker of the wave has finished.
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      auto at = [&](int k) -> bool { if constexpr (SG == FF_STAGE_DYN) return s == k; else return SG == k; };
+      auto upto3 = [&]() -> bool { if constexpr (SG == FF_STAGE_DYN) return true; else return SG <= 3; };
       // the lane indices are laundered once per evaluation: otherwise every LDS address below becomes a loop-invariant register
-      int ln = lane;
+      int ln = FF_LANE_SELF();
       FF_OPAQUE(ln);
       const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c, tl = 16 * c + 4 * w + r;
       const bool owner = p < M;
@@ -232,21 +244,34 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       // g_k = hs a_k + b_k with the stage's tableau entries a_k and b_k in {0, 1} by scalar selects on the (wave-uniform) stage index:
       // as a switch over the stages this was a chain of ten scalar branches (round 6: -0.3 % of the pass together -- they hid under the
       // LDS wait)
+#ifdef FF_HS_FROM_LDS
+      const double hs = s_ctl[w].S.h;
+#else
       const double hs = hs_keep;
-      const double a0 = s == 1 ? FF_A10 : (s == 2 ? FF_A20 : (s == 3 ? FF_A30 : 0.0));
-      const double a1 = s == 2 ? FF_A21 : (s == 3 ? FF_A31 : 0.0);
-      const double a2 = s == 3 ? FF_A32 : 0.0;
-      const double gy = s <= 3 ? 1.0 : 0.0;
-      double g0 = fma(hs, a0, s == 4 ? 1.0 : 0.0);
-      const double g1 = fma(hs, a1, s == 5 ? 1.0 : 0.0), g2 = fma(hs, a2, s == 6 ? 1.0 : 0.0);
-      if (s == -1) g0 = s_ctl[w].h0v * s_ctl[w].S.dir;      // (cold start only: the probe evaluation of Hairer's rule)
-      auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y.get(v)))); };
+#endif
+      const double a0 = at(1) ? FF_A10 : (at(2) ? FF_A20 : (at(3) ? FF_A30 : 0.0));
+      const double a1 = at(2) ? FF_A21 : (at(3) ? FF_A31 : 0.0);
+      const double a2 = at(3) ? FF_A32 : 0.0;
+      double g0 = fma(hs, a0, at(4) ? 1.0 : 0.0);
+      const double g1 = fma(hs, a1, at(5) ? 1.0 : 0.0), g2 = fma(hs, a2, at(6) ? 1.0 : 0.0);
+      if (at(-1)) g0 = s_ctl[w].h0v * s_ctl[w].S.dir;      // (cold start only: the probe evaluation of Hairer's rule)
+      // (with a compile-time stage the vanishing terms are not formed: y + g0 c0 at stage 1, c0 alone at stage 4, ...)
+      auto form = [&](int v) -> double {
+        if constexpr (SG == FF_STAGE_DYN) return fma(g0, c0[v], y.get(v));      // stages -2, 0: g0 = 0; the probe: h0 k0
+        else if constexpr (SG == 1) return fma(g0, c0[v], y.get(v));
+        else if constexpr (SG == 2) return fma(g1, c1[v], fma(g0, c0[v], y.get(v)));
+        else return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], y.get(v))));
+      };
       // The J blocks of y live in LDS columns, and stages 4-6 take their input from c0 / c1 / c2 alone: those stages skip the nine LDS
       // reads (twice per evaluation) -- the kernel is bound by the LDS, not by what it issues.  (From stage 5 on c0
       // carries the error accumulator, times g0 = 0 here: finite for every walker that is still integrating.  A run-time select among
       // c0 / c1 / c2 instead would put all three arrays into scratch: 336 B per lane.)
-      const bool use_y = s <= 3;
-      auto form_noy = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], g0 * c0[v])); };
+      const bool use_y = upto3();
+      auto form_noy = [&](int v) -> double {
+        if constexpr (SG == 4) return c0[v];
+        else if constexpr (SG == 5) return c1[v];
+        else return c2[v];
+      };
       double out[NV];
       const double zin = use_y ? form(0) : form_noy(0), kin = use_y ? form(IK) : form_noy(IK);
       FF_STAMP(0);
@@ -569,9 +594,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       FF_SCHED_FENCE();
       // ------------------------------------------------------------------ consume (Dormand-Prince bookkeeping)
 #if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
-      const int s_prev = s;
+      const int s_prev = SG == FF_STAGE_DYN ? s : SG;
 #endif
-      if (s == -2) {
+      if (at(-2)) {
         ctl_t C; C.get(s_ctl[w]);
         FF_WG1_SYNC();
         const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
@@ -598,7 +623,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         hs_keep = C.S.h;
         s_ctl[w].get(C);
         FF_WG1_SYNC();
-      } else if (s == -1) {
+      } else if (at(-1)) {
         ctl_t C; C.get(s_ctl[w]);
         FF_WG1_SYNC();
         const double sens_w = C.sens_w, w0 = owner ? 1.0 : A.sum_w * sens_w;
@@ -618,19 +643,19 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         s_ctl[w].get(C);
         FF_WG1_SYNC();
         s = 1;
-      } else if (s == 0) {
+      } else if (at(0)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         s = 1;
-      } else if (s == 1) {
+      } else if (at(1)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c1[v] = out[v];
         s = 2;
-      } else if (s == 2) {
+      } else if (at(2)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c2[v] = out[v];
         s = 3;
-      } else if (s == 3) {
+      } else if (at(3)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v], yv = y.get(v);
@@ -638,21 +663,27 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
           c1[v] = fma(hs, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
           c2[v] = fma(hs, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
           c3.set(v, hs * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v));
+          // (with the stages laid out one behind the other the compiler sinks these sums to where they are used -- c1 into stage 5, c2
+          // into stage 6 -- and keeps k0 .. k3, 96 registers, alive through the right-hand sides in between: 112 B of scratch per
+          // lane.  An empty asm pins each result here.)
+          FF_OPAQUE(c0[v]); FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]);
         }
         s = 4;
-      } else if (s == 4) {
+      } else if (at(4)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c1[v] = fma(hs * FF_A54, out[v], c1[v]);
           c2[v] = fma(hs * FF_B4, out[v], c2[v]);
           c0[v] = fma(hs * FF_E4, out[v], c3.get(v));      // c0 -- the input of this stage -- is free now: the error accumulator lives there
+          FF_OPAQUE(c0[v]); FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]);
         }                                                   // through stages 5 and 6 (its LDS columns: one write at stage 3, one read here)
         s = 5;
-      } else if (s == 5) {
+      } else if (at(5)) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c2[v] = fma(hs * FF_B5, out[v], c2[v]);
           c0[v] = fma(hs * FF_E5, out[v], c0[v]);
+          FF_OPAQUE(c0[v]); FF_OPAQUE(c2[v]);
         }
         s = 6;
       } else {
@@ -680,14 +711,27 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         s_ctl[w].get(C);
         FF_WG1_SYNC();
         const int any = ff_wave_or(&s_any, lane, C.S.done ? 0 : ((was_active && !acc) ? 3 : 1));
-        if (!any) break;
         s = (any & 2) ? 0 : 1;
+        if (!any) return true;
       }
 #if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)      // consume ticks by stage (the price list of a per-walker stage index: DESIGN.md 3o)
       { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stage_acc[s_prev + 2] += t_ - stamp_prev; stage_cnt[s_prev + 2]++; }
 #endif
       FF_STAMP(6);
       FF_SCHED_FENCE();
+      return false;
+    };
+    // the evaluations in front of a step, then its six stages
+#pragma unroll 1
+    for (;;) {
+#pragma unroll 1
+      while (s <= 0) evaluate(ff_stage_c<FF_STAGE_DYN>{});
+      evaluate(ff_stage_c<1>{});
+      evaluate(ff_stage_c<2>{});
+      evaluate(ff_stage_c<3>{});
+      evaluate(ff_stage_c<4>{});
+      evaluate(ff_stage_c<5>{});
+      if (evaluate(ff_stage_c<6>{})) break;
     }
     // ---------------------------------------------------------------------- fused finish (ff_eloc, nup = ndn; wave-uniform branch)
     // What ff_eloc_slater_fixed_kernel + ff_eloc_contract_kernel did from the workspace, on the walker's sixteen lanes while J is

@@ -171,6 +171,31 @@ def test_tabulated_adjoint_matches_direct(golden):
     np.testing.assert_allclose(gp_t2, gp_e2, atol=1e-9 * np.abs(gp_e2).max())
 
 
+def test_deposit_rows_are_as_long_as_the_weights_need(golden):
+    """ff_radial.h header slot 5: the table kernel picks 6, 8, 10 or 12 coefficients per deposit row from max|w1| (remainder of the
+    expansion held at 4.5e-12); the tabulated adjoint's parameter gradient equals the direct kernel's for every choice."""
+    G = golden["g4_cnf"]
+    eta, mu = net_arrays(G, "")
+    wmax = max(np.abs(eta[0]).max(), np.abs(mu[0]).max())
+    tag, rt, at = "tol10", 1e-10, 1e-12
+    seen = set()
+    for target in (0.3, 1.0, 2.5, 5.0):      # max|w1| after scaling: h_d = 1/16 -> 1.5 w h_d = 0.028 ... 0.47
+        sc = target / wmax
+        e2, m2 = (eta[0] * sc, eta[1], eta[2]), (mu[0] * sc, mu[1], mu[2])
+        tab = S.Net(e2, m2, table=True)
+        assert tab.tab[3] == 0.0 and tab.tab[4] == 0.0
+        nrow = int(tab.tab[5])
+        xd = 1.5 * target / 16.0
+        import math
+        want = next((n for n in (6, 8, 10) if xd ** n / math.factorial(n) <= 4.5e-12), 12)
+        assert nrow == want, (target, nrow, want)
+        seen.add(nrow)
+        _, gp_e, _ = S.cnf_adjoint(G[tag + "_zback"][:6], G[tag + "_cz"][:6], G[tag + "_cd"][:6], S.Net(e2, m2), rtol=rt, atol=at)
+        _, gp_t, _ = S.cnf_adjoint(G[tag + "_zback"][:6], G[tag + "_cz"][:6], G[tag + "_cd"][:6], tab, rtol=rt, atol=at)
+        np.testing.assert_allclose(gp_t, gp_e, atol=1e-10 * np.abs(gp_e).max())
+    assert seen == {6, 8, 10, 12}
+
+
 def test_radii_beyond_the_table_fall_back_to_direct_evaluation(golden):
     """walkers spread over +-60 (pair distances far beyond FF_TAB_RMAX = 32): the forward kernels evaluate those radii
     directly, the tabulated adjoint raises its off-table flag and the direct adjoint kernel redoes the call."""
