@@ -332,8 +332,13 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
       return t;
     };
 
-#pragma unroll 1
-    for (;;) {
+    // One evaluation and what the step does with it; instantiated per stage (with a run-time stage the step state --
+    // y, k0 .. k5 and the six records of every radius -- went through two sets of registers at the end of every evaluation).
+    // Returns true when every walker of the wave has finished.
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       double in[NV];
       const double h = S.h;
       {
@@ -341,10 +346,10 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         // from the constant table FF_ATAB by scalar loads issued where they were needed -- 1 600 of the 5 100 cycles of a
         // wave-evaluation were that wait (s_memtime stamps, profiles/r04_b_adjoint_stamps.json).  Same products in the same
         // order, the zero entries of a row dropped (fma(0, k, x) = x): bit-identical stage inputs.
-        const double hsel = (s == -1) ? h0v * S.dir : h;
+        const double hsel = (sv == -1) ? h0v * S.dir : h;
 #pragma unroll
         for (int v = 0; v < NV; v++) in[v] = y[v];
-        switch (s) {
+        switch (sv) {
           case -1:
 #pragma unroll
             for (int v = 0; v < NV; v++) in[v] = fma(hsel, k0[v], y[v]);
@@ -463,9 +468,9 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         out[1] = fma(s_ad[gg], gdi, -dvk);
       }
       FF_STAMP(3);
-      const int s_before = s;
+      const int s_before = sv;
       // ------------------------------------------------------------------ consume
-      if (s == -2) {
+      if (sv == -2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k0[v] = out[v];
 #pragma unroll
@@ -487,7 +492,7 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
           S.plan();
           s = 1;
         }
-      } else if (s == -1) {
+      } else if (sv == -1) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -499,35 +504,35 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
-      } else if (s == 0) {
+      } else if (sv == 0) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k0[v] = out[v];
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) r0[sl] = cur[sl];
         s = 1;
-      } else if (s == 1) {
+      } else if (sv == 1) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k1[v] = out[v];
         s = 2;
-      } else if (s == 2) {
+      } else if (sv == 2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k2[v] = out[v];
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) r2[sl] = cur[sl];
         s = 3;
-      } else if (s == 3) {
+      } else if (sv == 3) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k3[v] = out[v];
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) r3[sl] = cur[sl];
         s = 4;
-      } else if (s == 4) {
+      } else if (sv == 4) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k4[v] = out[v];
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) r4[sl] = cur[sl];
         s = 5;
-      } else if (s == 5) {
+      } else if (sv == 5) {
 #pragma unroll
         for (int v = 0; v < NV; v++) k5[v] = out[v];
 #pragma unroll
@@ -581,10 +586,22 @@ ff_ode_adjtab_kernel(ff_adj_args A) {
         }
         S.plan();
         const int any = ff_wave_or_w(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
-        if (!any) break;
         s = (any & 2) ? 0 : 1;
+        if (!any) { FF_STAMP(5); return true; }
       }
       if (s_before == 6) FF_STAMP(5); else FF_STAMP(4);
+      return false;
+    };
+#pragma unroll 1
+    for (;;) {
+#pragma unroll 1
+      while (s <= 0) evaluate(ff_stage_c<FF_STAGE_DYN>{});
+      evaluate(ff_stage_c<1>{});
+      evaluate(ff_stage_c<2>{});
+      evaluate(ff_stage_c<3>{});
+      evaluate(ff_stage_c<4>{});
+      evaluate(ff_stage_c<5>{});
+      if (evaluate(ff_stage_c<6>{})) break;
     }
     if (valid) {
       const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN gradients (see ff_ode_adj_kernel)

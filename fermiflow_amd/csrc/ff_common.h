@@ -68,6 +68,14 @@
 #define ff_wave_ballot(pred) __ballot(pred)      // (on the GPU a ballot IS per wave; the host simulator's needs to know which wave)
 #endif
 
+// Stage of a Dormand-Prince step as a compile-time constant (the kernels' evaluate() bodies are instantiated once per stage 1 .. 6,
+// straight-line code between them, and once for the rare evaluations in front of a step, where the stage is a run-time value)
+#ifndef FF_ASSUME
+#define FF_ASSUME(x) __builtin_assume(x)
+#endif
+#define FF_STAGE_DYN 99
+template <int V> struct ff_stage_c { static constexpr int value = V; };
+
 // the lane's index within its wave, recomputed where it is needed (two instructions) instead of kept in a register across a loop --
 // in a single-wave workgroup this IS threadIdx.x, which lives in an input register the allocator can only spill
 #ifndef FF_LANE_SELF

@@ -40,8 +40,6 @@
 //   weight 1: max 2.9e-6, p99.9 1.6e-7, launch 0.79 ms | 4: 2.1e-6, 5.5e-8, 0.89 ms | 16: 2.1e-6, 1.3e-8, 1.05 ms
 //   (column kernel: 2.1e-7, 1.7e-8, 1.03 ms; the bar is 1e-5)
 // The weight is ff_ode.sum_weight (A.sum_w; the entry point substitutes the default, 4, for 0).
-#define FF_STAGE_DYN 99      // ff_eloc_mfma_kernel's evaluate(): the stage is the run-time value (the evaluations in front of a step)
-template <int V> struct ff_stage_c { static constexpr int value = V; };
 template <int NB, int NS>
 struct ff_jsplit_vec {
   double* col;

@@ -31,6 +31,7 @@ inline pthread_barrier_t* ff_sim_bar = nullptr;
 // workgroups of several INDEPENDENT waves (the two-wave tabulated adjoint): one barrier per wave of 64 "lanes"
 inline pthread_barrier_t ff_sim_wave_bar[16];
 #define FF_WAVE_SYNC() pthread_barrier_wait(&ff_sim_wave_bar[threadIdx.x >> 6])
+#define FF_ASSUME(x) do { } while (0)
 #define FF_LANE_SELF() ((int)(threadIdx.x & 63))
 #define FF_WAVE_ORDER() FF_WAVE_SYNC()
 #define FF_WG1_SYNC() pthread_barrier_wait(ff_sim_bar)      // (single-wave workgroups: the workgroup barrier IS the wave barrier)
