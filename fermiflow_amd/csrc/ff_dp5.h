@@ -150,7 +150,9 @@ FF_D float ff_t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c);
 FF_D double ff_t_rcp(double x) { return ff_rcp(x); }
 FF_D float ff_t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp: error norms only
 
-template <int NA, class TA, class C3A, int NB, class C3B, class YA, class WB, class G>
+// PIN: the caller lays the stages out one behind the other (a compile-time s): the updated vectors are pinned where they are computed
+// -- the compiler otherwise sinks them into the stages that use them and keeps k0 .. k3 alive through the right-hand sides in between.
+template <int NA, class TA, class C3A, int NB, class C3B, class YA, class WB, class G, bool PIN = false>
 FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, TA* c1A, TA* c2A, C3A& c3A, const TA* outA, double wA_,
                          double* yB, double* c0B, double* c1B, double* c2B, C3B& c3B, const double* outB, WB wgtB, G gsum) {
   const double h = S.h, rtol = C.rtol, atol = C.atol;
@@ -230,6 +232,7 @@ FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, T
       c1A[v] = ff_t_fma(hA, (TA)FF_A50 * k0v + (TA)FF_A51 * k1v + (TA)FF_A52 * k2v + (TA)FF_A53 * k3v, yv);
       c2A[v] = ff_t_fma(hA, (TA)FF_B0 * k0v + (TA)FF_B2 * k2v + (TA)FF_B3 * k3v, yv);
       c3A[v] = hA * ((TA)FF_E0 * k0v + (TA)FF_E2 * k2v + (TA)FF_E3 * k3v);
+      if constexpr (PIN) { FF_OPAQUE(c0A[v]); FF_OPAQUE(c1A[v]); FF_OPAQUE(c2A[v]); }
     }
 #pragma unroll
     for (int v = 0; v < NB; v++) {
@@ -238,6 +241,7 @@ FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, T
       c1B[v] = fma(h, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
       c2B[v] = fma(h, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
       c3B[v] = h * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+      if constexpr (PIN) { FF_OPAQUE(c0B[v]); FF_OPAQUE(c1B[v]); FF_OPAQUE(c2B[v]); }
     }
     return 4;
   }
@@ -251,6 +255,7 @@ FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, T
       // with c3 in registers the longer life of c0 only costs -- the fp32 kernel of configs[4] spilled 92 B and lost 1.2 %)
       if constexpr (ACC0) c0A[v] = ff_t_fma(hA * (TA)FF_E4, outA[v], (TA)c3A[v]);
       else c3A[v] = ff_t_fma(hA * (TA)FF_E4, outA[v], (TA)c3A[v]);
+      if constexpr (PIN) { FF_OPAQUE(c1A[v]); FF_OPAQUE(c2A[v]); if constexpr (ACC0) FF_OPAQUE(c0A[v]); }
     }
 #pragma unroll
     for (int v = 0; v < NB; v++) {
@@ -258,6 +263,7 @@ FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, T
       c2B[v] = fma(h * FF_B4, outB[v], c2B[v]);
       if constexpr (ACC0) c0B[v] = fma(h * FF_E4, outB[v], c3B[v]);
       else c3B[v] = fma(h * FF_E4, outB[v], c3B[v]);
+      if constexpr (PIN) { FF_OPAQUE(c1B[v]); FF_OPAQUE(c2B[v]); if constexpr (ACC0) FF_OPAQUE(c0B[v]); }
     }
     return 5;
   }
@@ -267,12 +273,14 @@ FF_D int ff_dp5_consume2(int s, ff_stepper& S, ff_dp5_ctl& C, YA& yA, TA* c0A, T
       c2A[v] = ff_t_fma(hA * (TA)FF_B5, outA[v], c2A[v]);
       if constexpr (ACC0) c0A[v] = ff_t_fma(hA * (TA)FF_E5, outA[v], c0A[v]);
       else c3A[v] = ff_t_fma(hA * (TA)FF_E5, outA[v], (TA)c3A[v]);
+      if constexpr (PIN) { FF_OPAQUE(c2A[v]); if constexpr (ACC0) FF_OPAQUE(c0A[v]); }
     }
 #pragma unroll
     for (int v = 0; v < NB; v++) {
       c2B[v] = fma(h * FF_B5, outB[v], c2B[v]);
       if constexpr (ACC0) c0B[v] = fma(h * FF_E5, outB[v], c0B[v]);
       else c3B[v] = fma(h * FF_E5, outB[v], c3B[v]);
+      if constexpr (PIN) { FF_OPAQUE(c2B[v]); if constexpr (ACC0) FF_OPAQUE(c0B[v]); }
     }
     return 6;
   }

@@ -462,8 +462,18 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
     auto wgt = [&](int v) -> double { return v == IZ ? 1.0 : sens_w; };      // (the J elements all weigh sens_w)
     auto gsum = [&](double part) -> double { return ff_wide_sum<NTHR>(s_red, s_red2, tid, part); };
 
-#pragma unroll 1
-    for (;;) {
+    // One evaluation and what the Dormand-Prince step does with it, instantiated per stage where STATIC_STAGES (with a
+    // run-time stage every evaluation ends in a merge through which the compiler moves the whole step state -- here four vectors of
+    // 4 T + 4 values per lane plus the stage J, through AGPR copy chains).  Returns true when the walker has finished.
+#ifdef FF_WIDE_DYNAMIC_STAGES
+    constexpr bool STATIC_STAGES = false;
+#else
+    constexpr bool STATIC_STAGES = TAB;      // (the direct-evaluation fallbacks keep the loop over a run-time stage)
+#endif
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN && STATIC_STAGES) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       TJ outJ[NVJ];
       double out[NVS];
 #ifdef FF_WIDE_SELFCHECK   // (experiment of DESIGN.md 4: every right-hand side is evaluated twice from the same registers and compared)
@@ -473,7 +483,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       if (rep >= 1) __syncthreads();
 #endif
       double gy, g0, g1, g2;
-      ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
+      ff_dp5_coeffs(sv, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       auto form = [&](int v) -> double { return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], gy * y[v]))); };
       const TJ gyJ = (TJ)gy, g0J = (TJ)g0, g1J = (TJ)g1, g2J = (TJ)g2;
       FF_STAMP(7);
@@ -481,7 +491,7 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       // it is the B operand of J' = A J)
       auto formJ = [&](int v) -> TJ { return ff_t_fma(g2J, c2J[v], ff_t_fma(g1J, c1J[v], ff_t_fma(g0J, c0J[v], gyJ * yJ[v]))); };
       TJ Jin[NVJ];
-      if (!Y_LDS || s <= 3) {
+      if (!Y_LDS || sv <= 3) {
 #pragma unroll
         for (int v = 0; v < NVJ; v++) Jin[v] = formJ(v);
       } else {      // stages 4-6 take their input from c0 / c1 / c2 alone: no LDS read of y's J part (from stage 5 on c0 holds the error accumulator, times 0)
@@ -731,9 +741,29 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
       }
       }      // rep
 #endif
-      s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3), decltype(yJ)>(s, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
+      s = ff_dp5_consume2<NVJ, TJ, decltype(c3J), NVS, decltype(c3), decltype(yJ), decltype(wgt), decltype(gsum), STATIC_STAGES>(sv, S, C, yJ, c0J, c1J, c2J, c3J, outJ, sens_w, y, c0, c1, c2, c3, out, wgt, gsum);
       FF_STAMP(8);
-      if (s == 99) break;
+      return s == 99;
+    };
+    if constexpr (STATIC_STAGES) {
+#pragma unroll 1
+      for (;;) {
+        bool fin = false;
+#pragma unroll 1
+        while (s <= 0 && !fin) fin = evaluate(ff_stage_c<FF_STAGE_DYN>{});
+        if (fin) break;
+        evaluate(ff_stage_c<1>{});
+        evaluate(ff_stage_c<2>{});
+        evaluate(ff_stage_c<3>{});
+        evaluate(ff_stage_c<4>{});
+        evaluate(ff_stage_c<5>{});
+        if (evaluate(ff_stage_c<6>{})) break;
+      }
+    } else {
+#pragma unroll 1
+      for (;;) {
+        if (evaluate(ff_stage_c<FF_STAGE_DYN>{})) break;
+      }
     }
     // -------------------------------------------------------------------- results
     const bool failed = S.fail != 0;
