@@ -101,6 +101,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
   const bool has_mu = A.net.Hm > 0;
   const int nrad = has_mu ? P + n : P;
   const double tab_inv_h = rtab[0], tab_h = rtab[1];
+  const int dep_nrow = FF_UNIFORM(rtab[5] >= 6.0 && rtab[5] <= (double)FF_DEP_ROW ? (int)rtab[5] : FF_DEP_ROW);   // coefficients per deposit row
   int rq_id[NQ];
 #pragma unroll
   for (int sl = 0; sl < NQ; sl++) rq_id[sl] = ff_wadj_radius_id(n, lane + sl * NTHR, nrad);
@@ -141,11 +142,12 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
               const int pos = atomicAdd(&s_novl, 1);
               if (pos < FF_WOVL) { ff_wdep o = rc; o.ca *= w; o.cb *= w; s_ovl[pos] = o; }
             } else {
+              // (dep_nrow coefficients: what the launch's weights need -- header slot 5 of the radial table, ff_radial.h)
               double pk = 1.0, pm = 0.0;
               double* row = &s_Tt[rc.t][rc.j][0];
 #pragma unroll
               for (int k = 0; k < FF_DEP_ROW; k++) {
-                atomicAdd(row + k, w * fma(rc.ca, pk, rc.cb * pm));
+                if (k < 6 || k < dep_nrow) atomicAdd(row + k, w * fma(rc.ca, pk, rc.cb * pm));
                 pm = pk;
                 pk = pk * rc.dr * (1.0 / (k + 1));
               }
