@@ -81,7 +81,10 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
   constexpr int RW = (2 * D + 3) | 1;     // odd: the row lanes of a wave read up to 4 N records at a time, one bank group each
   constexpr int QF0 = D, QF1 = D + 1, QGQ = D + 2, QPW = D + 3;
   __shared__ double s_rec[(G * P + 1) * RW];   // one record per PAIR radius + one that stays zero
-  __shared__ double s_cv[2 * NB][FF_WAVE];   // the J blocks of y and of the error accumulator of the Dormand-Prince step, lane-private columns
+#ifndef FF_MFMA_Y_COLS
+#define FF_MFMA_Y_COLS 0      // 1: y's J blocks in LDS columns as in rounds 3-6 (A/B)
+#endif
+  __shared__ double s_cv[(FF_MFMA_Y_COLS ? 2 : 1) * NB][FF_WAVE];   // the J blocks of the error accumulator of the Dormand-Prince step (and, FF_MFMA_Y_COLS, of y), lane-private columns
   __shared__ int s_any;
   __shared__ int s_st[4];
   __shared__ long long s_next;
@@ -193,7 +196,11 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
     walker_of(w, b, valid);
     // Dormand-Prince storage as in ff_ode_fwd_kernel: y, c0..c2 (k0..k2, then the inputs of stages 4, 5 and y_new), c3 (error)
     double c0[NV], c1[NV], c2[NV];
-    ff_jsplit_vec<NB, 3> y(&s_cv[0][0], lane), c3(&s_cv[NB][0], lane);
+    // y in registers (round 6, late: with compile-time stages the kernel runs at 208 registers, and y's J blocks -- read from their LDS
+    // columns in every evaluation of stages 1-3, written at every accepted step -- fit: 238); the error accumulator c3, written at
+    // stage 3 and read at stage 4, keeps its J blocks in lane-private LDS columns (in registers as well: 256 + 68 B of scratch)
+    ff_jsplit_vec<FF_MFMA_Y_COLS ? NB : 0, FF_MFMA_Y_COLS ? 3 : NV> y(&s_cv[0][0], lane);
+    ff_jsplit_vec<NB, 3> c3(&s_cv[FF_MFMA_Y_COLS ? NB : 0][0], lane);
 #pragma unroll
     for (int v = 0; v < NV; v++) { y.set(v, 0.0); c0[v] = 0.0; c1[v] = 0.0; c2[v] = 0.0; c3.set(v, 0.0); }
     {
@@ -322,6 +329,9 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         }
       }
       // ------------------------------------------------------------------ S = J J^T on the matrix cores
+      // (stages 1-3: the stage's J blocks are formed ONCE -- y's part read from its LDS columns once -- and kept for J' = A J below:
+      // eighteen registers the kernel has had to spare since its stages are compile-time constants, 251 -> 208)
+      double Jk[NB];
       {
         // The blocks transposed in place, lane (r, c) <-> (c, r) -- by the matrix cores: a lane's element fed as the A operand IS the
         // transposed block (A_blk[i][k] is supplied by lane (k, i)), so one product with the identity returns it in the C/D layout,
@@ -331,7 +341,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         const double idn = r == c ? 1.0 : 0.0;
         if (use_y) {
 #pragma unroll
-          for (int e = 0; e < NB; e++) Jt[e] = ff_block_transpose(form(1 + e), idn, tl);
+          for (int e = 0; e < NB; e++) { Jk[e] = form(1 + e); Jt[e] = ff_block_transpose(Jk[e], idn, tl); }
         } else {
 #pragma unroll
           for (int e = 0; e < NB; e++) Jt[e] = ff_block_transpose(form_noy(1 + e), idn, tl);
@@ -540,7 +550,11 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         double Jin[NB];
         if (use_y) {
 #pragma unroll
+#ifdef FF_REFORM_JIN
           for (int e = 0; e < NB; e++) Jin[e] = form(1 + e);
+#else
+          for (int e = 0; e < NB; e++) Jin[e] = Jk[e];
+#endif
         } else {
 #pragma unroll
           for (int e = 0; e < NB; e++) Jin[e] = form_noy(1 + e);
