@@ -468,7 +468,9 @@ ff_wide_eloc_kernel(ff_fwd_args A, int n) {
 #ifdef FF_WIDE_DYNAMIC_STAGES
     constexpr bool STATIC_STAGES = false;
 #else
-    constexpr bool STATIC_STAGES = TAB;      // (the direct-evaluation fallbacks keep the loop over a run-time stage)
+    // (the direct-evaluation fallbacks keep the loop over a run-time stage; so does the one instantiation in which ROCm 7.2's register
+    // allocator answered the new layout with its copy-in-front-of-the-exec-restore bug: tools/check_agpr_spills.py, docs/LOG.md round 2)
+    constexpr bool STATIC_STAGES = TAB && !(D == 3 && T == 3 && sizeof(TJ) == 4 && FIN);
 #endif
     auto evaluate = [&](auto stage_tag) -> bool {
       constexpr int SG = decltype(stage_tag)::value;
