@@ -14,20 +14,23 @@
 // (= the instruction's B and C/D layout), MB^2 doubles.
 //   J' block (I, Kc)  = sum_K  mfma(A-operand of A(I,K), Jb[K][Kc]);  A is symmetric, so that operand -- A[4I+c][4K+r] --
 //                       is A[4K+r][4I+c]: element (r, c) of block (K, I), read straight from the assembled matrix in LDS;
-//   S  block (I, Kc)  = sum_K  mfma(Jt[I][K], Jt[Kc][K]),  Jt = the blocks transposed in place (lane (r,c) <-> (c,r): two
-//                       ds_bpermute per double); only I <= Kc is computed, both halves are written to LDS.
+//   S  block (I, Kc)  = sum_K  mfma(Jt[I][K], Jt[Kc][K]),  Jt = the blocks transposed in place (lane (r,c) <-> (c,r)) -- by the
+//                       matrix cores themselves: a lane's element fed as the A operand IS the transposed block, one product with the
+//                       identity returns it (round 6; the LDS crossbar took two ds_bpermute per double); only I <= Kc is computed.
 // Everything else is per-radius or per-coordinate work, without atomics:
-//   R1  radius lanes -- the R radii of a walker are dealt over ITS sixteen lanes (radius i16, i16 + 16, ...): heads from the
-//       radial table, one record per radius (rho, eta, eta'/r, c phi'/r, 1/r^2, the first-order part of D_v[kbar], eta'', c phi'')
-//       in LDS; the radius' shares of div v and of the Laplacian source stay on the lane (Delta and lap Delta are integrated as
-//       per-lane partial sums);
-//   rows  lane (r, c) owns coordinate p = 4r + c (< M) of particle a = p / D: it walks the N records of its particle (pairs
-//       with either sign, the one-body radius), sums v_p, (A kbar)_p, (grad div)_p and the diagonal block of A, and stores row p
-//       of A -- every element of A is written by exactly one lane;
+//   R1  radius lanes -- the P PAIR radii of a walker are dealt over ITS sixteen lanes: heads from the radial table, one record per
+//       radius (rho, eta, eta'/r, c phi'/r, the first-order part of D_v[kbar] + the second-order source) in LDS; the radius' shares
+//       of div v and of the Laplacian source stay on the lane (Delta and lap Delta are integrated as per-lane partial sums, joined
+//       over the walker's quads by a product with ones);
+//       the ONE-BODY radius of a particle is evaluated by that particle's own row lanes and applied from registers (no record);
+//   rows  lane (r, c) owns coordinate p = 4r + c (< M) of particle a = p / D: it walks the N - 1 pair records of its particle
+//       (either sign), sums v_p, (A kbar)_p, (grad div)_p and the diagonal block of A, and stores row p of A -- every element
+//       of A is written by exactly one lane;
 //   R2  radius lanes: W from S, the second-order sources written back into the record; the row lanes gather them.
+//   The six stages of a Dormand-Prince step are six instantiations of the evaluation (compile-time stage: DESIGN.md 3s).
 //   S takes the place of A in LDS once the last operand of J' = A J has been read (one wave per workgroup: program order).
 //   The component 4c + r of grad Delta sits on lane (r, c) (it comes out of the transposed blocks by a quad reduction).
-// 20 KB of LDS and <= 256 registers: two waves per SIMD (the vector pipe issues at half rate for a single wave).
+// 14 KB of LDS and 236 registers: two waves per SIMD (the vector pipe issues at half rate for a single wave).
 #pragma once
 
 // Dormand-Prince vector of a lane whose components 1 .. NB (the J blocks) live in lane-private LDS columns and whose other
@@ -244,11 +247,10 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
       const int r = ln >> 4, w = (ln >> 2) & 3, c = ln & 3, p = 4 * r + c, tl = 16 * c + 4 * w + r;
       const bool owner = p < M;
       const int ra = owner ? p / D : 0, rc = owner ? p % D : 0;
-      // ------------------------------------------------------------------ stage input (one expression for all stages)
+      // ------------------------------------------------------------------ stage input
       // The walker's step size comes from a register copy of s_ctl[w].S.h (no LDS round trip in front of an evaluation), and
-      // g_k = hs a_k + b_k with the stage's tableau entries a_k and b_k in {0, 1} by scalar selects on the (wave-uniform) stage index:
-      // as a switch over the stages this was a chain of ten scalar branches (round 6: -0.3 % of the pass together -- they hid under the
-      // LDS wait)
+      // g_k = hs a_k + b_k with the stage's tableau entries a_k and b_k in {0, 1}: constants in the per-stage instantiations, scalar
+      // selects on the (wave-uniform) stage index in the run-time one
 #ifdef FF_HS_FROM_LDS
       const double hs = s_ctl[w].S.h;
 #else
@@ -267,10 +269,7 @@ ff_eloc_mfma_kernel(ff_fwd_args A) {
         else if constexpr (SG == 2) return fma(g1, c1[v], fma(g0, c0[v], y.get(v)));
         else return fma(g2, c2[v], fma(g1, c1[v], fma(g0, c0[v], y.get(v))));
       };
-      // The J blocks of y live in LDS columns, and stages 4-6 take their input from c0 / c1 / c2 alone: those stages skip the nine LDS
-      // reads (twice per evaluation) -- the kernel is bound by the LDS, not by what it issues.  (From stage 5 on c0
-      // carries the error accumulator, times g0 = 0 here: finite for every walker that is still integrating.  A run-time select among
-      // c0 / c1 / c2 instead would put all three arrays into scratch: 336 B per lane.)
+      // Stages 4-6 take their input from c0 / c1 / c2 alone (with a compile-time stage: from the one array that holds it).
       const bool use_y = upto3();
       auto form_noy = [&](int v) -> double {
         if constexpr (SG == 4) return c0[v];
