@@ -771,11 +771,14 @@ ff_eloc_split_kernel(ff_fwd_args A) {
     const double sens_w = loose ? A.sens_w : 1.0;
     auto wgt = [&](int v) -> double { return ((v == 0 || v == MH + 1) && !owner) ? 0.0 : (v >= 1 ? sens_w : 1.0); };
 
-#pragma unroll 1
-    for (;;) {
+    // One evaluation and what the step does with it, instantiated per stage.  Returns true when every walker has finished.
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       const double hs = S.h;
       double gy = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
-      switch (s) {
+      switch (sv) {
         case -1: g0 = h0v * S.dir; break;
         case 1: g0 = hs * FF_A10; break;
         case 2: g0 = hs * FF_A20; g1 = hs * FF_A21; break;
@@ -955,7 +958,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
       out[MH + 3] = -divv;
       out[MH + 4] = -(qdiv + (owner ? gdi * in[MH + 1] : 0.0));
       // ------------------------------------------------------------------ consume
-      if (s == -2) {
+      if (sv == -2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         double p0 = 0.0, p1 = 0.0;
@@ -975,7 +978,7 @@ ff_eloc_split_kernel(ff_fwd_args A) {
           S.plan();
           s = 1;
         }
-      } else if (s == -1) {
+      } else if (sv == -1) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -987,19 +990,19 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
-      } else if (s == 0) {
+      } else if (sv == 0) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         s = 1;
-      } else if (s == 1) {
+      } else if (sv == 1) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c1[v] = out[v];
         s = 2;
-      } else if (s == 2) {
+      } else if (sv == 2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c2[v] = out[v];
         s = 3;
-      } else if (s == 3) {
+      } else if (sv == 3) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v], yv = y[v];
@@ -1007,21 +1010,24 @@ ff_eloc_split_kernel(ff_fwd_args A) {
           c1[v] = fma(hs, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, yv);
           c2[v] = fma(hs, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, yv);
           c3[v] = hs * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+          FF_OPAQUE(c0[v]); FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]);      // (not sunk into the stages that use them)
         }
         s = 4;
-      } else if (s == 4) {
+      } else if (sv == 4) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c1[v] = fma(hs * FF_A54, out[v], c1[v]);
           c2[v] = fma(hs * FF_B4, out[v], c2[v]);
           c3[v] = fma(hs * FF_E4, out[v], c3[v]);
+          FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]);
         }
         s = 5;
-      } else if (s == 5) {
+      } else if (sv == 5) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c2[v] = fma(hs * FF_B5, out[v], c2[v]);
           c3[v] = fma(hs * FF_E5, out[v], c3[v]);
+          FF_OPAQUE(c2[v]);
         }
         s = 6;
       } else {
@@ -1042,9 +1048,21 @@ ff_eloc_split_kernel(ff_fwd_args A) {
         }
         S.plan();
         const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
-        if (!any) break;
         s = (any & 2) ? 0 : 1;
+        if (!any) return true;
       }
+      return false;
+    };
+#pragma unroll 1
+    for (;;) {
+#pragma unroll 1
+      while (s <= 0) evaluate(ff_stage_c<FF_STAGE_DYN>{});
+      evaluate(ff_stage_c<1>{});
+      evaluate(ff_stage_c<2>{});
+      evaluate(ff_stage_c<3>{});
+      evaluate(ff_stage_c<4>{});
+      evaluate(ff_stage_c<5>{});
+      if (evaluate(ff_stage_c<6>{})) break;
     }
     // ---------------------------------------------------------------------- results: combine the per-lane partials
     const double dpart = y[MH + 2], delpart = y[MH + 3], lpart = y[MH + 4];
