@@ -221,8 +221,21 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
 #ifndef FF_ADJ_G12
 #define FF_ADJ_G12 3
 #endif
-template <int N, int D> struct ff_adjtab_geom { static constexpr int G = (N * D == 12) ? FF_ADJ_G12 : ff_geom<N, D>::G; };
-static int adj_tab_G(int n, int d) { return n * d == 12 ? FF_ADJ_G12 : (n * d > 0 && n * d <= FF_WAVE ? (FF_WAVE / (n * d) > 16 ? 16 : FF_WAVE / (n * d)) : 0); }
+// (4, 5, 7 and 9 particles likewise -- round 6: with 64 / M walkers their 80-135 radii per wave took two or three record slots per lane
+// and 144-528 B of scratch at two waves per SIMD; as many walkers as keep the radii at one per lane instead)
+constexpr int ff_adjtab_G(int n, int d) {
+  const int M = n * d;
+  if (M <= 0 || M > FF_WAVE) return 0;
+  const int g = FF_WAVE / M > 16 ? 16 : FF_WAVE / M;
+  if (M == 12) return FF_ADJ_G12;
+  if (d == 2 && (n == 4 || n == 5 || n == 7 || n == 9)) {
+    const int gr = FF_WAVE / (n * (n + 1) / 2);
+    return gr < 1 ? 1 : (gr < g ? gr : g);
+  }
+  return g;
+}
+template <int N, int D> struct ff_adjtab_geom { static constexpr int G = ff_adjtab_G(N, D); };
+static int adj_tab_G(int n, int d) { return ff_adjtab_G(n, d); }
 
 // WPW waves per workgroup.  A wave at 290 registers and 33 KB of LDS (27 KB of it the deposit table) is alone on its SIMD, and
 // every phase of its right-hand side -- radial-table fetch, LDS round trips, dependent fp64 issue -- is exposed: 5 100 cycles per
