@@ -221,14 +221,15 @@ FF_D void ff_deposit5(double (*sW)[FF_DEP_NLDS][FF_DEP_LROW], double* __restrict
 #ifndef FF_ADJ_G12
 #define FF_ADJ_G12 3
 #endif
-// (4, 5, 7 and 9 particles likewise -- round 6: with 64 / M walkers their 80-135 radii per wave took two or three record slots per lane
-// and 144-528 B of scratch at two waves per SIMD; as many walkers as keep the radii at one per lane instead)
+// (4, 5, 7, 9, 10 and 11 particles likewise -- round 6: with 64 / M walkers their 80-165 radii per wave took two or three record slots
+// per lane, 144-556 B of scratch at two waves per SIMD where the allocator had no AGPRs left; as many walkers as keep the radii at one
+// per lane -- at least one walker -- instead)
 constexpr int ff_adjtab_G(int n, int d) {
   const int M = n * d;
   if (M <= 0 || M > FF_WAVE) return 0;
   const int g = FF_WAVE / M > 16 ? 16 : FF_WAVE / M;
   if (M == 12) return FF_ADJ_G12;
-  if (d == 2 && (n == 4 || n == 5 || n == 7 || n == 9)) {
+  if (d == 2 && (n == 4 || n == 5 || n == 7 || n == 9 || n == 10 || n == 11)) {      // (measured: 8 and 12 particles are faster at 64 / M)
     const int gr = FF_WAVE / (n * (n + 1) / 2);
     return gr < 1 ? 1 : (gr < g ? gr : g);
   }
