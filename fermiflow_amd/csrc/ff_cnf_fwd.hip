@@ -59,6 +59,10 @@
 #ifndef FF_FLOW_WAVES
 #define FF_FLOW_WAVES 3      // waves per SIMD the tabulated flow kernel is compiled for (165 registers; 4: 128 + 140 B of scratch, 5: 95 + 280 B)
 #endif
+// instantiations whose step is laid out stage by stage (compile-time stages: DESIGN.md 3s)
+#ifndef FF_FWD_STATIC
+#define FF_FWD_STATIC(N, D, MODE, TAB) ((MODE) == 0 && (TAB) && (N) * (D) <= 12)
+#endif
 template <int N, int D, int MODE, bool TAB>
 __global__ void __launch_bounds__(FF_WAVE, (MODE == 0 && TAB && N * D <= 12) ? FF_FLOW_WAVES : FF_FWD_WAVES_PER_SIMD)
 ff_ode_fwd_kernel(ff_fwd_args A) {
@@ -226,8 +230,15 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       return (MODE == 2 && v >= 1) ? sens_w : 1.0;
     };
 
-#pragma unroll 1
-    for (;;) {
+    // One evaluation and what the Dormand-Prince step does with it, as a body that can be instantiated per stage (SG = 1 .. 6: the
+    // stage is a compile-time constant; FF_STAGE_DYN: the run-time value s).  Which instantiations lay their step out
+    // stage by stage is decided by FF_FWD_STATIC -- the others run this body in the loop over a run-time stage they always had.
+    // Returns true when every walker of the wave has finished.
+    constexpr bool STATIC_STAGES = FF_FWD_STATIC(N, D, MODE, TAB);
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN && STATIC_STAGES) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       // ------------------------------------------------------------------ stage input
       // The candidate state for stage s (a single wave-uniform switch; code size matters: the whole RHS loop has
       // to stay inside the 64 KB instruction cache that two CUs share).  Only the two published slots are formed
@@ -236,7 +247,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       // in = gy*y + g0*c0 + g1*c1 + g2*c2 with wave-uniform stage coefficients: one code path for all stages
       // (c1..c3 are zero-initialised, so unused terms are exact zeros)
       double gy = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
-      switch (s) {
+      switch (sv) {
         case -1: g0 = h0v * S.dir; break;
         case 1: g0 = h * FF_A10; break;
         case 2: g0 = h * FF_A20; g1 = h * FF_A21; break;
@@ -471,9 +482,9 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
       FF_STAMP(4);
       // ------------------------------------------------------------------ consume
 #if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
-      const int s_prev = s;
+      const int s_prev = sv;
 #endif
-      if (s == -2) {
+      if (sv == -2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         double p0 = 0.0, p1 = 0.0;
@@ -493,7 +504,7 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           S.plan();
           s = 1;
         }
-      } else if (s == -1) {
+      } else if (sv == -1) {
         double p2 = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -505,19 +516,19 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         if (warm) S.habs = fmin(hwarm, S.interval);
         S.plan();
         s = 1;
-      } else if (s == 0) {
+      } else if (sv == 0) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c0[v] = out[v];
         s = 1;
-      } else if (s == 1) {
+      } else if (sv == 1) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c1[v] = out[v];
         s = 2;
-      } else if (s == 2) {
+      } else if (sv == 2) {
 #pragma unroll
         for (int v = 0; v < NV; v++) c2[v] = out[v];
         s = 3;
-      } else if (s == 3) {
+      } else if (sv == 3) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           const double k0v = c0[v], k1v = c1[v], k2v = c2[v], k3v = out[v];
@@ -525,21 +536,24 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
           c1[v] = fma(h, FF_A50 * k0v + FF_A51 * k1v + FF_A52 * k2v + FF_A53 * k3v, y[v]);
           c2[v] = fma(h, FF_B0 * k0v + FF_B2 * k2v + FF_B3 * k3v, y[v]);
           c3[v] = h * (FF_E0 * k0v + FF_E2 * k2v + FF_E3 * k3v);
+          if constexpr (STATIC_STAGES) { FF_OPAQUE(c0[v]); FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]); }      // (not sunk into the stages that use them)
         }
         s = 4;
-      } else if (s == 4) {
+      } else if (sv == 4) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c1[v] = fma(h * FF_A54, out[v], c1[v]);
           c2[v] = fma(h * FF_B4, out[v], c2[v]);
           c3[v] = fma(h * FF_E4, out[v], c3[v]);
+          if constexpr (STATIC_STAGES) { FF_OPAQUE(c1[v]); FF_OPAQUE(c2[v]); }
         }
         s = 5;
-      } else if (s == 5) {
+      } else if (sv == 5) {
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           c2[v] = fma(h * FF_B5, out[v], c2[v]);
           c3[v] = fma(h * FF_E5, out[v], c3[v]);
+          if constexpr (STATIC_STAGES) { FF_OPAQUE(c2[v]); }
         }
         s = 6;
       } else {
@@ -561,13 +575,32 @@ ff_ode_fwd_kernel(ff_fwd_args A) {
         S.plan();
         // wave-wide: anybody still integrating?  anybody rejected (then everyone passes through stage 0)?
         const int any = ff_wave_or(&s_any, lane, S.done ? 0 : ((was_active && !acc) ? 3 : 1));
-        if (!any) break;
         s = (any & 2) ? 0 : 1;
+        if (!any) { FF_STAMP(5); return true; }
       }
 #if defined(FF_STAMPS) && defined(FF_STAMPS_TRACE)
       { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stage_acc[s_prev + 2] += t_ - stamp_prev; stage_cnt[s_prev + 2]++; }
 #endif
       FF_STAMP(5);
+      return false;
+    };
+    if constexpr (STATIC_STAGES) {
+#pragma unroll 1
+      for (;;) {
+#pragma unroll 1
+        while (s <= 0) evaluate(ff_stage_c<FF_STAGE_DYN>{});
+        evaluate(ff_stage_c<1>{});
+        evaluate(ff_stage_c<2>{});
+        evaluate(ff_stage_c<3>{});
+        evaluate(ff_stage_c<4>{});
+        evaluate(ff_stage_c<5>{});
+        if (evaluate(ff_stage_c<6>{})) break;
+      }
+    } else {
+#pragma unroll 1
+      for (;;) {
+        if (evaluate(ff_stage_c<FF_STAGE_DYN>{})) break;
+      }
     }
     // ---------------------------------------------------------------------- results
     if (A.wcost) {   // wave-uniform
