@@ -143,10 +143,14 @@ ff_wide_flow_kernel(ff_fwd_args A, int n) {
     auto wgt = [&](int v) -> double { return 1.0; };
     auto gsum = [&](double part) -> double { return ff_wide_sum<FF_WAVE>(s_red, s_red2, lane, part); };
 
-#pragma unroll 1
-    for (;;) {
+    // one evaluation, instantiated per stage for the table kernels; returns true when the walker has finished
+    constexpr bool STATIC_STAGES = TAB;
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN && STATIC_STAGES) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       double gy, g0, g1, g2;
-      ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
+      ff_dp5_coeffs(sv, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       __syncthreads();
       if (own) s_z[lane] = fma(g2, c2[0], fma(g1, c1[0], fma(g0, c0[0], gy * y[0])));
       __syncthreads();
@@ -196,8 +200,28 @@ ff_wide_flow_kernel(ff_fwd_args A, int n) {
         out[0] = vi;
         if constexpr (MODE == 1) out[1] = -dsum;
       }
-      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
-      if (s == 99) break;
+      s = ff_dp5_consume<NV>(sv, S, C, y, c0, c1, c2, c3, out, wgt, gsum);
+      return s == 99;
+    };
+    if constexpr (STATIC_STAGES) {
+#pragma unroll 1
+      for (;;) {
+        bool fin = false;
+#pragma unroll 1
+        while (s <= 0 && !fin) fin = evaluate(ff_stage_c<FF_STAGE_DYN>{});
+        if (fin) break;
+        evaluate(ff_stage_c<1>{});
+        evaluate(ff_stage_c<2>{});
+        evaluate(ff_stage_c<3>{});
+        evaluate(ff_stage_c<4>{});
+        evaluate(ff_stage_c<5>{});
+        if (evaluate(ff_stage_c<6>{})) break;
+      }
+    } else {
+#pragma unroll 1
+      for (;;) {
+        if (evaluate(ff_stage_c<FF_STAGE_DYN>{})) break;
+      }
     }
     // -------------------------------------------------------------------- results
     const bool failed = S.fail != 0;
