@@ -157,10 +157,13 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       }
     };
 
-#pragma unroll 1
-    for (;;) {
+    // one evaluation, instantiated per stage; returns true when the walker has finished
+    auto evaluate = [&](auto stage_tag) -> bool {
+      constexpr int SG = decltype(stage_tag)::value;
+      if constexpr (SG == FF_STAGE_DYN) FF_ASSUME(s <= 0);
+      const int sv = SG == FF_STAGE_DYN ? s : SG;
       double gy, g0, g1, g2;
-      ff_dp5_coeffs(s, S.h, C.h0v * S.dir, gy, g0, g1, g2);
+      ff_dp5_coeffs(sv, S.h, C.h0v * S.dir, gy, g0, g1, g2);
       __syncthreads();
       if (own) {
         s_z[rp] = fma(g2, c2[0], fma(g1, c1[0], fma(g0, c0[0], gy * y[0])));
@@ -221,7 +224,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       double out[NV] = {0.0, 0.0};
       if (own) { out[0] = vi; out[1] = fma(ad, gdi, -dvk); }
       // ------------------------------------------------------------------ this stage's share of the step's quadrature
-      const int s_was = s;
+      const int s_was = sv;
       const double h_was = S.h;
       const int nacc_was = S.nacc;
       if (s_was == 1) deposit(cur ^ 1, h_was * FF_B0);            // the step starts: its k0 records, now that h is known
@@ -229,7 +232,7 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
       else if (s_was == 3) deposit(cur, h_was * FF_B3);
       else if (s_was == 4) deposit(cur, h_was * FF_B4);
       else if (s_was == 5) deposit(cur, h_was * FF_B5);
-      s = ff_dp5_consume<NV>(s, S, C, y, c0, c1, c2, c3, out, wgt, gsum);      // (its reductions are workgroup barriers)
+      s = ff_dp5_consume<NV>(sv, S, C, y, c0, c1, c2, c3, out, wgt, gsum);      // (its reductions are workgroup barriers)
       if (s_was == -2 || s_was == 0) cur ^= 1;                      // f(y): these records are the step's k0
       if (s_was == 6) {
         const bool acc = S.nacc != nacc_was;                         // workgroup-uniform
@@ -256,7 +259,20 @@ ff_wide_adjtab_kernel(ff_adj_args A, int n) {
         if (lane == 0) s_novl = 0;
         if (acc) cur ^= 1;                                           // FSAL: the stage-6 records open the next step
       }
-      if (s == 99) break;
+      return s == 99;
+    };
+#pragma unroll 1
+    for (;;) {
+      bool fin = false;
+#pragma unroll 1
+      while (s <= 0 && !fin) fin = evaluate(ff_stage_c<FF_STAGE_DYN>{});
+      if (fin) break;
+      evaluate(ff_stage_c<1>{});
+      evaluate(ff_stage_c<2>{});
+      evaluate(ff_stage_c<3>{});
+      evaluate(ff_stage_c<4>{});
+      evaluate(ff_stage_c<5>{});
+      if (evaluate(ff_stage_c<6>{})) break;
     }
     const double bad = S.fail ? __builtin_nan("") : 0.0;   // failed integration -> NaN gradients
     if (own && A.gx_out) A.gx_out[b * M + rp] = y[1] + bad;
